@@ -1,0 +1,219 @@
+/*
+ * lgmi.h — C ABI of liblgmi.so: the MI355X (gfx950) pairwise mutual-information
+ * engine that replaces L-GIREMI's site-pair MI step.
+ *
+ * What each entry point replaces in the reference (gxiaolab/L-GIREMI v0.2.4,
+ * pure Python, paths relative to the reference root):
+ *
+ *   lgmi_run / lgmi_run_device
+ *       src/giremi/mutual_information.py:6-45   mismatch_pair_mutual_info()
+ *           (pair enumeration :10-12, common reads :15-20, allele->class :25-40,
+ *            sklearn.metrics.mutual_info_score :41, row assembly :42-45)
+ *       src/giremi/mismatch.py:392-396          het_snp pair filter (het_only=1)
+ *       src/giremi/mutual_information.py:48-60  mean_mismatch_pair_mutual_info()
+ *           (per-site mean of the kept rows; site_mean_mi / site_n_pairs)
+ *   lgmi_site_mean
+ *       src/giremi/mutual_information.py:48-60  for caller-supplied rows
+ *   permutation p-value (row_p / row_exceed)
+ *       no reference counterpart (BASELINE.json north_star asks for it; the
+ *       reference has no permutation test) — specified in DESIGN.md §5 and
+ *       restated on the CPU in oracle/lgmi_oracle.c.
+ *
+ * The reference has no FFI of its own (it is pure Python); the binding a
+ * maintainer would add is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no C++/torch types.
+ *   - every function returns 0 on success or a negative LGMI_E_* code; the
+ *     message is available from lgmi_last_error() (thread-local).
+ *   - inputs are borrowed (never written, must stay alive for the call);
+ *     results are library-owned and released by the matching *_free().
+ *   - the library never initialises HIP at load time (dlopen may precede a
+ *     fork); HIP is first touched in lgmi_device_count()/lgmi_ctx_create().
+ *   - there is no CPU fallback: without a usable gfx950 device
+ *     lgmi_ctx_create() fails with LGMI_E_NODEV.
+ */
+#ifndef LGMI_H
+#define LGMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGMI_ABI_VERSION 1
+
+/* error codes */
+#define LGMI_OK        0
+#define LGMI_E_ARG    -1   /* bad argument / malformed batch            */
+#define LGMI_E_OOM    -2   /* host or device allocation failed          */
+#define LGMI_E_HIP    -3   /* HIP runtime error                         */
+#define LGMI_E_RCCL   -4   /* RCCL error                                */
+#define LGMI_E_NODEV  -5   /* no usable GPU                             */
+#define LGMI_E_STATE  -6   /* call made in the wrong state              */
+#define LGMI_E_DOMAIN -7   /* a pair with 0 common reads reached the MI
+                              (min_common == 0): the reference raises
+                              ValueError('math domain error') there     */
+
+/* site types (mismatch.py:29-44, :326-340) */
+#define LGMI_TYPE_MISMATCH 0
+#define LGMI_TYPE_SNP      1
+#define LGMI_TYPE_HET_SNP  2
+
+/* 2-bit allele-class code of one read at one site, stored as two bit planes
+ * (bit r%64 of word r/64):   hi lo
+ *    not covered              0  0
+ *    class 1 (minor allele)   0  1      mutual_information.py:35,38
+ *    class 2 (major allele)   1  0      mutual_information.py:36,39
+ *    class 0 (any other)      1  1      defaultdict(int), :34,:37          */
+
+/*
+ * lgmi_batch — the packed read x site allele matrix ("LGB" blocks).
+ * A block is one (footprint, strand): pairs never cross blocks
+ * (mismatch.py:387-391). Sites of a block are sorted by position; reads of a
+ * block are numbered 0..block_n_reads-1; each site stores only the band of
+ * 64-read words [word_off, word_off+n_words) that can contain covered reads.
+ * planes[plane_off .. plane_off+n_words)            = lo plane of the band
+ * planes[plane_off+n_words .. plane_off+2*n_words)  = hi plane of the band
+ * Bits beyond block_n_reads in the last word must be zero.
+ */
+typedef struct lgmi_batch {
+    uint64_t n_blocks;
+    uint64_t n_sites;                 /* == block_site_begin[n_blocks]        */
+    uint64_t n_plane_words;           /* length of planes[] in 64-bit words   */
+    const uint64_t* block_site_begin; /* [n_blocks+1] first site of each block */
+    const uint32_t* block_n_reads;    /* [n_blocks]                            */
+    const int64_t*  site_pos;         /* [n_sites] strictly increasing / block */
+    const uint8_t*  site_type;        /* [n_sites] LGMI_TYPE_*                 */
+    const uint32_t* site_word_off;    /* [n_sites]                             */
+    const uint32_t* site_n_words;     /* [n_sites]                             */
+    const uint64_t* site_plane_off;   /* [n_sites]                             */
+    const uint64_t* planes;           /* [n_plane_words]                       */
+} lgmi_batch;
+
+typedef struct lgmi_params {
+    uint32_t min_common;   /* mutual_information.py:19 (library default 5, CLI 6) */
+    uint32_t n_shuffles;   /* S; 0 = no permutation p (row_p = NaN)               */
+    uint64_t seed;         /* Philox key for the permutation draws                */
+    uint8_t  het_only;     /* 1: only pairs with >=1 het_snp side (mismatch.py:392-396);
+                              0: all P(P-1)/2 pairs (mutual_information.py:12)   */
+    uint8_t  emit_counts;  /* 1: fill row_counts (3x3 table per row)              */
+    uint8_t  reserved[6];  /* must be 0 */
+} lgmi_params;
+
+/*
+ * lgmi_result — rows in reference order: block, then combinations() order of
+ * the sorted positions (i < j). Site indices are GLOBAL (into the batch's site
+ * arrays). row_counts[9*r + 3*a + b] = #common reads with class a at site i
+ * and class b at site j (a, b in 0,1,2). site_mean_mi[s] is NaN and
+ * site_n_pairs[s] 0 for a site that appears in no row.
+ */
+typedef struct lgmi_result {
+    uint64_t n_rows;
+    uint64_t n_sites;
+    const uint32_t* row_i;
+    const uint32_t* row_j;
+    const double*   row_mi;
+    const double*   row_p;        /* NULL when n_shuffles == 0 */
+    const uint32_t* row_exceed;   /* NULL when n_shuffles == 0 */
+    const uint32_t* row_counts;   /* NULL unless emit_counts   */
+    const double*   site_mean_mi; /* [n_sites] */
+    const uint32_t* site_n_pairs; /* [n_sites] */
+    void* owner_;                 /* private */
+} lgmi_result;
+
+/* figures of one run: work done and HIP-event time of each stage (ms), taken
+ * on the stream the kernels were launched on */
+typedef struct lgmi_run_info {
+    uint64_t n_rows;        /* emitted pairs M                                     */
+    uint64_t n_examined;    /* examined pairs E (het-involved, or all)   */
+    uint64_t n_tile_pairs;  /* pairs inside the tiles the count kernel computed    */
+    uint64_t word_pairs;    /* sum over examined pairs of overlapping 64-bit words */
+    uint64_t bytes_in;      /* algorithmic input bytes (planes once + site meta)   */
+    uint64_t bytes_out;     /* algorithmic output bytes (rows)                     */
+    float ms_total;
+    float ms_prep;          /* band/class prep + tile list                         */
+    float ms_count;         /* pair co-occurrence count kernel                     */
+    float ms_emit;          /* validity scan + MI + ordered row emission           */
+    float ms_perm;          /* permutation p-values                                */
+    float ms_mean;          /* per-site mean MI                                    */
+    uint32_t n_count_launches;
+    uint32_t reserved;
+} lgmi_run_info;
+
+/* device-side synthetic chromosome generator (SURVEY 8d "dense" regime):
+ * one block of n_sites x n_reads, every read spans every site, per-(site,read)
+ * dropout, haplotype-linked het SNPs every het_every-th site, independent
+ * mismatch sites elsewhere, a third allele on tri_per_1024/1024 of the sites. */
+typedef struct lgmi_synth_spec {
+    uint64_t seed;
+    uint32_t n_sites;
+    uint32_t n_reads;
+    uint32_t het_every;      /* site s is het_snp iff s % het_every == 0 (5)      */
+    uint32_t dropout_u16;    /* P(read does not cover site) * 65536   (6554)       */
+    uint32_t het_noise_u16;  /* P(het allele != haplotype) * 65536    (1311)       */
+    uint32_t tri_per_1024;   /* sites with a third allele, per 1024   (20)         */
+    uint32_t tri_frac_u16;   /* P(third allele | covered) * 65536     (3277)       */
+    uint32_t snp_per_1024;   /* non-het sites typed 'snp', per 1024   (10)         */
+} lgmi_synth_spec;
+
+typedef struct lgmi_ctx     lgmi_ctx;     /* one device, one stream, workspace */
+typedef struct lgmi_dbatch  lgmi_dbatch;  /* a batch resident in HBM           */
+typedef struct lgmi_dresult lgmi_dresult; /* result rows resident in HBM       */
+
+int         lgmi_abi_version(void);
+const char* lgmi_last_error(void);
+int         lgmi_device_count(int* out_count);
+
+int  lgmi_ctx_create(int device_id, lgmi_ctx** out);
+void lgmi_ctx_destroy(lgmi_ctx* ctx);
+
+/* host -> HBM (validates the batch) */
+int  lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* batch, lgmi_dbatch** out);
+/* synthetic dense chromosome generated directly in HBM */
+int  lgmi_synth_dense(lgmi_ctx* ctx, const lgmi_synth_spec* spec, lgmi_dbatch** out);
+/* HBM -> host copy of a resident batch; arrays are owned by the dbatch and
+ * stay valid until lgmi_dbatch_free() */
+int  lgmi_dbatch_download(lgmi_dbatch* db, lgmi_batch* out);
+void lgmi_dbatch_free(lgmi_dbatch* db);
+
+/* the hot path on a resident batch; rows stay in HBM */
+int  lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm,
+                     lgmi_dresult** out);
+int  lgmi_dresult_info(const lgmi_dresult* dr, lgmi_run_info* out);
+/* raw device pointers of a resident result (for RCCL / zero-copy consumers) */
+int  lgmi_dresult_device_ptrs(const lgmi_dresult* dr, lgmi_result* out_device_view);
+/* HBM -> host; the host arrays live until lgmi_result_free(out) */
+int  lgmi_dresult_fetch(lgmi_dresult* dr, lgmi_result* out);
+void lgmi_dresult_free(lgmi_dresult* dr);
+
+/* upload + run + fetch in one call (what the Python drop-ins use) */
+int  lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_params* prm,
+              lgmi_result* out, lgmi_run_info* info_or_null);
+void lgmi_result_free(lgmi_result* res);
+
+/* per-site mean of caller-supplied rows (mutual_information.py:48-60):
+ * mean_out[s] = mean of mi[r] over rows with row_i[r]==s or row_j[r]==s,
+ * NaN / n_out 0 when the site is in no row. */
+int  lgmi_site_mean(lgmi_ctx* ctx, uint64_t n_rows, const uint32_t* row_i,
+                    const uint32_t* row_j, const double* row_mi, uint64_t n_sites,
+                    double* mean_out, uint32_t* n_out);
+
+/* ---- multi-GPU: one process per GPU, RCCL used only for the final gather ---- */
+#define LGMI_UNIQUE_ID_BYTES 128
+int  lgmi_comm_unique_id(void* out128);                 /* rank 0 creates, host broadcasts */
+int  lgmi_comm_init(lgmi_ctx* ctx, const void* id128, int rank, int world);
+/* all-gather of one u64 per rank (row counts) over RCCL */
+int  lgmi_comm_allgather_u64(lgmi_ctx* ctx, uint64_t mine, uint64_t* out_world);
+/* gather every rank's rows (row_i,row_j,row_mi[,row_p]) to rank `root` in rank
+ * order; on root `out` is a host-resident concatenation, elsewhere n_rows = 0 */
+int  lgmi_comm_gather_rows(lgmi_ctx* ctx, const lgmi_dresult* mine, int root,
+                           lgmi_result* out);
+void lgmi_comm_destroy(lgmi_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGMI_H */

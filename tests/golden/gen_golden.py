@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    python3 -B tests/golden/gen_golden.py            # rewrites tests/golden/*.json
+
+The reference (gxiaolab/L-GIREMI, /root/reference, read-only) is imported by file
+path — `import giremi` fails because the dist is not pip-installed
+(src/giremi/__init__.py:3) — and driven with synthetic `mismatches` dicts built
+here.  Only DATA leaves this script: inputs and the reference's outputs.  The
+3x3 tables are captured from the label vectors the reference hands to
+sklearn.metrics.mutual_info_score (mutual_information.py:41), by wrapping that
+one name in the imported module.
+
+/root/reference does not exist on the GPU box; tests read the JSON only.
+"""
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/src/giremi'
+NTS = 'ACGT'
+
+
+def load_ref(name):
+    spec = importlib.util.spec_from_file_location('ref_' + name, os.path.join(REF, name + '.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref_mi = load_ref('mutual_information')
+ref_stat = load_ref('stat')
+
+_captured = []
+_orig_mis = ref_mi.mutual_info_score
+
+
+def _recording_mis(l1, l2):
+    t = [0] * 9
+    for a, b in zip(l1, l2):
+        t[3 * a + b] += 1
+    _captured.append(t)
+    return _orig_mis(l1, l2)
+
+
+ref_mi.mutual_info_score = _recording_mis
+
+
+def run_ref(mismatches, min_common):
+    _captured.clear()
+    rows = ref_mi.mismatch_pair_mutual_info(mismatches, min_common_reads=min_common)
+    tables = [list(t) for t in _captured]
+    assert len(tables) == len(rows)
+    het = [r for r in rows if r[1] == 'het_snp' or r[3] == 'het_snp']
+    mean_all = ref_mi.mean_mismatch_pair_mutual_info(rows) if rows else []
+    mean_het = ref_mi.mean_mismatch_pair_mutual_info(het) if het else []
+    return rows, tables, mean_all, mean_het
+
+
+def site(type_, alleles):
+    """alleles: list of (nt, [read names]) in insertion order; depth = list lengths."""
+    return {'ref': alleles[0][0], 'type': type_,
+            'depth': {nt: len(names) for nt, names in alleles},
+            'nt': {nt: list(names) for nt, names in alleles},
+            'neighbor': {}, 'up': 'A', 'down': 'C'}
+
+
+def ser_mismatches(mm):
+    return [[int(pos), s['type'], [[nt, int(d)] for nt, d in s['depth'].items()],
+             [[nt, list(names)] for nt, names in s['nt'].items()]]
+            for pos, s in mm.items()]
+
+
+def case(name, mm, min_common):
+    rows, tables, mean_all, mean_het = run_ref(mm, min_common)
+    return {'name': name, 'min_common': min_common, 'sites': ser_mismatches(mm),
+            'rows': [[int(r[0]), r[1], int(r[2]), r[3], float(r[4])] for r in rows],
+            'tables': tables,
+            'mean_all': [[int(a), float(b)] for a, b in mean_all],
+            'mean_het': [[int(a), float(b)] for a, b in mean_het]}
+
+
+def R(prefix, idx):
+    return ['%s%d' % (prefix, i) for i in idx]
+
+
+def edge_cases():
+    out = []
+    r = lambda a, b: R('r', range(a, b))
+    # 2-allele x 2-allele, partial and perfect linkage
+    mm = {100: site('het_snp', [('A', r(0, 10)), ('G', r(10, 20))]),
+          200: site('mismatch', [('A', r(0, 7) + r(10, 14)), ('G', r(7, 10) + r(14, 20))]),
+          300: site('mismatch', [('C', r(0, 10)), ('T', r(10, 20))])}
+    out.append(case('two_allele_linkage', mm, 5))
+    # a 3-allele site (3x2 and 3x3 tables)
+    mm = {10: site('het_snp', [('A', r(0, 12)), ('G', r(12, 21)), ('T', r(21, 27))]),
+          20: site('mismatch', [('C', r(0, 5) + r(12, 18) + r(21, 23)), ('T', r(5, 12) + r(18, 21) + r(23, 27))]),
+          30: site('snp', [('A', r(0, 9) + r(21, 24)), ('C', r(9, 15)), ('G', r(15, 21) + r(24, 27))])}
+    out.append(case('three_allele', mm, 5))
+    # one site monomorphic among the COMMON reads -> exactly 0.0, row still emitted
+    mm = {10: site('het_snp', [('A', r(0, 8)), ('G', r(8, 16))]),
+          30: site('mismatch', [('C', r(0, 8)), ('T', r(20, 30))])}
+    out.append(case('monomorphic_in_common', mm, 5))
+    # common reads below the threshold -> pair skipped
+    mm = {10: site('het_snp', [('A', r(0, 8)), ('G', r(8, 16))]),
+          30: site('mismatch', [('C', r(0, 2)), ('T', r(14, 16) + r(20, 30))]),
+          40: site('mismatch', [('C', r(0, 3)), ('T', r(13, 16) + r(20, 30))])}
+    out.append(case('below_min_common', mm, 6))
+    out.append(case('below_min_common_mc1', mm, 1))
+    # a read listed under two alleles of one site: the last allele in nt order wins
+    mm = {10: site('het_snp', [('A', r(0, 8)), ('G', r(6, 16))]),
+          30: site('mismatch', [('C', r(0, 5) + r(10, 13)), ('T', r(5, 10) + r(13, 16))])}
+    out.append(case('duplicate_read_last_allele_wins', mm, 5))
+    # depth ties with 4 alleles: stable sort on depth decides which two fall to class 0
+    mm = {10: site('mismatch', [('A', r(0, 6)), ('C', r(6, 12)), ('G', r(12, 18)), ('T', r(18, 24))]),
+          20: site('het_snp', [('A', r(0, 3) + r(6, 9) + r(12, 15) + r(18, 21)),
+                               ('G', r(3, 6) + r(9, 12) + r(15, 18) + r(21, 24))]),
+          25: site('het_snp', [('T', r(0, 4) + r(12, 20)), ('C', r(4, 12) + r(20, 24))])}
+    out.append(case('depth_ties_four_alleles', mm, 5))
+    # depth dict that disagrees with the nt lists (ranking follows depth, not len(nt))
+    s = site('mismatch', [('A', r(0, 9)), ('G', r(9, 14)), ('T', r(14, 20))])
+    s['depth'] = {'A': 2, 'G': 50, 'T': 7}
+    mm = {5: s, 9: site('het_snp', [('C', r(0, 4) + r(9, 12) + r(14, 17)), ('T', r(4, 9) + r(12, 14) + r(17, 20))])}
+    out.append(case('depth_dict_overrides', mm, 5))
+    # allele present in nt but absent from depth -> class 0
+    s = site('mismatch', [('A', r(0, 9)), ('G', r(9, 14)), ('T', r(14, 20))])
+    s['depth'] = {'A': 9, 'G': 5}
+    mm = {5: s, 9: site('het_snp', [('C', r(0, 4) + r(9, 12) + r(14, 17)), ('T', r(4, 9) + r(12, 14) + r(17, 20))])}
+    out.append(case('allele_missing_from_depth', mm, 5))
+    # single site / empty -> no rows
+    out.append(case('single_site', {7: site('het_snp', [('A', r(0, 8)), ('G', r(8, 16))])}, 5))
+    out.append(case('empty', {}, 5))
+    # exactly min_common common reads; n words boundary 64/65 reads
+    mm = {1: site('het_snp', [('A', r(0, 32)), ('G', r(32, 64))]),
+          2: site('mismatch', [('A', r(0, 20) + r(32, 40)), ('G', r(20, 32) + r(40, 65))]),
+          3: site('mismatch', [('C', r(59, 62)), ('T', r(62, 65))])}
+    out.append(case('word_boundary_64_65', mm, 5))
+    # perfectly linked het pair, big counts
+    mm = {1: site('het_snp', [('A', r(0, 500)), ('G', r(500, 1000))]),
+          2: site('het_snp', [('C', r(0, 500)), ('T', r(500, 1000))]),
+          3: site('mismatch', [('C', r(0, 1000, )[::2]), ('T', r(0, 1000)[1::2])])}
+    out.append(case('perfect_linkage_1000', mm, 5))
+    return out
+
+
+def random_block(rng, n_sites, n_reads, max_alleles, cover, het_frac=0.3):
+    names = R('q', range(n_reads))
+    order = rng.permutation(n_reads)
+    names = [names[i] for i in order]  # first-seen order differs from sorted order
+    hap = rng.integers(0, 2, n_reads)
+    mm = {}
+    pos = 1000
+    for _s in range(n_sites):
+        pos += int(rng.integers(1, 60))
+        k = int(rng.integers(2, max_alleles + 1))
+        covered = np.nonzero(rng.random(n_reads) < cover)[0]
+        if len(covered) < 2:
+            covered = np.arange(min(n_reads, 4))
+        is_het = rng.random() < het_frac
+        if is_het:
+            al = (hap[covered] ^ (rng.random(len(covered)) < 0.05)).astype(int)
+            if k > 2:
+                third = rng.random(len(covered)) < 0.1
+                al = np.where(third, rng.integers(2, k, len(covered)), al)
+        else:
+            p = rng.dirichlet(np.ones(k) * 1.5)
+            al = rng.choice(k, size=len(covered), p=p)
+        nts = list(rng.permutation(list(NTS))[:k])
+        alleles = []
+        for a in range(k):
+            members = [names[i] for i in covered[al == a]]
+            if members:
+                alleles.append((nts[a], members))
+        if len(alleles) < 2:
+            half = len(covered) // 2
+            alleles = [(nts[0], [names[i] for i in covered[:half]]),
+                       (nts[1], [names[i] for i in covered[half:]])]
+        t = 'het_snp' if is_het else ('snp' if rng.random() < 0.1 else 'mismatch')
+        mm[pos] = site(t, alleles)
+    return mm
+
+
+def random_cases():
+    out = []
+    rng = np.random.Generator(np.random.PCG64(20250808))
+    for i in range(40):
+        n_sites = int(rng.integers(2, 41))
+        n_reads = int(rng.integers(6, 301))
+        max_alleles = int(rng.integers(2, 5))
+        cover = float(rng.uniform(0.15, 1.0))
+        mc = int(rng.choice([1, 5, 6, 20]))
+        mm = random_block(rng, n_sites, n_reads, max_alleles, cover)
+        out.append(case('random_%02d_P%d_R%d_A%d_mc%d' % (i, n_sites, n_reads, max_alleles, mc), mm, mc))
+    return out
+
+
+def banded_block(seed, n_sites, n_reads, mean_span=20):
+    """cfg1-like: reads sorted by start, each spans a window of sites."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    start = np.sort(rng.integers(0, n_sites, n_reads))
+    span = 1 + rng.geometric(1.0 / mean_span, n_reads)
+    hap = rng.integers(0, 2, n_reads)
+    lists = {}
+    for s in range(n_sites):
+        is_het = (s % 5 == 0)
+        e = rng.uniform(0.05, 0.5)
+        tri = rng.random() < 0.02
+        cov = np.nonzero((start <= s) & (s < start + span) & (rng.random(n_reads) >= 0.10))[0]
+        if is_het:
+            al = hap[cov] ^ (rng.random(len(cov)) < 0.02)
+        else:
+            al = (rng.random(len(cov)) < e).astype(int)
+        if tri:
+            al = np.where(rng.random(len(cov)) < 0.05, 2, al)
+        groups = [(nt, ['b%d' % i for i in cov[al == a]]) for a, nt in enumerate('AGT')]
+        tot = sum(len(g[1]) for g in groups)
+        groups = [g for g in groups if len(g[1]) >= 3 and len(g[1]) / max(tot, 1) >= 0.05]
+        if len(groups) < 2:
+            continue
+        t = 'het_snp' if is_het else ('snp' if rng.random() < 0.01 else 'mismatch')
+        lists[10_000 + 37 * s] = site(t, groups)
+    return lists
+
+
+def time_reference(out_path):
+    """wall time of the reference's own MI step, this container."""
+    res = {'host': '8 vCPU Intel Xeon @ 2.10GHz container', 'python': sys.version.split()[0]}
+    import sklearn
+    res['sklearn'] = sklearn.__version__
+    blocks = []
+    mm = banded_block(20250809, 500, 2000)
+    t0 = time.perf_counter()
+    rows = _orig_call(mm, 6)
+    dt = time.perf_counter() - t0
+    p = len(mm)
+    blocks.append({'block': 'cfg1 banded 500x2000 (%d sites kept)' % p, 'pairs_examined': p * (p - 1) // 2,
+                   'pairs_emitted': len(rows), 'wall_s': dt})
+    rng = np.random.Generator(np.random.PCG64(7))
+    mm = random_block(rng, 60, 2000, 2, 0.8)
+    t0 = time.perf_counter()
+    rows = _orig_call(mm, 6)
+    dt = time.perf_counter() - t0
+    blocks.append({'block': 'dense 60x2000 cover 0.8', 'pairs_examined': 60 * 59 // 2,
+                   'pairs_emitted': len(rows), 'wall_s': dt})
+    res['blocks'] = blocks
+    with open(out_path, 'w') as f:
+        json.dump(res, f, indent=1)
+
+
+def _orig_call(mm, mc):
+    ref_mi.mutual_info_score = _orig_mis
+    try:
+        return ref_mi.mismatch_pair_mutual_info(mm, min_common_reads=mc)
+    finally:
+        ref_mi.mutual_info_score = _recording_mis
+
+
+def ecdf_cases():
+    rng = np.random.Generator(np.random.PCG64(99))
+    out = []
+    for n in (1, 4, 50):
+        sample = [float(x) for x in np.round(rng.random(n), 3)]
+        f = ref_stat.ecdf(sample)
+        q = sample + [0.0, 1.0, 0.5, -1.0, 2.0]
+        out.append({'sample': sample, 'query': q, 'value': [float(f(v)) for v in q]})
+    return out
+
+
+def main():
+    import sklearn
+    import scipy
+    meta = {'reference': 'gxiaolab/L-GIREMI v0.2.4 imported by file path',
+            'sklearn': sklearn.__version__, 'numpy': np.__version__, 'scipy': scipy.__version__}
+    with open(os.path.join(HERE, 'pairs_edge.json'), 'w') as f:
+        json.dump({'meta': meta, 'cases': edge_cases()}, f)
+    with open(os.path.join(HERE, 'pairs_random.json'), 'w') as f:
+        json.dump({'meta': meta, 'cases': random_cases()}, f)
+    mm = banded_block(20250809, 500, 2000)
+    with open(os.path.join(HERE, 'pairs_banded_cfg1.json'), 'w') as f:
+        json.dump({'meta': meta, 'cases': [case('cfg1_banded_500x2000', mm, 6)]}, f)
+    with open(os.path.join(HERE, 'ecdf.json'), 'w') as f:
+        json.dump({'meta': meta, 'cases': ecdf_cases()}, f)
+    if '--time' in sys.argv:
+        time_reference(os.path.join(HERE, 'reference_timing.json'))
+
+
+if __name__ == '__main__':
+    main()
