@@ -1,0 +1,120 @@
+// lgmi_internal.h — device data layout and kernel launchers shared by the HIP
+// translation units of liblgmi.so.  Not part of the public ABI (include/lgmi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lgmi.h"
+
+namespace lgmi {
+
+// ---------------------------------------------------------------- layout in HBM
+//
+// A *column* is what the count kernel pairs up: a real site (coverage plane C,
+// allele plane A = reads of class 2) or, for a site that has class-0 reads
+// ("tri" site), an extra pseudo column (C, A = reads of class 1).  Real site s
+// is column s; pseudo columns follow at n_sites .. n_cols-1.
+// cplanes holds, per column, the band's words interleaved as (C_k, A_k) pairs so
+// that one 16-byte load/LDS read brings both planes of 64 reads.
+struct Col {
+    uint64_t off;   // index (in 16-byte pairs) of the band's first word in cplanes
+    uint32_t w0;    // first 64-read word of the band
+    uint32_t nw;    // words in the band
+};
+
+// per-block plan entry (built on the host for every run, depends on het_only)
+struct BlockPlan {
+    uint64_t slot_base;  // first slot of the block's nx x ny_pad slot matrix
+    uint32_t xl_off;     // offset of the block's x list in xlist[]
+    uint32_t yl_off;     // offset of the block's y list in ylist[]
+    uint32_t nx;         // rows: x sites then pseudo rows of tri x sites
+    uint32_t ny;         // cols: non-x sites, x sites, pseudo cols of tri sites
+    uint32_t ny_pad;     // row stride of the slot matrix (multiple of 4)
+    uint32_t nxs;        // number of real x sites (prefix of the x list)
+    uint32_t site_begin; // first global site of the block
+    uint32_t site_end;
+};
+
+// one 64 x 64 tile of a block's slot matrix and the word range it must sweep
+struct Tile {
+    uint32_t block;
+    uint32_t x0;   // first row (index into the block's x list)
+    uint32_t y0;   // first col (index into the block's y list)
+    uint32_t k0;   // word range [k0, k1) — intersection of the two union bands
+    uint32_t k1;
+};
+
+// per-site lookup used by the emit kernels
+struct SiteMap {
+    uint32_t xrow;   // row of the site in its block's slot matrix, or NONE
+    uint32_t ycol;   // col of the site
+    uint32_t prow;   // pseudo row (tri site that is an x site), or NONE
+    uint32_t pcol;   // pseudo col (tri site), or NONE
+    uint32_t xnext;  // number of real x sites of the block with index <= this site
+    uint32_t block;
+};
+static const uint32_t NONE = 0xFFFFFFFFu;
+
+static const int TILE = 64;      // tile edge in columns
+static const int KC = 8;         // 64-bit words staged per LDS stage
+static const double MEAN_SCALE = 1099511627776.0;  // 2^40 fixed point for mean MI
+
+struct DevBatch {  // what lgmi_dbatch owns on the device
+    uint64_t n_blocks = 0, n_sites = 0, n_cols = 0, n_pairs16 = 0;
+    int64_t*  d_pos = nullptr;
+    uint8_t*  d_type = nullptr;
+    uint8_t*  d_tri = nullptr;       // [n_sites] 1 when the site has class-0 reads
+    Col*      d_cols = nullptr;      // [n_cols]
+    ulonglong2* d_cplanes = nullptr; // [n_pairs16]
+};
+
+// ---------------------------------------------------------------- launchers
+// count.hip
+void launch_count(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
+                  const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
+                  const ulonglong2* cplanes, uint32_t* sN, uint32_t* sR, uint32_t* sC, uint32_t* sA);
+
+// emit.hip
+struct EmitArgs {
+    uint32_t n_sites;
+    uint32_t min_common;
+    int het_only;
+    const BlockPlan* plans;
+    const SiteMap* smap;
+    const uint32_t* xlist;
+    const Col* cols;
+    const uint8_t* type;
+    const uint8_t* tri;
+    const uint32_t* sN; const uint32_t* sR; const uint32_t* sC; const uint32_t* sA;
+    uint32_t* row_cnt;        // [n_sites]   pass 1 out
+    const uint64_t* row_start;// [n_sites+1] pass 2 in
+    uint32_t* out_i; uint32_t* out_j; double* out_mi; uint32_t* out_counts; // pass 2 out
+    unsigned long long* site_sum; uint32_t* site_cnt;  // [n_sites] fixed-point sums
+    int* err_flag;            // set to 1 when a pair with N == 0 reaches the MI
+    unsigned long long* word_pairs;  // pass 1: sum over examined pairs of overlapping words
+};
+void launch_emit_count(hipStream_t st, const EmitArgs& a);
+void launch_scan(hipStream_t st, const uint32_t* cnt, uint64_t* start, uint32_t n);
+void launch_emit_write(hipStream_t st, const EmitArgs& a);
+void launch_site_mean(hipStream_t st, uint32_t n_sites, const unsigned long long* sum,
+                      const uint32_t* cnt, double* mean);
+void launch_rows_mean(hipStream_t st, uint64_t n_rows, const uint32_t* ri, const uint32_t* rj,
+                      const double* mi, unsigned long long* sum, uint32_t* cnt);
+
+// perm.hip
+void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const uint32_t* out_j,
+                 const uint32_t* counts, const double* nlogn, uint32_t nlogn_len,
+                 uint32_t n_shuffles, uint64_t seed, double* out_p, uint32_t* out_exceed);
+
+// synth.hip: layout prep for uploaded batches and the dense synthetic generator
+void launch_tri_flags(hipStream_t st, uint32_t n_sites, const uint32_t* site_nw,
+                      const uint64_t* site_plane_off, const uint64_t* planes, uint8_t* tri);
+// column c (real: site c; pseudo: col_site[c - n_sites]) <- (C, A) pairs from lo/hi planes
+void launch_prep_cols(hipStream_t st, uint32_t n_cols, uint32_t n_sites, const Col* cols,
+                      const uint32_t* pseudo_site, const uint64_t* site_plane_off,
+                      const uint64_t* planes, ulonglong2* cplanes);
+void launch_synth_depth(hipStream_t st, const lgmi_synth_spec& sp, uint32_t W, uint32_t* depth3);
+void launch_synth_write(hipStream_t st, const lgmi_synth_spec& sp, uint32_t W, const uint32_t* depth3,
+                        const uint32_t* pseudo_of_site, ulonglong2* cplanes);
+
+}  // namespace lgmi

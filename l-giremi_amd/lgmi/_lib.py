@@ -1,0 +1,115 @@
+"""ctypes binding of liblgmi.so (include/lgmi.h) — the only way the Python host
+reaches the HIP kernels.  No torch, no fallback: if the shared library is missing
+or no MI355X is usable, calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('LGMI_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'liblgmi.so'))
+
+ABI_VERSION = 1
+OK, E_ARG, E_OOM, E_HIP, E_RCCL, E_NODEV, E_STATE, E_DOMAIN = 0, -1, -2, -3, -4, -5, -6, -7
+TYPE_MISMATCH, TYPE_SNP, TYPE_HET_SNP = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+
+u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+i64p, f64p = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+
+
+class Batch(C.Structure):
+    _fields_ = [('n_blocks', C.c_uint64), ('n_sites', C.c_uint64), ('n_plane_words', C.c_uint64),
+                ('block_site_begin', u64p), ('block_n_reads', u32p), ('site_pos', i64p),
+                ('site_type', u8p), ('site_word_off', u32p), ('site_n_words', u32p),
+                ('site_plane_off', u64p), ('planes', u64p)]
+
+
+class Params(C.Structure):
+    _fields_ = [('min_common', C.c_uint32), ('n_shuffles', C.c_uint32), ('seed', C.c_uint64),
+                ('het_only', C.c_uint8), ('emit_counts', C.c_uint8), ('reserved', C.c_uint8 * 6)]
+
+
+class Result(C.Structure):
+    _fields_ = [('n_rows', C.c_uint64), ('n_sites', C.c_uint64), ('row_i', u32p), ('row_j', u32p),
+                ('row_mi', f64p), ('row_p', f64p), ('row_exceed', u32p), ('row_counts', u32p),
+                ('site_mean_mi', f64p), ('site_n_pairs', u32p), ('owner_', C.c_void_p)]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [('n_rows', C.c_uint64), ('n_examined', C.c_uint64), ('n_tile_pairs', C.c_uint64),
+                ('word_pairs', C.c_uint64), ('bytes_in', C.c_uint64), ('bytes_out', C.c_uint64),
+                ('ms_total', C.c_float), ('ms_prep', C.c_float), ('ms_count', C.c_float),
+                ('ms_emit', C.c_float), ('ms_perm', C.c_float), ('ms_mean', C.c_float),
+                ('n_count_launches', C.c_uint32), ('reserved', C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('n_sites', C.c_uint32), ('n_reads', C.c_uint32),
+                ('het_every', C.c_uint32), ('dropout_u16', C.c_uint32), ('het_noise_u16', C.c_uint32),
+                ('tri_per_1024', C.c_uint32), ('tri_frac_u16', C.c_uint32), ('snp_per_1024', C.c_uint32)]
+
+
+class LgmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('liblgmi error %d: %s' % (code, msg))
+        self.code = code
+
+
+# every exported symbol of include/lgmi.h: name -> (restype, argtypes)
+VP = C.c_void_p
+SYMBOLS = {
+    'lgmi_abi_version': (C.c_int, []),
+    'lgmi_last_error': (C.c_char_p, []),
+    'lgmi_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'lgmi_ctx_create': (C.c_int, [C.c_int, C.POINTER(VP)]),
+    'lgmi_ctx_destroy': (None, [VP]),
+    'lgmi_batch_upload': (C.c_int, [VP, C.POINTER(Batch), C.POINTER(VP)]),
+    'lgmi_synth_dense': (C.c_int, [VP, C.POINTER(SynthSpec), C.POINTER(VP)]),
+    'lgmi_dbatch_download': (C.c_int, [VP, C.POINTER(Batch)]),
+    'lgmi_dbatch_free': (None, [VP]),
+    'lgmi_run_device': (C.c_int, [VP, VP, C.POINTER(Params), C.POINTER(VP)]),
+    'lgmi_dresult_info': (C.c_int, [VP, C.POINTER(RunInfo)]),
+    'lgmi_dresult_device_ptrs': (C.c_int, [VP, C.POINTER(Result)]),
+    'lgmi_dresult_fetch': (C.c_int, [VP, C.POINTER(Result)]),
+    'lgmi_dresult_free': (None, [VP]),
+    'lgmi_run': (C.c_int, [VP, C.POINTER(Batch), C.POINTER(Params), C.POINTER(Result), C.POINTER(RunInfo)]),
+    'lgmi_result_free': (None, [C.POINTER(Result)]),
+    'lgmi_site_mean': (C.c_int, [VP, C.c_uint64, u32p, u32p, f64p, C.c_uint64, f64p, u32p]),
+    'lgmi_comm_unique_id': (C.c_int, [VP]),
+    'lgmi_comm_init': (C.c_int, [VP, VP, C.c_int, C.c_int]),
+    'lgmi_comm_allgather_u64': (C.c_int, [VP, C.c_uint64, u64p]),
+    'lgmi_comm_gather_rows': (C.c_int, [VP, VP, C.c_int, C.POINTER(Result)]),
+    'lgmi_comm_destroy': (None, [VP]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen liblgmi.so and bind every symbol; raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('liblgmi.so not found at %s — build it with `make -C l-giremi_amd` '
+                               '(or __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.lgmi_abi_version() != ABI_VERSION:
+            raise RuntimeError('liblgmi.so ABI %d != binding ABI %d' % (lib.lgmi_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().lgmi_last_error().decode('utf-8', 'replace')
+        if rc == E_DOMAIN:
+            raise ValueError('math domain error')  # what the reference raises (log(0) in sklearn's MI)
+        raise LgmiError(rc, msg)

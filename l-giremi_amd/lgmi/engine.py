@@ -1,0 +1,197 @@
+"""Engine: one MI355X, one HIP stream — thin object wrapper over the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .pack import PackedBatch
+
+
+@dataclass
+class MIResult:
+    """rows in reference order; indices are global site indices of the batch"""
+    row_i: np.ndarray
+    row_j: np.ndarray
+    row_mi: np.ndarray
+    row_p: Optional[np.ndarray]
+    row_exceed: Optional[np.ndarray]
+    row_counts: Optional[np.ndarray]     # (n_rows, 3, 3): [class at i][class at j]
+    site_mean_mi: np.ndarray
+    site_n_pairs: np.ndarray
+    info: dict
+
+    @property
+    def n_rows(self):
+        return len(self.row_i)
+
+
+def _copy_result(res: _lib.Result, info: dict) -> MIResult:
+    n, ns = int(res.n_rows), int(res.n_sites)
+
+    def a(ptr, count, dt, shape=None):
+        if not ptr:
+            return None
+        if count == 0:
+            out = np.zeros(0, dt)
+        else:
+            out = np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
+        return out.reshape(shape) if shape else out
+    return MIResult(a(res.row_i, n, np.uint32), a(res.row_j, n, np.uint32), a(res.row_mi, n, np.float64),
+                    a(res.row_p, n, np.float64), a(res.row_exceed, n, np.uint32),
+                    a(res.row_counts, 9 * n, np.uint32, (n, 3, 3)),
+                    a(res.site_mean_mi, ns, np.float64), a(res.site_n_pairs, ns, np.uint32), info)
+
+
+def make_params(min_common=5, n_shuffles=0, seed=0, het_only=True, emit_counts=False) -> _lib.Params:
+    if min_common < 0:
+        min_common = 0
+    return _lib.Params(int(min_common), int(n_shuffles), int(seed) & (2**64 - 1),
+                       1 if het_only else 0, 1 if emit_counts else 0, (C.c_uint8 * 6)())
+
+
+def default_synth_spec(n_sites, n_reads, seed=20250808) -> _lib.SynthSpec:
+    """SURVEY §8d dense regime: 10 % dropout, het SNP every 5th site with 2 % noise,
+    2 % tri-allelic sites with a 5 % third allele, 1 % of the other sites typed snp"""
+    return _lib.SynthSpec(int(seed), int(n_sites), int(n_reads), 5, 6554, 1311, 20, 3277, 10)
+
+
+class DeviceBatch:
+    def __init__(self, engine, handle):
+        self.engine, self.handle = engine, handle
+
+    def download(self) -> PackedBatch:
+        b = _lib.Batch()
+        _lib.check(self.engine.lib.lgmi_dbatch_download(self.handle, C.byref(b)))
+        return PackedBatch.from_struct(b)
+
+    def free(self):
+        if self.handle:
+            self.engine.lib.lgmi_dbatch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceResult:
+    def __init__(self, engine, handle):
+        self.engine, self.handle = engine, handle
+
+    def info(self) -> dict:
+        ri = _lib.RunInfo()
+        _lib.check(self.engine.lib.lgmi_dresult_info(self.handle, C.byref(ri)))
+        return ri.as_dict()
+
+    def fetch(self) -> MIResult:
+        res = _lib.Result()
+        _lib.check(self.engine.lib.lgmi_dresult_fetch(self.handle, C.byref(res)))
+        try:
+            return _copy_result(res, self.info())
+        finally:
+            self.engine.lib.lgmi_result_free(C.byref(res))
+
+    def free(self):
+        if self.handle:
+            self.engine.lib.lgmi_dresult_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """Owns an ``lgmi_ctx``.  HIP is first touched here, never at import: create the
+    engine AFTER any fork (the reference calls the MI step inside multiprocessing
+    workers, script/giremi.py:375-380; a HIP context does not survive fork)."""
+
+    def __init__(self, device: Optional[int] = None):
+        self.lib = _lib.load()
+        if device is None:
+            device = int(os.environ.get('LGMI_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        h = C.c_void_p()
+        _lib.check(self.lib.lgmi_ctx_create(int(device), C.byref(h)))
+        self.handle, self.device, self.pid = h, int(device), os.getpid()
+
+    def _alive(self):
+        if not self.handle:
+            raise RuntimeError('engine is closed')
+        if os.getpid() != self.pid:
+            raise RuntimeError('lgmi Engine used in a forked child: create the Engine after fork')
+
+    def close(self):
+        if self.handle and os.getpid() == self.pid:
+            self.lib.lgmi_ctx_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- one-shot path (upload + kernels + fetch)
+    def run(self, batch: PackedBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
+            emit_counts=False) -> MIResult:
+        self._alive()
+        st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts)
+        res, info = _lib.Result(), _lib.RunInfo()
+        _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
+        try:
+            return _copy_result(res, info.as_dict())
+        finally:
+            self.lib.lgmi_result_free(C.byref(res))
+
+    # ---- resident path (bench, multi-GPU)
+    def upload(self, batch: PackedBatch) -> DeviceBatch:
+        self._alive()
+        st, h = batch.as_struct(), C.c_void_p()
+        _lib.check(self.lib.lgmi_batch_upload(self.handle, C.byref(st), C.byref(h)))
+        return DeviceBatch(self, h)
+
+    def synth_dense(self, spec: _lib.SynthSpec) -> DeviceBatch:
+        self._alive()
+        h = C.c_void_p()
+        _lib.check(self.lib.lgmi_synth_dense(self.handle, C.byref(spec), C.byref(h)))
+        return DeviceBatch(self, h)
+
+    def run_device(self, dbatch: DeviceBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
+                   emit_counts=False) -> DeviceResult:
+        self._alive()
+        prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts), C.c_void_p()
+        _lib.check(self.lib.lgmi_run_device(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
+        return DeviceResult(self, h)
+
+    def site_mean(self, row_i, row_j, row_mi, n_sites):
+        self._alive()
+        ri = np.ascontiguousarray(row_i, np.uint32)
+        rj = np.ascontiguousarray(row_j, np.uint32)
+        rm = np.ascontiguousarray(row_mi, np.float64)
+        mean = np.empty(n_sites, np.float64)
+        cnt = np.empty(n_sites, np.uint32)
+
+        def p(a, t):
+            return a.ctypes.data_as(t) if a.size else C.cast(None, t)
+        _lib.check(self.lib.lgmi_site_mean(self.handle, len(ri), p(ri, _lib.u32p), p(rj, _lib.u32p),
+                                           p(rm, _lib.f64p), n_sites, p(mean, _lib.f64p), p(cnt, _lib.u32p)))
+        return mean, cnt
+
+
+_default: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default
+    if _default is None or _default.pid != os.getpid() or not _default.handle:
+        _default = Engine()
+    return _default

@@ -1,0 +1,97 @@
+"""Drop-ins for the reference's site-pair MI step, computed on the MI355X.
+
+Same names, arguments, return shapes and error behaviour as
+``src/giremi/mutual_information.py`` of gxiaolab/L-GIREMI (v0.2.4):
+
+    mismatch_pair_mutual_info(mismatches, min_common_reads=5)   (:6-45)
+    mean_mismatch_pair_mutual_info(mismatch_pair_mi)            (:48-60)
+
+plus ``region_pair_mi`` — the batched form of the caller's MI block
+(``src/giremi/mismatch.py:384-418``) that does both strands in one launch
+sequence and is what a GPU-aware host should call.
+
+Everything numeric happens in liblgmi.so (HIP, gfx950) through ctypes; there is
+no CPU fallback — without the library or a GPU these functions raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .engine import Engine, default_engine
+from .pack import pack_blocks
+
+
+def _min_common(min_common_reads) -> int:
+    # the reference tests len(common) < min_common_reads (:19); any real threshold works
+    return max(0, int(math.ceil(min_common_reads)))
+
+
+def mismatch_pair_mutual_info(mismatches: dict, min_common_reads=5, engine: Optional[Engine] = None) -> List[list]:
+    """All pairs of positions (sorted, ``itertools.combinations`` order) with at least
+    ``min_common_reads`` common reads -> ``[p1, type1, p2, type2, mi]`` rows."""
+    if len(mismatches) < 2:
+        return []
+    eng = engine or default_engine()
+    batch = pack_blocks([mismatches])
+    res = eng.run(batch, min_common=_min_common(min_common_reads), het_only=False)
+    if batch.bad_sites.any() and res.n_rows:
+        if batch.bad_sites[res.row_i].any() or batch.bad_sites[res.row_j].any():
+            raise IndexError('list index out of range')   # fewer than two alleles in depth (:30,:32)
+    pos, names = batch.site_pos, batch.type_names
+    keys = sorted(mismatches.keys())                       # hand back the caller's own key objects
+    return [[keys[i], names[i], keys[j], names[j], float(mi)]
+            for i, j, mi in zip(res.row_i.tolist(), res.row_j.tolist(), res.row_mi.tolist())]
+
+
+def mean_mismatch_pair_mutual_info(mismatch_pair_mi, engine: Optional[Engine] = None) -> List[list]:
+    """``[pos, mean mi]`` per site, in order of first appearance; every row counts
+    for both of its sites."""
+    index: Dict[object, int] = {}
+    ri, rj, rm = [], [], []
+    for p1, _t1, p2, _t2, mi in mismatch_pair_mi:
+        ri.append(index.setdefault(p1, len(index)))
+        rj.append(index.setdefault(p2, len(index)))
+        rm.append(mi)
+    if not index:
+        return []
+    eng = engine or default_engine()
+    mean, _cnt = eng.site_mean(ri, rj, rm, len(index))
+    return [[pos, float(mean[k])] for pos, k in index.items()]
+
+
+def region_pair_mi(mismatches_by_strand: dict, chromosome: str, min_common_reads=5, n_shuffles=0, seed=0,
+                   engine: Optional[Engine] = None):
+    """Batched MI block of ``region_mismatch_analysis`` (mismatch.py:384-418).
+
+    Returns ``(records, mean_mi, p_values)``: ``records`` are the rows of
+    ``df_mismatch_pair_mi`` — ``[chromosome, strand, p1, type1, p2, type2, mi]``, '+'
+    rows then '-' rows, het_snp-involved pairs only; ``mean_mi[strand]`` maps position
+    -> mean MI (what ``mean_mismatch_pair_mutual_info`` feeds the mismatch table);
+    ``p_values`` is None unless ``n_shuffles`` > 0 (then one permutation p per record).
+    """
+    strands = ('+', '-')
+    blocks = [mismatches_by_strand.get(s, {}) for s in strands]
+    records, means, pvals = [], {'+': {}, '-': {}}, ([] if n_shuffles else None)
+    if not any(len(b) > 1 for b in blocks):
+        return records, means, pvals
+    eng = engine or default_engine()
+    batch = pack_blocks(blocks)
+    res = eng.run(batch, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True)
+    if batch.bad_sites.any() and res.n_rows:
+        if batch.bad_sites[res.row_i].any() or batch.bad_sites[res.row_j].any():
+            raise IndexError('list index out of range')
+    bsb = batch.block_site_begin
+    pos, names = batch.site_pos.tolist(), batch.type_names
+    for k, (i, j, mi) in enumerate(zip(res.row_i.tolist(), res.row_j.tolist(), res.row_mi.tolist())):
+        strand = strands[0] if i < int(bsb[1]) else strands[1]
+        records.append([chromosome, strand, pos[i], names[i], pos[j], names[j], mi])
+        if pvals is not None:
+            pvals.append(float(res.row_p[k]))
+    for b, strand in enumerate(strands):
+        for s in range(int(bsb[b]), int(bsb[b + 1])):
+            if res.site_n_pairs[s]:
+                means[strand][pos[s]] = float(res.site_mean_mi[s])
+    return records, means, pvals

@@ -1,0 +1,59 @@
+"""CPU-only checks of the drop-in boundary: liblgmi.so loads without a GPU, exports
+every symbol include/lgmi.h declares, and refuses to work without a device (no
+CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from lgmi import _lib
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'lgmi.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(lgmi_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), 'liblgmi.so does not export %s' % name
+    assert sorted(_lib.SYMBOLS) == names, 'ctypes binding and header disagree'
+
+
+def test_abi_version_and_struct_sizes():
+    lib = _lib.load()
+    assert lib.lgmi_abi_version() == _lib.ABI_VERSION
+    assert C.sizeof(_lib.Batch) == 88
+    assert C.sizeof(_lib.Params) == 24
+    assert C.sizeof(_lib.Result) == 88
+    assert C.sizeof(_lib.RunInfo) == 80
+    assert C.sizeof(_lib.SynthSpec) == 40
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.lgmi_ctx_create(0, C.byref(h))
+    assert rc == _lib.E_NODEV and not h
+    assert b'no CPU fallback' in lib.lgmi_last_error()
+    with pytest.raises(_lib.LgmiError):
+        import lgmi
+        lgmi.Engine()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'l-giremi_amd')
+    for dirpath, _dirs, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.cpp', '.hip', '.h')):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert 'oracle' not in src.lower() or fn == 'README.md', '%s mentions the oracle' % fn

@@ -1,0 +1,210 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden
+vectors and against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): counts bit-exact, MI / mean MI within 1e-6."""
+import numpy as np
+import pytest
+
+from conftest import all_pair_cases, sites_to_mismatches
+from util_synth import random_batch
+
+pytestmark = pytest.mark.gpu
+
+MI_TOL = 1e-6
+
+
+@pytest.fixture(scope='module')
+def engine():
+    import lgmi
+    eng = lgmi.Engine(0)
+    yield eng
+    eng.close()
+
+
+def assert_same_as_oracle(res, ora, check_counts=True):
+    assert res.n_rows == len(ora['row_i'])
+    np.testing.assert_array_equal(res.row_i, ora['row_i'])
+    np.testing.assert_array_equal(res.row_j, ora['row_j'])
+    if check_counts:
+        np.testing.assert_array_equal(res.row_counts, ora['row_counts'])        # bit-exact
+    if res.n_rows:
+        assert np.max(np.abs(res.row_mi - ora['row_mi'])) <= MI_TOL
+        assert ((res.row_mi == 0.0) == (ora['row_mi'] == 0.0)).all()
+    np.testing.assert_array_equal(res.site_n_pairs, ora['site_n_pairs'])
+    m = ora['site_n_pairs'] > 0
+    assert np.isnan(res.site_mean_mi[~m]).all()
+    if m.any():
+        assert np.max(np.abs(res.site_mean_mi[m] - ora['site_mean_mi'][m])) <= MI_TOL
+
+
+# ---------------------------------------------------------------- reference golden vectors
+@pytest.mark.parametrize('case', all_pair_cases(), ids=lambda c: c['name'])
+def test_dropin_pair_mi_matches_reference(engine, case):
+    import lgmi
+    mm = sites_to_mismatches(case['sites'])
+    rows = lgmi.mismatch_pair_mutual_info(mm, case['min_common'], engine=engine)
+    assert [r[:4] for r in rows] == [r[:4] for r in case['rows']]
+    for got, exp in zip(rows, case['rows']):
+        assert abs(got[4] - exp[4]) <= MI_TOL
+        assert isinstance(got[4], float)
+        if exp[4] == 0.0:
+            assert got[4] == 0.0
+    # 3x3 tables through the batched entry, bit-exact against the reference's label vectors
+    if len(mm) > 1:
+        res = engine.run(lgmi.pack_blocks([mm]), min_common=case['min_common'], het_only=False, emit_counts=True)
+        assert res.row_counts.reshape(-1, 9).tolist() == case['tables']
+
+
+@pytest.mark.parametrize('case', all_pair_cases(), ids=lambda c: c['name'])
+def test_dropin_mean_mi_matches_reference(engine, case):
+    import lgmi
+    for key, rows in (('mean_all', case['rows']),
+                      ('mean_het', [r for r in case['rows'] if r[1] == 'het_snp' or r[3] == 'het_snp'])):
+        got = lgmi.mean_mismatch_pair_mutual_info(rows, engine=engine)
+        assert [g[0] for g in got] == [e[0] for e in case[key]]
+        for g, e in zip(got, case[key]):
+            assert abs(g[1] - e[1]) <= MI_TOL
+
+
+def test_region_pair_mi_matches_reference_filter(engine):
+    """mismatch.py:384-418: '+' rows then '-' rows, het_snp-involved pairs only, mean over kept rows"""
+    import lgmi
+    cases = {c['name']: c for c in all_pair_cases()}
+    plus, minus = cases['random_03_P%s' % cases_suffix(cases, 'random_03')], cases['three_allele']
+    mm = {'+': sites_to_mismatches(plus['sites']), '-': sites_to_mismatches(minus['sites'])}
+    # both goldens were generated with their own min_common; use one the two share
+    mc = 5
+    from oracle import mi_oracle
+    kept, means = mi_oracle.region_mi(mm, mc)
+    records, mean_mi, pv = lgmi.region_pair_mi(mm, 'chrS', mc, engine=engine)
+    exp = [['chrS', '+'] + r for r in kept['+']] + [['chrS', '-'] + r for r in kept['-']]
+    assert pv is None
+    assert [r[:6] for r in records] == [r[:6] for r in exp]
+    for g, e in zip(records, exp):
+        assert abs(g[6] - e[6]) <= MI_TOL
+    for strand in '+-':
+        em = dict(means[strand])
+        assert set(em) == set(mean_mi[strand])
+        for p in em:
+            assert abs(em[p] - mean_mi[strand][p]) <= MI_TOL
+
+
+def cases_suffix(cases, prefix):
+    name = [n for n in cases if n.startswith(prefix)][0]
+    return name[len(prefix) + 2:]
+
+
+# ---------------------------------------------------------------- error behaviour of the reference
+def test_zero_common_with_min_common_zero_raises_valueerror(engine):
+    import lgmi
+    mm = sites_to_mismatches([c for c in all_pair_cases() if c['name'] == 'below_min_common'][0]['sites'])
+    mm[99999] = {'type': 'snp', 'depth': {'A': 5, 'G': 3}, 'nt': {'A': ['x1'], 'G': ['x2']}}
+    with pytest.raises(ValueError, match='math domain error'):
+        lgmi.mismatch_pair_mutual_info(mm, 0, engine=engine)
+
+
+def test_fewer_than_two_alleles_raises_indexerror(engine):
+    import lgmi
+    mm = {1: {'type': 'mismatch', 'depth': {'A': 9}, 'nt': {'A': ['a', 'b']}},
+          2: {'type': 'mismatch', 'depth': {'A': 9, 'C': 2}, 'nt': {'A': ['a'], 'C': ['b']}}}
+    with pytest.raises(IndexError):
+        lgmi.mismatch_pair_mutual_info(mm, 1, engine=engine)
+    assert lgmi.mismatch_pair_mutual_info(mm, 5, engine=engine) == []   # never ranked: no pair passes :19
+
+
+def test_empty_and_single_site(engine):
+    import lgmi
+    assert lgmi.mismatch_pair_mutual_info({}, 5, engine=engine) == []
+    assert lgmi.mean_mismatch_pair_mutual_info([], engine=engine) == []
+    one = {7: {'type': 'het_snp', 'depth': {'A': 3, 'G': 3}, 'nt': {'A': ['a', 'b', 'c'], 'G': ['d', 'e', 'f']}}}
+    assert lgmi.mismatch_pair_mutual_info(one, 1, engine=engine) == []
+    rec, means, _ = lgmi.region_pair_mi({'+': one, '-': {}}, 'c', 5, engine=engine)
+    assert rec == [] and means == {'+': {}, '-': {}}
+
+
+# ---------------------------------------------------------------- seeded random batches vs the C oracle
+@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('het_only', [True, False])
+def test_random_batches_match_oracle(engine, seed, het_only):
+    from oracle import c_oracle
+    pb = random_batch(1000 + seed, n_blocks=1 + seed % 4, tri_frac=0.15 if seed % 3 else 0.0)
+    mc = [1, 5, 6, 20][seed % 4]
+    ora = c_oracle.run(pb, min_common=mc, het_only=het_only)
+    res = engine.run(pb, min_common=mc, het_only=het_only, emit_counts=True)
+    assert_same_as_oracle(res, ora)
+    assert res.info['n_examined'] == ora['n_examined']
+
+
+def test_many_small_blocks_and_empty_blocks(engine):
+    from oracle import c_oracle
+    from util_synth import pack_class_matrix, random_block
+    rng = np.random.Generator(np.random.PCG64(5))
+    blocks = []
+    for k in range(60):
+        P = int(rng.integers(0, 9))
+        R = int(rng.integers(1, 130))
+        if P == 0:
+            blocks.append((np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros((0, R), np.int8)))
+        else:
+            blocks.append(random_block(rng, P, R, banded=False, tri_frac=0.2, het_frac=0.5))
+    pb = pack_class_matrix(blocks)
+    for het_only in (True, False):
+        ora = c_oracle.run(pb, min_common=2, het_only=het_only)
+        res = engine.run(pb, min_common=2, het_only=het_only, emit_counts=True)
+        assert_same_as_oracle(res, ora)
+
+
+def test_tile_edges_and_long_bands(engine):
+    """sizes around the 64-column tile edge and the 8-word LDS stage"""
+    from oracle import c_oracle
+    from util_synth import pack_class_matrix, random_block
+    rng = np.random.Generator(np.random.PCG64(11))
+    for P, R in ((63, 64), (64, 65), (65, 511), (129, 513), (200, 1025)):
+        pb = pack_class_matrix([random_block(rng, P, R, banded=(P % 2 == 1), tri_frac=0.1, het_frac=0.4)])
+        ora = c_oracle.run(pb, min_common=3, het_only=True)
+        res = engine.run(pb, min_common=3, het_only=True, emit_counts=True)
+        assert_same_as_oracle(res, ora)
+
+
+def test_no_het_sites_gives_no_rows(engine):
+    from util_synth import pack_class_matrix, random_block
+    rng = np.random.Generator(np.random.PCG64(3))
+    pos, typ, cls = random_block(rng, 20, 100)
+    typ[:] = 0
+    res = engine.run(pack_class_matrix([(pos, typ, cls)]), min_common=1, het_only=True)
+    assert res.n_rows == 0 and np.isnan(res.site_mean_mi).all()
+
+
+# ---------------------------------------------------------------- device-side synthetic chromosome
+def test_synth_dense_roundtrip_and_parity(engine):
+    import lgmi
+    from oracle import c_oracle
+    spec = lgmi.default_synth_spec(150, 3000, seed=42)
+    spec.tri_per_1024 = 200
+    db = engine.synth_dense(spec)
+    pb = db.download()
+    assert pb.n_sites == 150 and int(pb.block_n_reads[0]) == 3000
+    assert (pb.site_type[::5] == 2).all()
+    # the downloaded batch, re-uploaded, is the same problem
+    dr = engine.run_device(db, min_common=6, het_only=True, emit_counts=True)
+    res = dr.fetch()
+    ora = c_oracle.run(pb, min_common=6, het_only=True)
+    assert_same_as_oracle(res, ora)
+    res2 = engine.run(pb, min_common=6, het_only=True, emit_counts=True)
+    np.testing.assert_array_equal(res.row_counts, res2.row_counts)
+    np.testing.assert_array_equal(res.row_mi, res2.row_mi)
+    # dropout ~10 %, so common reads ~ 0.81 R; het pairs are strongly linked
+    n = res.row_counts.sum(axis=(1, 2))
+    assert 0.75 * 3000 < n.mean() < 0.87 * 3000
+    info = dr.info()
+    assert info['n_rows'] == res.n_rows and info['ms_count'] > 0
+    dr.free()
+    db.free()
+
+
+def test_run_is_deterministic(engine):
+    pb = random_batch(77, n_blocks=2)
+    a = engine.run(pb, min_common=3, het_only=True, emit_counts=True)
+    b = engine.run(pb, min_common=3, het_only=True, emit_counts=True)
+    for f in ('row_i', 'row_j', 'row_mi', 'row_counts', 'site_mean_mi', 'site_n_pairs'):
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f))
