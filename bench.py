@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — site-pair MI throughput of the MI355X engine on BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shuffles S]
+
+A "step" is one pass of the hot path (pair counts -> MI -> ordered rows -> per-site
+mean MI [-> permutation p]) over one synthetic chromosome that is already resident
+in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
+owns its own chromosome (weak scaling: blocks never share pairs); the
+only collective on the data path is the final RCCL gather of per-rank row counts.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'l-giremi_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # BASELINE.json north_star target: "50k-site x 200k-read synthetic chromosome"
+    'north_star_dense_50kx200k': dict(n_sites=50_000, n_reads=200_000),
+    # BASELINE.json configs[1]
+    'cfg2_dense_10kx50k': dict(n_sites=10_000, n_reads=50_000),
+    'small_dense_2kx20k': dict(n_sites=2_000, n_reads=20_000),
+}
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 (= 157.3 TF fp32 / 2)
+WORD_OP_LANE_OPS = 4                  # one 64-bit AND+POPC = 2 v_and_b32 + 2 v_bcnt_u32_b32
+
+
+def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
+    """The CPU oracle (oracle/lgmi_oracle.c, OpenMP) timed on a bounded sample of the
+    same workload: same read count, fewer sites, so it finishes in ~10-30 s."""
+    import lgmi
+    from oracle import c_oracle
+    n_reads = wl['n_reads']
+    cores = c_oracle.load().lgo_num_threads()
+    # ~2.5e9 pair-words keeps 16 host cores busy for ~10-20 s
+    target_pair_words = 2.5e9 * max(1, cores) / 16
+    words = (n_reads + 63) // 64
+    p = int(max(60, min(wl['n_sites'], (target_pair_words / words / 0.18) ** 0.5)))
+    spec = lgmi.default_synth_spec(p, n_reads, seed=seed)
+    db = eng.synth_dense(spec)
+    pb = db.download()
+    db.free()
+    t0 = time.perf_counter()
+    out = c_oracle.run(pb, min_common=min_common, het_only=True, n_shuffles=n_shuffles, seed=seed, threads=cores)
+    dt = time.perf_counter() - t0
+    return {'value': out['n_examined'] / dt, 'unit': 'site-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': 'same generator and read count (%d reads), first-principles subsample of %d sites: '
+                      '%d examined pairs, %d emitted, %.1f s wall' % (n_reads, p, out['n_examined'],
+                                                                      len(out['row_i']), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='north_star_dense_50kx200k', choices=sorted(WORKLOADS))
+    ap.add_argument('--shuffles', type=int, default=0)
+    ap.add_argument('--min-common', type=int, default=6)      # l-giremi CLI default (script/giremi.py:212-216)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        args.gpus = world
+
+    import torch
+    import lgmi
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    eng = lgmi.Engine(local_rank)
+    wl = WORKLOADS[args.workload]
+    seed = 20250808 + 1000 * rank
+    spec = lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed)
+    db = eng.synth_dense(spec)                                 # input resident in HBM before timing
+    if world > 1:
+        eng.comm_init_torch(dist, rank, world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        dr = eng.run_device(db, min_common=args.min_common, n_shuffles=args.shuffles, seed=seed, het_only=True)
+        info = dr.info()
+        if world > 1:
+            info['world_rows'] = eng.comm_allgather_u64(info['n_rows'])   # final gather (RCCL over xGMI)
+        dr.free()
+        return info
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    infos = [step() for _ in range(args.steps)]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = infos[-1]
+    examined = info['n_examined']
+    ms_count = sum(i['ms_count'] for i in infos) / len(infos)
+    out = None
+    if rank == 0:
+        # dominant kernel: k_count.  Algorithmic HBM bytes per launch:
+        # every column's planes once (16 B per 64-read word) + site metadata + the 4 count planes
+        # of every computed slot (16 B).
+        alg_bytes = info['bytes_in'] + 16 * info['n_tile_pairs']
+        word_ops = 4 * info['word_pairs']                      # 4 mandatory AND+POPC per pair-word
+        secs = ms_count * 1e-3
+        out = {
+            'metric': 'MI site-pairs/sec (incl. permutation p)' if args.shuffles else 'MI site-pairs/sec',
+            'value': examined * world * args.steps / elapsed,
+            'unit': 'site-pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u64 bit-planes / u32 counts / f64 MI', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'n_sites': wl['n_sites'], 'n_reads': wl['n_reads'],
+                       'regime': 'dense', 'het_every': 5, 'min_common': args.min_common,
+                       'n_shuffles': args.shuffles, 'examined_pairs_per_gpu': examined,
+                       'emitted_pairs_per_gpu': info['n_rows'], 'parallelism': 'dp%d' % world},
+            'stage_ms': {k: sum(i[k] for i in infos) / len(infos)
+                         for k in ('ms_total', 'ms_prep', 'ms_count', 'ms_emit', 'ms_perm', 'ms_mean')},
+            'roofline': {'kernel': 'k_count', 'bound': 'hbm', 'achieved': alg_bytes / secs / 1e9,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
+                         'traffic': None,
+                         'note': 'k_count is VALU(popcount)-bound, not HBM-bound: see valu_roofline'},
+            'valu_roofline': {'kernel': 'k_count', 'bound': 'valu_popcount',
+                              'achieved': word_ops / secs / 1e12, 'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12,
+                              'unit': 'T word-ops/s (64-bit AND+POPC)',
+                              'frac': word_ops / secs / (VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS)},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, args.shuffles, seed)
+    db.free()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

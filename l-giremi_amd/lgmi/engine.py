@@ -33,17 +33,19 @@ class MIResult:
 def _copy_result(res: _lib.Result, info: dict) -> MIResult:
     n, ns = int(res.n_rows), int(res.n_sites)
 
-    def a(ptr, count, dt, shape=None):
-        if not ptr:
+    def a(ptr, count, dt, shape=None, present=True):
+        if not present:
             return None
-        if count == 0:
-            out = np.zeros(0, dt)
+        if count == 0 or not ptr:
+            out = np.zeros(count if not ptr and count else 0, dt)
         else:
             out = np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
         return out.reshape(shape) if shape else out
+    has_p = bool(res.row_p) or (n == 0 and info.get('has_p', False))
+    has_c = bool(res.row_counts) or (n == 0 and info.get('has_counts', False))
     return MIResult(a(res.row_i, n, np.uint32), a(res.row_j, n, np.uint32), a(res.row_mi, n, np.float64),
-                    a(res.row_p, n, np.float64), a(res.row_exceed, n, np.uint32),
-                    a(res.row_counts, 9 * n, np.uint32, (n, 3, 3)),
+                    a(res.row_p, n, np.float64, present=has_p), a(res.row_exceed, n, np.uint32, present=has_p),
+                    a(res.row_counts, 9 * n, np.uint32, (n, 3, 3), present=has_c),
                     a(res.site_mean_mi, ns, np.float64), a(res.site_n_pairs, ns, np.uint32), info)
 
 
@@ -148,7 +150,9 @@ class Engine:
         res, info = _lib.Result(), _lib.RunInfo()
         _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
         try:
-            return _copy_result(res, info.as_dict())
+            d = info.as_dict()
+            d['has_p'], d['has_counts'] = n_shuffles > 0, bool(emit_counts)
+            return _copy_result(res, d)
         finally:
             self.lib.lgmi_result_free(C.byref(res))
 
