@@ -90,8 +90,9 @@ struct lgmi_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     Pool pool;
-    double* d_nlogn = nullptr;  // n*ln(n) table for the permutation statistic
-    uint32_t nlogn_len = 0;
+    long long* d_G = nullptr;   // round(n ln n * 2^28): permutation statistic (perm.hip)
+    double* d_LF = nullptr;     // ln n!
+    uint32_t tables_len = 0;
     void* comm = nullptr;       // ncclComm_t (comm.cpp)
     int rank = 0, world = 1;
 };
@@ -171,7 +172,8 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     lgmi_comm_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->d_nlogn) (void)hipFree(ctx->d_nlogn);
+    if (ctx->d_G) (void)hipFree(ctx->d_G);
+    if (ctx->d_LF) (void)hipFree(ctx->d_LF);
     ctx->pool.destroy();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -497,15 +499,23 @@ static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
 }
 
 // ---------------------------------------------------------------- the run
-static int ensure_nlogn(lgmi_ctx* ctx, uint32_t max_n) {
-    if (ctx->nlogn_len > max_n) return LGMI_OK;
-    if (ctx->d_nlogn) { (void)hipFree(ctx->d_nlogn); ctx->d_nlogn = nullptr; ctx->nlogn_len = 0; }
-    std::vector<double> t((size_t)max_n + 1);
-    t[0] = 0.0;
-    for (uint32_t n = 1; n <= max_n; ++n) t[n] = (double)n * std::log((double)n);
-    HIPCHK(hipMalloc((void**)&ctx->d_nlogn, t.size() * sizeof(double)));
-    HIPCHK(hipMemcpy(ctx->d_nlogn, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->nlogn_len = max_n + 1;
+// host-built tables of the permutation test: libm is only ever called
+// here, on the host, so the device results do not depend on the device math library
+static int ensure_perm_tables(lgmi_ctx* ctx, uint32_t max_n) {
+    if (ctx->tables_len > max_n) return LGMI_OK;
+    if (ctx->d_G) { (void)hipFree(ctx->d_G); ctx->d_G = nullptr; }
+    if (ctx->d_LF) { (void)hipFree(ctx->d_LF); ctx->d_LF = nullptr; }
+    ctx->tables_len = 0;
+    std::vector<long long> g((size_t)max_n + 1);
+    std::vector<double> lf((size_t)max_n + 1);
+    g[0] = 0;
+    for (uint32_t n = 1; n <= max_n; ++n) g[n] = llrint((double)n * std::log((double)n) * 268435456.0);
+    for (uint32_t n = 0; n <= max_n; ++n) lf[n] = lgamma((double)n + 1.0);
+    HIPCHK(hipMalloc((void**)&ctx->d_G, g.size() * sizeof(long long)));
+    HIPCHK(hipMalloc((void**)&ctx->d_LF, lf.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_G, g.data(), g.size() * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_LF, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->tables_len = max_n + 1;
     return LGMI_OK;
 }
 
@@ -530,6 +540,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     const bool want_counts = prm->emit_counts != 0;
     int rc;
 
+    if (want_p && (rc = ensure_perm_tables(ctx, db->max_reads))) return rc;   // first use only
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     Plan pl;
     build_plan(db, prm->het_only != 0, pl);
@@ -616,9 +627,12 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     if (want_p && n_rows) {
-        if ((rc = ensure_nlogn(ctx, db->max_reads))) return rc;
-        launch_perm(st, n_rows, res->d_i, res->d_j, res->d_counts, ctx->d_nlogn, ctx->nlogn_len, prm->n_shuffles,
-                    prm->seed, res->d_p, res->d_exceed);
+        uint32_t* d_genlist; unsigned int* d_gencount;
+        if ((rc = salloc((void**)&d_genlist, (size_t)n_rows * 4))) return rc;
+        if ((rc = salloc((void**)&d_gencount, 4))) return rc;
+        HIPCHK(hipMemsetAsync(d_gencount, 0, 4, st));
+        launch_perm(st, n_rows, res->d_i, res->d_j, res->d_counts, ctx->d_G, ctx->d_LF, prm->n_shuffles,
+                    prm->seed, res->d_p, res->d_exceed, d_genlist, d_gencount);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));

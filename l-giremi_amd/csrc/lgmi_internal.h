@@ -103,8 +103,8 @@ void launch_rows_mean(hipStream_t st, uint64_t n_rows, const uint32_t* ri, const
 
 // perm.hip
 void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const uint32_t* out_j,
-                 const uint32_t* counts, const double* nlogn, uint32_t nlogn_len,
-                 uint32_t n_shuffles, uint64_t seed, double* out_p, uint32_t* out_exceed);
+                 const uint32_t* counts, const long long* G, const double* LF, uint32_t n_shuffles, uint64_t seed,
+                 double* out_p, uint32_t* out_exceed, uint32_t* gen_list, unsigned int* gen_count);
 
 // synth.hip: layout prep for uploaded batches and the dense synthetic generator
 void launch_tri_flags(hipStream_t st, uint32_t n_sites, const uint32_t* site_nw,

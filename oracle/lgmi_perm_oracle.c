@@ -1,8 +1,398 @@
-/* placeholder: replaced by the permutation-test specification */
+/*
+ * lgmi_perm_oracle.c — CPU specification of the permutation-test p-value of a site
+ * pair.  TEST INFRASTRUCTURE ONLY (see lgmi_oracle.c).
+ *
+ * PARITY UNPINNED: the reference (gxiaolab/L-GIREMI v0.2.4) has no permutation test
+ * (its only p-value is the ECDF `mip`, src/giremi/stat.py:7-29); BASELINE.json's
+ * north_star asks for one.  This file IS the specification; the HIP
+ * kernel (l-giremi_amd/csrc/perm.hip) must reproduce `exceed` bit for bit.
+ *
+ * Null hypothesis: the class labels of site j are shuffled uniformly among the N
+ * reads common to both sites; the 3x3 table is then multivariate hypergeometric
+ * with the observed margins.  Statistic: MI, compared through
+ *     S(T) = sum_ab G[T_ab],  G[n] = round(n*ln(n) * 2^28)   (MI*N = S/2^28 - const for fixed margins)
+ * in 64-bit INTEGER arithmetic: the sum does not depend on the order of the cells, so
+ * tables made of the same cell counts (very common with small counts) tie exactly.
+ * p = (1 + #{S(T_s) >= S(T_obs)}) / (n_shuffles + 1).
+ *
+ *  - <= 1 non-empty row or column: every shuffle gives the same table, exceed = n_shuffles.
+ *  - exactly 2 x 2 non-empty: one degree of freedom k.  Shuffle s draws k by inverse
+ *    CDF with the "as or more extreme" set enumerated first, so it lands in that set
+ *    iff u_s < P_tail; P_tail is evaluated exactly from log-factorials (no table is
+ *    materialised).  u_s are 32-bit Philox outputs, threshold floor(P_tail * 2^32).
+ *  - anything larger: shuffle s draws the table cell by cell with conditional
+ *    hypergeometric draws (simple urn scheme for small samples, Stadlober's HRUA
+ *    ratio-of-uniforms otherwise) and evaluates S.
+ *
+ * Everything that decides an outcome uses only +,-,*,/ and comparisons on doubles
+ * (compiled with -ffp-contract=off), integer arithmetic, and the tables G[] (fixed
+ * point) and LF[] (ln n!, double) computed once with libm on the host — so the CPU and the GPU agree
+ * bit for bit.  exp, log and sqrt are the deterministic routines below, not libm.
+ *
+ * Published algorithms restated here: Philox4x32-10 (Salmon, Moraes, Dror, Shaw,
+ * SC'11); HRUA (Stadlober, "The ratio of uniforms approach for generating discrete
+ * random variates", J. Comput. Appl. Math. 31 (1990)).
+ */
+#include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TAG_PERM2X2 0x5eed0004u
+#define TAG_PERMGEN 0x60000000u
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+static void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    int r;
+    for (r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* ------------------------------------------------------------------ deterministic exp / log / sqrt */
+static double bits_to_double(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static uint64_t double_to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+static const double INV_LN2 = 1.44269504088896338700e+00;
+/* 1/n, correctly rounded (IEEE division of exact constants, folded by the compiler) */
+static const double INV_N[24] = {0.0, 1.0, 1.0 / 2.0, 1.0 / 3.0, 1.0 / 4.0, 1.0 / 5.0, 1.0 / 6.0, 1.0 / 7.0, 1.0 / 8.0,
+                                 1.0 / 9.0, 1.0 / 10.0, 1.0 / 11.0, 1.0 / 12.0, 1.0 / 13.0, 1.0 / 14.0, 1.0 / 15.0,
+                                 1.0 / 16.0, 1.0 / 17.0, 1.0 / 18.0, 1.0 / 19.0, 1.0 / 20.0, 1.0 / 21.0, 1.0 / 22.0,
+                                 1.0 / 23.0};
+
+double lgo_det_exp(double x)   /* x <= 0; relative error ~1e-16, identical on CPU and GPU */
+{
+    double k, r, p;
+    int ki, n;
+    if (!(x > -745.0)) return 0.0;
+    if (x > 0.0) x = 0.0;
+    k = floor(x * INV_LN2 + 0.5);
+    r = (x - k * LN2_HI) - k * LN2_LO;
+    p = 1.0;
+    for (n = 14; n >= 1; --n) p = 1.0 + p * (r * INV_N[n]);   /* Horner form of sum r^n/n! */
+    ki = (int)k;
+    if (ki >= -1000) return p * bits_to_double((uint64_t)(ki + 1023) << 52);
+    return (p * bits_to_double((uint64_t)(-1000 + 1023) << 52)) * bits_to_double((uint64_t)(ki + 1000 + 1023) << 52);
+}
+
+double lgo_det_log(double x)   /* x > 0, normal */
+{
+    uint64_t b = double_to_bits(x);
+    int e = (int)((b >> 52) & 0x7FF) - 1023, n;
+    double m = bits_to_double((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);   /* [1,2) */
+    double f, f2, s;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    f = (m - 1.0) / (m + 1.0);
+    f2 = f * f;
+    s = 0.0;
+    for (n = 23; n >= 1; n -= 2) s = s * f2 + INV_N[n];   /* sum f^(2j)/(2j+1) */
+    return (double)e * LN2_HI + (2.0 * f * s + (double)e * LN2_LO);
+}
+
+double lgo_det_sqrt(double a)   /* a > 0: Newton from an exponent-halving guess, 6 steps */
+{
+    uint64_t b = double_to_bits(a);
+    double x = bits_to_double((b >> 1) + 0x1FF8000000000000ull);
+    int n;
+    for (n = 0; n < 6; ++n) x = 0.5 * (x + a / x);
+    return x;
+}
+
+/* ------------------------------------------------------------------ tables */
+typedef struct { int64_t* G; double* LF; uint32_t len; } perm_tables;
+
+static int tables_init(perm_tables* t, uint32_t max_n)
+{
+    uint32_t n;
+    t->len = max_n + 1;
+    t->G = (int64_t*)malloc((size_t)t->len * sizeof(int64_t));
+    t->LF = (double*)malloc((size_t)t->len * sizeof(double));
+    if (!t->G || !t->LF) { free(t->G); free(t->LF); return -1; }
+    t->G[0] = 0;
+    for (n = 1; n <= max_n; ++n) t->G[n] = llrint((double)n * log((double)n) * 268435456.0);   /* 2^28 */
+    for (n = 0; n <= max_n; ++n) t->LF[n] = lgamma((double)n + 1.0);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ uniform streams */
+typedef struct { uint32_t c0, c1, c2, k0, k1, call; uint32_t buf[4]; int have; } gen_stream;
+
+static double next_uniform(gen_stream* g)   /* (0,1), 52 bits: (m + 0.5) * 2^-52, exact in double */
+{
+    uint64_t m;
+    if (g->have == 0) {
+        philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
+        g->call++;
+        g->have = 2;
+    }
+    m = g->have == 2 ? (((uint64_t)g->buf[0] << 20) | (g->buf[1] >> 12)) : (((uint64_t)g->buf[2] << 20) | (g->buf[3] >> 12));
+    g->have--;
+    return ((double)m + 0.5) * 2.220446049250313e-16;
+}
+
+/* ------------------------------------------------------------------ hypergeometric draw */
+static const double HRUA_D1 = 1.7155277699214135;   /* 2*sqrt(2/e)     */
+static const double HRUA_D2 = 0.8989161620588988;   /* 3 - 2*sqrt(3/e) */
+
+/* number of "good" items in `sample` draws without replacement from pop = good + bad */
+static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint32_t sample, gen_stream* g)
+{
+    const uint32_t bad = pop - good;
+    const uint32_t m = sample < pop - sample ? sample : pop - sample;
+    uint32_t z;
+    if (sample == 0 || good == 0) return 0;
+    if (bad == 0) return sample;
+    if (sample == pop) return good;
+    if (m < 10) {
+        /* urn scheme on the smaller of the sample and its complement */
+        uint32_t rem_total = pop, rem_good = good, left = m;
+        while (left > 0 && rem_good > 0 && rem_total > rem_good) {
+            const double u = next_uniform(g);
+            if ((uint32_t)(u * (double)rem_total) < rem_good) rem_good--;
+            rem_total--;
+            left--;
+        }
+        if (rem_total == rem_good) rem_good -= left;   /* only good items remain */
+        z = good - rem_good;                           /* good items among the m drawn */
+    } else {
+        const uint32_t mn = good < bad ? good : bad, mx = good < bad ? bad : good;
+        const double d4 = (double)mn / (double)pop, d5 = 1.0 - d4;
+        const double d6 = (double)m * d4 + 0.5;
+        const double d7 = lgo_det_sqrt((double)(pop - m) * (double)m * d4 * d5 / (double)(pop - 1) + 0.5);
+        const double d8 = HRUA_D1 * d7 + HRUA_D2;
+        const uint32_t d9 = (uint32_t)(((uint64_t)(m + 1) * (uint64_t)(mn + 1)) / ((uint64_t)pop + 2));   /* mode */
+        const double d10 = t->LF[d9] + t->LF[mn - d9] + t->LF[m - d9] + t->LF[mx - m + d9];
+        const double cap = (double)((m < mn ? m : mn) + 1u);
+        const double lim = floor(d6 + 16.0 * d7);
+        const double d11 = cap < lim ? cap : lim;
+        for (;;) {
+            const double x = next_uniform(g), y = next_uniform(g);
+            const double w = d6 + d8 * (y - 0.5) / x;
+            uint32_t zc;
+            double tt;
+            if (w < 0.0 || w >= d11) continue;
+            zc = (uint32_t)floor(w);
+            tt = d10 - (t->LF[zc] + t->LF[mn - zc] + t->LF[m - zc] + t->LF[mx - m + zc]);
+            if (x * (4.0 - x) - 3.0 <= tt) { z = zc; break; }
+            if (x * (x - tt) >= 1.0) continue;
+            if (2.0 * lgo_det_log(x) <= tt) { z = zc; break; }
+        }
+        if (good > bad) z = m - z;   /* z counted the minority kind */
+    }
+    if (m < sample) z = good - z;    /* drew the complement */
+    return z;
+}
+
+/* ------------------------------------------------------------------ statistic */
+static int64_t stat9(const perm_tables* t, const uint32_t T[9])
+{
+    int64_t s = 0;
+    int k;
+    for (k = 0; k < 9; ++k) s += t->G[T[k]];
+    return s;
+}
+
+/* 2 x 2 core: rows a1 < a2, cols b1 < b2 non-empty; k = T[a2][b2] */
+typedef struct { uint32_t N, K, n, kmin, kmax; double c0; } hg22;
+
+static int64_t stat22(const perm_tables* t, const hg22* h, uint32_t k)
+{
+    int64_t s = 0;
+    s += t->G[h->N - h->K - h->n + k];
+    s += t->G[h->n - k];
+    s += t->G[h->K - k];
+    s += t->G[k];
+    return s;
+}
+
+static double pmf22(const perm_tables* t, const hg22* h, uint32_t k)
+{
+    double e = h->c0;
+    e -= t->LF[k];
+    e -= t->LF[h->K - k];
+    e -= t->LF[h->n - k];
+    e -= t->LF[h->N - h->K - h->n + k];
+    return lgo_det_exp(e);
+}
+
+/* P(S(k) >= S(k_obs)) under the hypergeometric null */
+static double ptail22(const perm_tables* t, const hg22* h, uint32_t kobs)
+{
+    const int64_t sobs = stat22(t, h, kobs);
+    uint32_t kc = (uint32_t)(((uint64_t)h->n * (uint64_t)h->K) / (uint64_t)h->N);   /* S decreases up to kc, increases after */
+    int64_t klo, khi;   /* tail = [kmin, klo] U [khi, kmax] */
+    double var, clen, p;
+    if (kc < h->kmin) kc = h->kmin;
+    if (kc > h->kmax) kc = h->kmax;
+    if (kobs <= kc) {
+        int64_t lo = (int64_t)kc + 1, hi = (int64_t)h->kmax + 1;   /* first k in [kc+1, kmax] with S(k) >= sobs */
+        klo = kobs;
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (stat22(t, h, (uint32_t)mid) >= sobs) hi = mid; else lo = mid + 1;
+        }
+        khi = lo;
+    } else {
+        int64_t lo = (int64_t)h->kmin - 1, hi = (int64_t)kc;       /* last k in [kmin, kc] with S(k) >= sobs */
+        khi = kobs;
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo + 1) / 2;
+            if (stat22(t, h, (uint32_t)mid) >= sobs) lo = mid; else hi = mid - 1;
+        }
+        klo = lo;
+    }
+    var = (double)h->n * (double)h->K * (double)(h->N - h->K) * (double)(h->N - h->n)
+          / ((double)h->N * (double)h->N * (double)(h->N > 1 ? h->N - 1 : 1));
+    clen = (double)(khi - klo - 1);
+    if (clen * clen <= 16.0 * var + 64.0) {
+        /* few values are less extreme: 1 - their mass */
+        double c = 0.0;
+        int64_t k;
+        for (k = klo + 1; k < khi; ++k) c += pmf22(t, h, (uint32_t)k);
+        p = 1.0 - c;
+    } else {
+        double acc = 0.0;
+        int64_t k;
+        for (k = klo; k >= (int64_t)h->kmin; --k) {
+            const double term = pmf22(t, h, (uint32_t)k);
+            acc += term;
+            if (term < acc * 2.168404344971009e-19) break;   /* 2^-62 */
+        }
+        for (k = khi; k <= (int64_t)h->kmax; ++k) {
+            const double term = pmf22(t, h, (uint32_t)k);
+            acc += term;
+            if (term < acc * 2.168404344971009e-19) break;
+        }
+        p = acc;
+    }
+    if (p > 1.0) p = 1.0;
+    if (p < 0.0) p = 0.0;
+    return p;
+}
+
+static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row_i, uint32_t row_j,
+                         uint32_t n_shuffles, uint64_t seed, double* ptail_out)
+{
+    uint32_t R[3], C[3], N = 0, nzr[3], nzc[3], nr = 0, nc = 0, a, b, s, exceed = 0;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (ptail_out) *ptail_out = NAN;
+    for (a = 0; a < 3; ++a) {
+        R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2];
+        C[a] = T[a] + T[3 + a] + T[6 + a];
+        N += R[a];
+    }
+    for (a = 0; a < 3; ++a) { if (R[a]) nzr[nr++] = a; if (C[a]) nzc[nc++] = a; }
+    if (nr <= 1 || nc <= 1) { if (ptail_out) *ptail_out = 1.0; return n_shuffles; }
+    if (nr == 2 && nc == 2) {
+        hg22 h;
+        double p;
+        uint64_t thr;
+        uint32_t out[4];
+        const uint32_t kobs = T[3 * nzr[1] + nzc[1]];
+        h.N = N; h.K = R[nzr[1]]; h.n = C[nzc[1]];
+        h.kmin = h.K + h.n > N ? h.K + h.n - N : 0;
+        h.kmax = h.K < h.n ? h.K : h.n;
+        h.c0 = t->LF[h.K];
+        h.c0 += t->LF[N - h.K];
+        h.c0 += t->LF[h.n];
+        h.c0 += t->LF[N - h.n];
+        h.c0 -= t->LF[N];
+        p = ptail22(t, &h, kobs);
+        if (ptail_out) *ptail_out = p;
+        thr = (uint64_t)(p * 4294967296.0);
+        if (thr > 4294967296ull) thr = 4294967296ull;
+        for (s = 0; s < n_shuffles; ++s) {
+            if ((s & 3u) == 0) philox(s >> 2, row_i, row_j, TAG_PERM2X2, k0, k1, out);
+            exceed += ((uint64_t)out[s & 3u] < thr);
+        }
+        return exceed;
+    }
+    {
+        const int64_t sobs = stat9(t, T);
+        for (s = 0; s < n_shuffles; ++s) {
+            gen_stream g;
+            uint32_t rr[3] = {R[0], R[1], R[2]}, Ts[9], pop_all = N;
+            g.c0 = s; g.c1 = row_i; g.c2 = row_j; g.k0 = k0; g.k1 = k1; g.call = 0; g.have = 0;
+            for (b = 0; b < 3; ++b) {
+                /* column b: distribute C[b] reads over the rows' remaining capacities */
+                uint32_t cc = C[b], pop = pop_all;
+                for (a = 0; a < 3; ++a) {
+                    const uint32_t x = hg_draw(t, pop, rr[a], cc, &g);
+                    Ts[3 * a + b] = x;
+                    pop -= rr[a];
+                    cc -= x;
+                }
+                for (a = 0; a < 3; ++a) rr[a] -= Ts[3 * a + b];
+                pop_all -= C[b];
+            }
+            exceed += (stat9(t, Ts) >= sobs);
+        }
+        return exceed;
+    }
+}
+
 int lgo_perm_rows(uint64_t n_rows, const uint32_t* row_i, const uint32_t* row_j, const uint32_t* counts,
                   uint32_t n_shuffles, uint64_t seed, double* p_out, uint32_t* exceed_out, int n_threads)
 {
-    (void)n_rows; (void)row_i; (void)row_j; (void)counts; (void)n_shuffles; (void)seed; (void)p_out; (void)exceed_out; (void)n_threads;
-    return -8;
+    perm_tables t;
+    uint32_t max_n = 0;
+    uint64_t r;
+    for (r = 0; r < n_rows; ++r) {
+        uint32_t n = 0;
+        int k;
+        for (k = 0; k < 9; ++k) n += counts[9 * r + k];
+        if (n > max_n) max_n = n;
+    }
+    if (tables_init(&t, max_n)) return -1;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t rr = 0; rr < (int64_t)n_rows; ++rr) {
+        const uint32_t e = perm_one(&t, counts + 9 * rr, row_i[rr], row_j[rr], n_shuffles, seed, NULL);
+        exceed_out[rr] = e;
+        p_out[rr] = (1.0 + (double)e) / ((double)n_shuffles + 1.0);
+    }
+    free(t.G); free(t.LF);
+    return 0;
+}
+
+/* ---- hooks for the statistical tests of this specification (tests/test_perm_oracle.py) ---- */
+int lgo_hg_draw_many(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed, uint32_t n, uint32_t* out)
+{
+    perm_tables t;
+    uint32_t i;
+    if (tables_init(&t, pop)) return -1;
+    for (i = 0; i < n; ++i) {
+        gen_stream g;
+        g.c0 = i; g.c1 = 1; g.c2 = 2; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0;
+        out[i] = hg_draw(&t, pop, good, sample, &g);
+    }
+    free(t.G); free(t.LF);
+    return 0;
+}
+
+int lgo_perm_ptail(const uint32_t T[9], double* ptail)
+{
+    perm_tables t;
+    uint32_t n = 0;
+    int k;
+    for (k = 0; k < 9; ++k) n += T[k];
+    if (tables_init(&t, n)) return -1;
+    (void)perm_one(&t, T, 0, 1, 0, 0, ptail);
+    free(t.G); free(t.LF);
+    return 0;
 }

@@ -208,3 +208,52 @@ def test_run_is_deterministic(engine):
     b = engine.run(pb, min_common=3, het_only=True, emit_counts=True)
     for f in ('row_i', 'row_j', 'row_mi', 'row_counts', 'site_mean_mi', 'site_n_pairs'):
         np.testing.assert_array_equal(getattr(a, f), getattr(b, f))
+
+
+# ---------------------------------------------------------------- permutation p-values (parity unpinned: vs the CPU specification)
+def assert_perm_same(res, ora, n_shuffles):
+    np.testing.assert_array_equal(res.row_i, ora['row_i'])
+    np.testing.assert_array_equal(res.row_exceed, ora['row_exceed'])        # bit-exact
+    np.testing.assert_array_equal(res.row_p, ora['row_p'])
+    np.testing.assert_array_equal(res.row_p, (1.0 + res.row_exceed) / (n_shuffles + 1.0))
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_permutation_p_matches_cpu_specification(engine, seed):
+    from oracle import c_oracle
+    pb = random_batch(3000 + seed, n_blocks=1 + seed % 3, tri_frac=0.25 if seed % 2 else 0.0, R=(6, 900))
+    S = [1, 7, 100, 257][seed % 4]
+    ora = c_oracle.run(pb, min_common=[1, 5][seed % 2], het_only=True, n_shuffles=S, seed=99 + seed)
+    res = engine.run(pb, min_common=[1, 5][seed % 2], het_only=True, n_shuffles=S, seed=99 + seed, emit_counts=True)
+    assert_same_as_oracle(res, ora)
+    assert_perm_same(res, ora, S)
+
+
+def test_permutation_p_large_counts_and_tri_sites(engine):
+    """thousands of common reads: HRUA draws, exact-tail sums in both the centre and the tail form"""
+    import lgmi
+    from oracle import c_oracle
+    spec = lgmi.default_synth_spec(60, 40000, seed=5)
+    spec.tri_per_1024 = 250
+    db = engine.synth_dense(spec)
+    pb = db.download()
+    S = 64
+    res = engine.run_device(db, min_common=6, het_only=True, n_shuffles=S, seed=1234).fetch()
+    ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=S, seed=1234)
+    assert_perm_same(res, ora, S)
+    # linked het pairs are significant, independent pairs are not systematically so
+    t = pb.site_type
+    hh = (t[res.row_i] == 2) & (t[res.row_j] == 2)
+    assert hh.any() and (res.row_p[hh] == 1.0 / (S + 1)).all()
+    assert np.median(res.row_p[~hh]) > 0.2
+    db.free()
+
+
+def test_permutation_seed_changes_draws_not_counts(engine):
+    pb = random_batch(4242, n_blocks=1, P=(30, 30), R=(300, 300))
+    a = engine.run(pb, min_common=5, n_shuffles=500, seed=1, emit_counts=True)
+    b = engine.run(pb, min_common=5, n_shuffles=500, seed=2, emit_counts=True)
+    np.testing.assert_array_equal(a.row_counts, b.row_counts)
+    np.testing.assert_array_equal(a.row_mi, b.row_mi)
+    assert (a.row_exceed != b.row_exceed).any()
+    assert a.row_p.min() >= 1 / 501 and a.row_p.max() <= 1.0

@@ -1,0 +1,164 @@
+"""Statistical validation of the permutation-test SPECIFICATION (oracle/lgmi_perm_oracle.c).
+The reference has no permutation test (parity unpinned), so the specification itself is
+checked here against scipy's hypergeometric distribution and brute-force enumeration.
+CPU only."""
+import ctypes as C
+import itertools
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from oracle import c_oracle
+
+u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope='module')
+def lib():
+    lib = c_oracle.load()
+    lib.lgo_hg_draw_many.restype = C.c_int
+    lib.lgo_hg_draw_many.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, u32p]
+    lib.lgo_perm_ptail.restype = C.c_int
+    lib.lgo_perm_ptail.argtypes = [u32p, f64p]
+    return lib
+
+
+HG_CASES = [  # (pop, good, sample): urn path, HRUA path, complements, good > bad, extremes
+    (20, 7, 5), (20, 15, 5), (20, 7, 16), (1000, 3, 9), (1000, 997, 9), (1000, 500, 995),
+    (50, 25, 25), (300, 40, 150), (300, 260, 150), (300, 150, 20), (300, 150, 280),
+    (5000, 2500, 2500), (5000, 100, 4000), (5000, 4900, 1000), (160000, 80000, 48000),
+    (160000, 8000, 150000), (2000, 1990, 1000), (64, 10, 10), (64, 54, 54), (21, 11, 10), (21, 11, 11),
+]
+
+
+@pytest.mark.parametrize('pop,good,sample', HG_CASES)
+def test_hypergeometric_sampler_matches_scipy(lib, pop, good, sample):
+    n = 40000
+    out = np.zeros(n, np.uint32)
+    assert lib.lgo_hg_draw_many(pop, good, sample, 1234 + pop, n, out.ctypes.data_as(u32p)) == 0
+    lo, hi = max(0, sample + good - pop), min(good, sample)
+    assert out.min() >= lo and out.max() <= hi
+    ks = np.arange(lo, hi + 1)
+    pmf = stats.hypergeom.pmf(ks, pop, good, sample)
+    obs = np.bincount(out - lo, minlength=len(ks)).astype(float)
+    exp = pmf * n
+    # pool the sparse tails so that every cell expects >= 8 draws
+    order = np.argsort(-exp)
+    keep = exp[order] >= 8
+    o = np.append(obs[order][keep], obs[order][~keep].sum())
+    e = np.append(exp[order][keep], exp[order][~keep].sum())
+    if e[-1] < 1e-9:
+        o, e = o[:-1], e[:-1]
+    chi2 = ((o - e) ** 2 / e).sum()
+    p = stats.chi2.sf(chi2, len(e) - 1)
+    assert p > 1e-4, 'chi2 %.1f over %d cells, p=%.2e' % (chi2, len(e), p)
+    mean = good * sample / pop
+    assert abs(out.mean() - mean) < 5 * np.sqrt(max(stats.hypergeom.var(pop, good, sample), 1e-9) / n) + 1e-9
+
+
+def stat_of(table):
+    t = np.asarray(table, float).ravel()
+    return float(np.sum(np.where(t > 0, t * np.log(np.where(t > 0, t, 1.0)), 0.0)))
+
+
+def brute_ptail_2x2(T):
+    """exact P(S >= S_obs) band for a table with exactly 2 non-empty rows and columns"""
+    T = np.asarray(T).reshape(3, 3)
+    rows = [a for a in range(3) if T[a].sum()]
+    cols = [b for b in range(3) if T[:, b].sum()]
+    N, K, n = int(T.sum()), int(T[rows[1]].sum()), int(T[:, cols[1]].sum())
+    kobs = int(T[rows[1], cols[1]])
+    ks = np.arange(max(0, K + n - N), min(K, n) + 1)
+    pmf = stats.hypergeom.pmf(ks, N, K, n)
+    s = np.array([stat_of([[N - K - n + k, n - k], [K - k, k]]) for k in ks])
+    sobs = stat_of([[N - K - n + kobs, n - kobs], [K - kobs, kobs]])
+    tol = 1e-11 * max(1.0, abs(sobs))
+    return pmf[s > sobs + tol].sum(), pmf[s >= sobs - tol].sum()
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_exact_tail_probability_2x2(lib, seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([6, 13, 40, 200, 3000, 60000]))
+    a = rng.multinomial(N, rng.dirichlet(np.ones(4) * (0.5 + 3 * rng.random())))
+    r, c = sorted(rng.choice(3, 2, replace=False)), sorted(rng.choice(3, 2, replace=False))
+    T = np.zeros((3, 3), np.uint32)
+    T[np.ix_(r, c)] = a.reshape(2, 2)
+    if (T.sum(axis=1) > 0).sum() < 2 or (T.sum(axis=0) > 0).sum() < 2:
+        pytest.skip('degenerate draw')
+    p = C.c_double()
+    assert lib.lgo_perm_ptail(np.ascontiguousarray(T.ravel()).ctypes.data_as(u32p), C.byref(p)) == 0
+    lo, hi = brute_ptail_2x2(T)
+    assert lo - 1e-9 <= p.value <= hi + 1e-9, (p.value, lo, hi)
+
+
+def run_perm(tables, n_shuffles, seed=7):
+    lib = c_oracle.load()
+    t = np.ascontiguousarray(np.asarray(tables, np.uint32).reshape(-1, 9))
+    n = len(t)
+    ri = np.arange(n, dtype=np.uint32)
+    rj = ri + np.uint32(n)
+    p = np.zeros(n)
+    ex = np.zeros(n, np.uint32)
+    rc = lib.lgo_perm_rows(n, ri.ctypes.data_as(u32p), rj.ctypes.data_as(u32p), t.ctypes.data_as(u32p),
+                           n_shuffles, seed, p.ctypes.data_as(f64p), ex.ctypes.data_as(u32p), 0)
+    assert rc == 0
+    return p, ex
+
+
+def test_degenerate_tables_have_p_one():
+    p, ex = run_perm([[0, 0, 0, 0, 5, 9, 0, 0, 0], [0, 0, 0, 0, 4, 0, 0, 7, 0]], 100)
+    assert (ex == 100).all() and (p == 1.0).all()
+
+
+def test_monte_carlo_2x2_agrees_with_exact_tail(lib):
+    tables = [[0, 0, 0, 0, 30, 10, 0, 12, 28], [0, 0, 0, 0, 5, 4, 0, 3, 6], [0, 0, 0, 0, 500, 480, 0, 470, 520],
+              [7, 0, 3, 0, 0, 0, 2, 0, 9]]
+    S = 40000
+    p, ex = run_perm(tables, S)
+    for T, e in zip(tables, ex):
+        pt = C.c_double()
+        lib.lgo_perm_ptail(np.asarray(T, np.uint32).ctypes.data_as(u32p), C.byref(pt))
+        sd = np.sqrt(max(pt.value * (1 - pt.value), 1e-12) / S)
+        assert abs(e / S - pt.value) < 5 * sd + 1e-9
+
+
+def exact_p_general(T):
+    """brute-force P(S >= S_obs) over all tables with the margins of T (small N only)"""
+    T = np.asarray(T).reshape(3, 3)
+    R, Cm, N = T.sum(axis=1), T.sum(axis=0), int(T.sum())
+    sobs = stat_of(T)
+    from math import lgamma
+    const = sum(lgamma(x + 1) for x in R) + sum(lgamma(x + 1) for x in Cm) - lgamma(N + 1)
+    tot = tail = 0.0
+    for a, b, c, d in itertools.product(range(R[0] + 1), range(R[0] + 1), range(R[1] + 1), range(R[1] + 1)):
+        t = np.array([[a, b, R[0] - a - b], [c, d, R[1] - c - d], [0, 0, 0]])
+        t[2] = Cm - t[0] - t[1]
+        if (t < 0).any():
+            continue
+        pr = np.exp(const - sum(lgamma(x + 1) for x in t.ravel()))
+        tot += pr
+        if stat_of(t) >= sobs - 1e-11 * max(1, abs(sobs)):
+            tail += pr
+    assert abs(tot - 1) < 1e-9
+    return tail
+
+
+@pytest.mark.parametrize('T', [[3, 2, 1, 1, 6, 2, 2, 1, 7], [4, 0, 2, 1, 5, 0, 0, 2, 6], [0, 0, 0, 2, 6, 3, 5, 1, 4],
+                               [2, 0, 5, 1, 0, 8, 6, 0, 3], [10, 3, 2, 2, 9, 4, 1, 3, 12]])
+def test_monte_carlo_general_tables_agree_with_enumeration(T):
+    S = 30000
+    p, ex = run_perm([T], S)
+    exact = exact_p_general(T)
+    sd = np.sqrt(max(exact * (1 - exact), 1e-12) / S)
+    assert abs(ex[0] / S - exact) < 5 * sd + 2e-4, (ex[0] / S, exact)
+
+
+def test_streams_are_keyed_by_seed_and_pair():
+    T = [[0, 0, 0, 0, 30, 14, 0, 12, 28]] * 4
+    p1, e1 = run_perm(T, 999, seed=1)
+    p2, e2 = run_perm(T, 999, seed=2)
+    p3, e3 = run_perm(T, 999, seed=1)
+    assert (e1 == e3).all() and (e1 != e2).any() and len(set(e1.tolist())) > 1
+    assert np.allclose(p1, (1 + e1) / 1000.0)
