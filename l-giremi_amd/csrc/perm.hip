@@ -52,7 +52,7 @@ __device__ __forceinline__ double det_exp(double x) {   // x <= 0
     const double r = (x - k * LN2_HI) - k * LN2_LO;
     double p = 1.0;
 #pragma unroll
-    for (int n = 14; n >= 1; --n) p = 1.0 + p * (r * inv_n(n));
+    for (int n = 11; n >= 1; --n) p = 1.0 + p * (r * inv_n(n));   // |r| <= 0.347: error < 1e-14
     const int ki = (int)k;
     if (ki >= -1000) return p * __longlong_as_double((long long)(ki + 1023) << 52);
     return (p * __longlong_as_double((long long)(-1000 + 1023) << 52)) *
@@ -72,12 +72,18 @@ __device__ __forceinline__ double det_log(double x) {   // x > 0, normal
     return (double)e * LN2_HI + (2.0 * f * s + (double)e * LN2_LO);
 }
 
-__device__ __forceinline__ double det_sqrt(double a) {   // a > 0
+__device__ __forceinline__ double det_sqrt(double a) {   // a > 0: division-free Newton on 1/sqrt(a), then a*y
     const unsigned long long b = (unsigned long long)__double_as_longlong(a);
-    double x = __longlong_as_double((long long)((b >> 1) + 0x1FF8000000000000ull));
+    double y = __longlong_as_double((long long)(0x5FE6EB50C7B537A9ull - (b >> 1)));
 #pragma unroll
-    for (int n = 0; n < 6; ++n) x = 0.5 * (x + a / x);
-    return x;
+    for (int n = 0; n < 5; ++n) {
+        double t = a * y;
+        t = t * y;
+        t = 0.5 * t;
+        t = 1.5 - t;
+        y = y * t;
+    }
+    return a * y;
 }
 
 // ---------------------------------------------------------------- 2 x 2 exact tail
@@ -96,54 +102,63 @@ __device__ __forceinline__ double pmf22(const double* __restrict__ LF, const HG2
     return det_exp(e);
 }
 
-__device__ double ptail22(const long long* __restrict__ G, const double* __restrict__ LF, const HG22& h, uint32_t kobs) {
+// lane-private part of the exact tail: bisection for the far boundary of the "as or more
+// extreme" set {k <= klo} U {k >= khi}, and the choice between summing that set or its
+// complement (whichever lies within ~7 sigma)
+struct Tail22 { long long klo, khi; int centre; };
+
+__device__ Tail22 bounds22(const long long* __restrict__ G, const HG22& h, uint32_t kobs) {
     const long long sobs = stat22(G, h, kobs);
     uint32_t kc = (uint32_t)(((unsigned long long)h.n * (unsigned long long)h.K) / (unsigned long long)h.N);
     if (kc < h.kmin) kc = h.kmin;
     if (kc > h.kmax) kc = h.kmax;
-    long long klo, khi;   // tail = [kmin, klo] U [khi, kmax]
+    Tail22 t;
     if (kobs <= kc) {
         long long lo = (long long)kc + 1, hi = (long long)h.kmax + 1;
-        klo = kobs;
+        t.klo = kobs;
         while (lo < hi) {
             const long long mid = lo + (hi - lo) / 2;
             if (stat22(G, h, (uint32_t)mid) >= sobs) hi = mid; else lo = mid + 1;
         }
-        khi = lo;
+        t.khi = lo;
     } else {
         long long lo = (long long)h.kmin - 1, hi = (long long)kc;
-        khi = kobs;
+        t.khi = kobs;
         while (lo < hi) {
             const long long mid = lo + (hi - lo + 1) / 2;
             if (stat22(G, h, (uint32_t)mid) >= sobs) lo = mid; else hi = mid - 1;
         }
-        klo = lo;
+        t.klo = lo;
     }
     const double var = (double)h.n * (double)h.K * (double)(h.N - h.K) * (double)(h.N - h.n) /
                        ((double)h.N * (double)h.N * (double)(h.N > 1 ? h.N - 1 : 1));
-    const double clen = (double)(khi - klo - 1);
-    double p;
-    if (clen * clen <= 16.0 * var + 64.0) {
-        double c = 0.0;
-        for (long long k = klo + 1; k < khi; ++k) c += pmf22(LF, h, (uint32_t)k);
-        p = 1.0 - c;
-    } else {
-        double acc = 0.0;
-        for (long long k = klo; k >= (long long)h.kmin; --k) {
-            const double term = pmf22(LF, h, (uint32_t)k);
+    const double clen = (double)(t.khi - t.klo - 1);
+    t.centre = (clen * clen <= 49.0 * var + 64.0) ? 1 : 0;
+    return t;
+}
+
+// wave-cooperative run: term number q goes to lane q % 64; after each 64-term chunk the
+// run stops when its farthest term has fallen below 2^-44 of the run's first term.
+// All control flow is wave-uniform (count, base and the two broadcast terms).
+__device__ __forceinline__ void run_sum_wave(const double* __restrict__ LF, const HG22& h, long long k0, long long kend,
+                                             int dir, int stop_rule, uint32_t lane, double& acc) {
+    const long long count = dir > 0 ? kend - k0 + 1 : k0 - kend + 1;
+    if (count <= 0) return;
+    double first = 0.0;
+    for (long long base = 0; base < count; base += 64) {
+        const long long idx = base + lane;
+        double term = 0.0;
+        if (idx < count) {
+            term = pmf22(LF, h, (uint32_t)(k0 + dir * idx));
             acc += term;
-            if (term < acc * 2.168404344971009e-19) break;
         }
-        for (long long k = khi; k <= (long long)h.kmax; ++k) {
-            const double term = pmf22(LF, h, (uint32_t)k);
-            acc += term;
-            if (term < acc * 2.168404344971009e-19) break;
+        if (base == 0) first = __shfl(term, 0);
+        if (stop_rule) {
+            const long long rem = count - base - 1;
+            const double last = __shfl(term, (int)(rem < 63 ? rem : 63));
+            if (!(last >= first * 5.684341886080802e-14)) break;
         }
-        p = acc;
     }
-    if (p > 1.0) p = 1.0;
-    if (p < 0.0) p = 0.0;
-    return p;
 }
 
 __global__ __launch_bounds__(256) void k_perm_fast(
@@ -153,35 +168,74 @@ __global__ __launch_bounds__(256) void k_perm_fast(
     uint32_t* __restrict__ gen_list, unsigned int* __restrict__ gen_count)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    uint32_t T[9];
+    const uint32_t lane = threadIdx.x & 63u;
+    // ---- phase A (one lane per row): classify, set up the hypergeometric, find the bounds
+    int kind = 0;   // 0 nothing, 1 degenerate, 2 two-by-two, 3 queued for k_perm_general
+    HG22 h = {1u, 0u, 0u, 0u, 0u, 0.0};
+    Tail22 tb = {0, 0, 1};
+    if (r < n_rows) {
+        uint32_t T[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) T[k] = counts[9 * r + k];
-    uint32_t R[3], C[3], N = 0;
+        for (int k = 0; k < 9; ++k) T[k] = counts[9 * r + k];
+        uint32_t R[3], C[3], N = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2];
-        C[a] = T[a] + T[3 + a] + T[6 + a];
-        N += R[a];
+        for (int a = 0; a < 3; ++a) {
+            R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2];
+            C[a] = T[a] + T[3 + a] + T[6 + a];
+            N += R[a];
+        }
+        const int nr = (R[0] != 0) + (R[1] != 0) + (R[2] != 0), nc = (C[0] != 0) + (C[1] != 0) + (C[2] != 0);
+        if (nr <= 1 || nc <= 1) {
+            kind = 1;
+        } else if (nr == 2 && nc == 2) {
+            kind = 2;
+            const int a2 = R[2] ? 2 : 1, b2 = C[2] ? 2 : 1;   // second non-empty row / column
+            h.N = N; h.K = R[a2]; h.n = C[b2];
+            h.kmin = h.K + h.n > N ? h.K + h.n - N : 0u;
+            h.kmax = h.K < h.n ? h.K : h.n;
+            h.c0 = LF[h.K];
+            h.c0 += LF[N - h.K];
+            h.c0 += LF[h.n];
+            h.c0 += LF[N - h.n];
+            h.c0 -= LF[N];
+            tb = bounds22(G, h, T[3 * a2 + b2]);
+        } else {
+            kind = 3;
+            gen_list[atomicAdd(gen_count, 1u)] = (uint32_t)r;
+        }
     }
-    const int nr = (R[0] != 0) + (R[1] != 0) + (R[2] != 0), nc = (C[0] != 0) + (C[1] != 0) + (C[2] != 0);
+    // ---- phase B (the wave works on one row at a time): exact tail mass
+    double my_p = 1.0;
+    unsigned long long todo = __ballot(kind == 2);
+    while (todo) {
+        const int L = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        HG22 hb;
+        hb.N = __shfl(h.N, L); hb.K = __shfl(h.K, L); hb.n = __shfl(h.n, L);
+        hb.kmin = __shfl(h.kmin, L); hb.kmax = __shfl(h.kmax, L); hb.c0 = __shfl(h.c0, L);
+        const long long klo = __shfl(tb.klo, L), khi = __shfl(tb.khi, L);
+        const int centre = __shfl(tb.centre, L);
+        double acc = 0.0;
+        if (centre) {
+            run_sum_wave(LF, hb, klo + 1, khi - 1, +1, 0, lane, acc);
+        } else {
+            run_sum_wave(LF, hb, klo, (long long)hb.kmin, -1, 1, lane, acc);
+            run_sum_wave(LF, hb, khi, (long long)hb.kmax, +1, 1, lane, acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        double p = centre ? 1.0 - acc : acc;
+        if (p > 1.0) p = 1.0;
+        if (p < 0.0) p = 0.0;
+        if ((int)lane == L) my_p = p;
+    }
+    // ---- phase C (one lane per row): the shuffles
+    if (kind == 0 || kind == 3) return;
     uint32_t exceed;
-    if (nr <= 1 || nc <= 1) {
+    if (kind == 1) {
         exceed = n_shuffles;
-    } else if (nr == 2 && nc == 2) {
-        // second non-empty row / column
-        const int a2 = R[2] ? 2 : 1, b2 = C[2] ? 2 : 1;
-        HG22 h;
-        h.N = N; h.K = R[a2]; h.n = C[b2];
-        h.kmin = h.K + h.n > N ? h.K + h.n - N : 0u;
-        h.kmax = h.K < h.n ? h.K : h.n;
-        h.c0 = LF[h.K];
-        h.c0 += LF[N - h.K];
-        h.c0 += LF[h.n];
-        h.c0 += LF[N - h.n];
-        h.c0 -= LF[N];
-        const double p = ptail22(G, LF, h, T[3 * a2 + b2]);
-        unsigned long long thr = (unsigned long long)(p * 4294967296.0);
+    } else {
+        unsigned long long thr = (unsigned long long)(my_p * 4294967296.0);
         if (thr > 4294967296ull) thr = 4294967296ull;
         const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), ci = row_i[r], cj = row_j[r];
         exceed = 0;
@@ -192,9 +246,6 @@ __global__ __launch_bounds__(256) void k_perm_fast(
             if (s + 2u < n_shuffles) exceed += ((unsigned long long)o.z < thr);
             if (s + 3u < n_shuffles) exceed += ((unsigned long long)o.w < thr);
         }
-    } else {
-        gen_list[atomicAdd(gen_count, 1u)] = (uint32_t)r;
-        return;
     }
     out_exceed[r] = exceed;
     out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
@@ -218,7 +269,29 @@ __device__ __forceinline__ double next_uniform(GenStream& g) {   // (0,1): (m + 
 #define HRUA_D1 1.7155277699214135
 #define HRUA_D2 0.8989161620588988
 
-__device__ uint32_t hg_draw(const double* __restrict__ LF, uint32_t pop, uint32_t good, uint32_t sample, GenStream& g) {
+// HRUA set-up of one (pop, good, sample); hoisted out of the shuffle loop for the one draw
+// whose parameters do not depend on earlier draws (the values are what hg_draw computes)
+struct HrSetup { uint32_t pop, good, sample; double d6, d8, d10, d11; };
+
+__device__ __forceinline__ void hrua_setup(const double* __restrict__ LF, uint32_t pop, uint32_t good, uint32_t sample,
+                                           HrSetup& hs) {
+    const uint32_t bad = pop - good;
+    const uint32_t m = sample < pop - sample ? sample : pop - sample;
+    const uint32_t mn = good < bad ? good : bad, mx = good < bad ? bad : good;
+    const double d4 = (double)mn / (double)pop, d5 = 1.0 - d4;
+    hs.pop = pop; hs.good = good; hs.sample = sample;
+    hs.d6 = (double)m * d4 + 0.5;
+    const double d7 = det_sqrt((double)(pop - m) * (double)m * d4 * d5 / (double)(pop - 1u) + 0.5);
+    hs.d8 = HRUA_D1 * d7 + HRUA_D2;
+    const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * (double)(mn + 1u) / ((double)pop + 2.0));
+    hs.d10 = LF[d9] + LF[mn - d9] + LF[m - d9] + LF[mx - m + d9];
+    const double cap = (double)((m < mn ? m : mn) + 1u);
+    const double lim = floor(hs.d6 + 16.0 * d7);
+    hs.d11 = cap < lim ? cap : lim;
+}
+
+__device__ __noinline__ uint32_t hg_draw(const double* __restrict__ LF, uint32_t pop, uint32_t good, uint32_t sample,
+                                         GenStream& g, const HrSetup& cached) {
     const uint32_t bad = pop - good;
     const uint32_t m = sample < pop - sample ? sample : pop - sample;
     uint32_t z;
@@ -237,22 +310,15 @@ __device__ uint32_t hg_draw(const double* __restrict__ LF, uint32_t pop, uint32_
         z = good - rem_good;
     } else {
         const uint32_t mn = good < bad ? good : bad, mx = good < bad ? bad : good;
-        const double d4 = (double)mn / (double)pop, d5 = 1.0 - d4;
-        const double d6 = (double)m * d4 + 0.5;
-        const double d7 = det_sqrt((double)(pop - m) * (double)m * d4 * d5 / (double)(pop - 1u) + 0.5);
-        const double d8 = HRUA_D1 * d7 + HRUA_D2;
-        const uint32_t d9 = (uint32_t)(((unsigned long long)(m + 1u) * (unsigned long long)(mn + 1u)) /
-                                       ((unsigned long long)pop + 2ull));
-        const double d10 = LF[d9] + LF[mn - d9] + LF[m - d9] + LF[mx - m + d9];
-        const double cap = (double)((m < mn ? m : mn) + 1u);
-        const double lim = floor(d6 + 16.0 * d7);
-        const double d11 = cap < lim ? cap : lim;
+        HrSetup hs;
+        if (cached.pop == pop && cached.good == good && cached.sample == sample) hs = cached;
+        else hrua_setup(LF, pop, good, sample, hs);
         for (;;) {
             const double x = next_uniform(g), y = next_uniform(g);
-            const double w = d6 + d8 * (y - 0.5) / x;
-            if (w < 0.0 || w >= d11) continue;
+            const double w = hs.d6 + hs.d8 * (y - 0.5) / x;
+            if (w < 0.0 || w >= hs.d11) continue;
             const uint32_t zc = (uint32_t)floor(w);
-            const double tt = d10 - (LF[zc] + LF[mn - zc] + LF[m - zc] + LF[mx - m + zc]);
+            const double tt = hs.d10 - (LF[zc] + LF[mn - zc] + LF[m - zc] + LF[mx - m + zc]);
             if (x * (4.0 - x) - 3.0 <= tt) { z = zc; break; }
             if (x * (x - tt) >= 1.0) continue;
             if (2.0 * det_log(x) <= tt) { z = zc; break; }
@@ -287,6 +353,17 @@ __global__ __launch_bounds__(256) void k_perm_general(
         long long sobs = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) sobs += G[T[k]];
+        // the first draw that is not trivially determined has the same parameters in every shuffle
+        HrSetup fixed;
+        fixed.pop = 0u; fixed.good = 0u; fixed.sample = 0u; fixed.d6 = 0.0; fixed.d8 = 0.0; fixed.d10 = 0.0; fixed.d11 = 0.0;
+        {
+            const uint32_t cb = C[0] ? C[0] : (C[1] ? C[1] : C[2]);          // first non-empty column
+            uint32_t pop = N, good = R[0];
+            if (good == 0u) { good = R[1]; }                                  // row 0 empty: its draw is trivial
+            if (good == pop) { pop = 0u; }                                    // (cannot happen with >= 2 non-empty rows)
+            const uint32_t m = cb < pop - cb ? cb : pop - cb;
+            if (pop && good && good < pop && cb < pop && m >= 10u) hrua_setup(LF, pop, good, cb, fixed);
+        }
         uint32_t exceed = 0;
         for (uint32_t s = lane; s < n_shuffles; s += 64u) {
             GenStream g;
@@ -294,16 +371,17 @@ __global__ __launch_bounds__(256) void k_perm_general(
             g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0;
             uint32_t rr0 = R[0], rr1 = R[1], rr2 = R[2], pop_all = N;
             long long ss = 0;
-#pragma unroll
+#pragma unroll 1
             for (int b = 0; b < 3; ++b) {
-                uint32_t cc = C[b], pop = pop_all;
-                const uint32_t x0 = hg_draw(LF, pop, rr0, cc, g);
+                const uint32_t cb = b == 0 ? C[0] : (b == 1 ? C[1] : C[2]);
+                uint32_t cc = cb, pop = pop_all;
+                const uint32_t x0 = hg_draw(LF, pop, rr0, cc, g, fixed);
                 pop -= rr0; cc -= x0;
-                const uint32_t x1 = hg_draw(LF, pop, rr1, cc, g);
-                pop -= rr1; cc -= x1;
-                const uint32_t x2 = hg_draw(LF, pop, rr2, cc, g);
+                const uint32_t x1 = hg_draw(LF, pop, rr1, cc, g, fixed);
+                cc -= x1;                        // the last row takes what is left of the column
+                const uint32_t x2 = cc;
                 rr0 -= x0; rr1 -= x1; rr2 -= x2;
-                pop_all -= C[b];
+                pop_all -= cb;
                 ss += G[x0] + G[x1] + G[x2];
             }
             exceed += (ss >= sobs);
@@ -324,8 +402,8 @@ void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const u
     if (!n_rows) return;
     hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, n_rows, out_i, out_j,
                        counts, G, LF, n_shuffles, seed, out_p, out_exceed, gen_list, gen_count);
-    // 256 CUs x 8 waves: a fixed grid whose waves stride over the queued rows
-    hipLaunchKernelGGL(k_perm_general, dim3(512), dim3(256), 0, st, gen_list, gen_count, out_i, out_j, counts, G, LF,
+    // a fixed grid (8 blocks per CU) whose waves stride over the queued rows
+    hipLaunchKernelGGL(k_perm_general, dim3(2048), dim3(256), 0, st, gen_list, gen_count, out_i, out_j, counts, G, LF,
                        n_shuffles, seed, out_p, out_exceed);
 }
 

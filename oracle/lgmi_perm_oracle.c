@@ -71,7 +71,7 @@ static const double INV_N[24] = {0.0, 1.0, 1.0 / 2.0, 1.0 / 3.0, 1.0 / 4.0, 1.0 
                                  1.0 / 16.0, 1.0 / 17.0, 1.0 / 18.0, 1.0 / 19.0, 1.0 / 20.0, 1.0 / 21.0, 1.0 / 22.0,
                                  1.0 / 23.0};
 
-double lgo_det_exp(double x)   /* x <= 0; relative error ~1e-16, identical on CPU and GPU */
+double lgo_det_exp(double x)   /* x <= 0; relative error ~1e-14, identical on CPU and GPU */
 {
     double k, r, p;
     int ki, n;
@@ -80,7 +80,7 @@ double lgo_det_exp(double x)   /* x <= 0; relative error ~1e-16, identical on CP
     k = floor(x * INV_LN2 + 0.5);
     r = (x - k * LN2_HI) - k * LN2_LO;
     p = 1.0;
-    for (n = 14; n >= 1; --n) p = 1.0 + p * (r * INV_N[n]);   /* Horner form of sum r^n/n! */
+    for (n = 11; n >= 1; --n) p = 1.0 + p * (r * INV_N[n]);   /* Horner form of sum r^n/n!, |r| <= 0.347: error < 1e-14 */
     ki = (int)k;
     if (ki >= -1000) return p * bits_to_double((uint64_t)(ki + 1023) << 52);
     return (p * bits_to_double((uint64_t)(-1000 + 1023) << 52)) * bits_to_double((uint64_t)(ki + 1000 + 1023) << 52);
@@ -100,13 +100,19 @@ double lgo_det_log(double x)   /* x > 0, normal */
     return (double)e * LN2_HI + (2.0 * f * s + (double)e * LN2_LO);
 }
 
-double lgo_det_sqrt(double a)   /* a > 0: Newton from an exponent-halving guess, 6 steps */
+double lgo_det_sqrt(double a)   /* a > 0: division-free Newton on 1/sqrt(a) from a bit-level guess, then a*y */
 {
-    uint64_t b = double_to_bits(a);
-    double x = bits_to_double((b >> 1) + 0x1FF8000000000000ull);
+    const uint64_t b = double_to_bits(a);
+    double y = bits_to_double(0x5FE6EB50C7B537A9ull - (b >> 1));
     int n;
-    for (n = 0; n < 6; ++n) x = 0.5 * (x + a / x);
-    return x;
+    for (n = 0; n < 5; ++n) {
+        double t = a * y;
+        t = t * y;
+        t = 0.5 * t;
+        t = 1.5 - t;
+        y = y * t;
+    }
+    return a * y;
 }
 
 /* ------------------------------------------------------------------ tables */
@@ -171,7 +177,7 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
         const double d6 = (double)m * d4 + 0.5;
         const double d7 = lgo_det_sqrt((double)(pop - m) * (double)m * d4 * d5 / (double)(pop - 1) + 0.5);
         const double d8 = HRUA_D1 * d7 + HRUA_D2;
-        const uint32_t d9 = (uint32_t)(((uint64_t)(m + 1) * (uint64_t)(mn + 1)) / ((uint64_t)pop + 2));   /* mode */
+        const uint32_t d9 = (uint32_t)floor((double)(m + 1) * (double)(mn + 1) / ((double)pop + 2.0));   /* mode */
         const double d10 = t->LF[d9] + t->LF[mn - d9] + t->LF[m - d9] + t->LF[mx - m + d9];
         const double cap = (double)((m < mn ? m : mn) + 1u);
         const double lim = floor(d6 + 16.0 * d7);
@@ -226,13 +232,49 @@ static double pmf22(const perm_tables* t, const hg22* h, uint32_t k)
     return lgo_det_exp(e);
 }
 
+/* 64-way strided summation, the order the GPU wave uses: term number q of a run goes to
+ * accumulator q % 64; the 64 accumulators are combined by an xor butterfly. */
+static double butterfly64(double acc[64])
+{
+    int o, l;
+    for (o = 32; o > 0; o >>= 1) {
+        double nxt[64];
+        for (l = 0; l < 64; ++l) nxt[l] = acc[l] + acc[l ^ o];
+        memcpy(acc, nxt, sizeof nxt);
+    }
+    return acc[0];
+}
+
+/* sum pmf over k = k0, k0+dir, ... up to kend (inclusive) in chunks of 64 terms; after a
+ * chunk, stop if its farthest term is below 2^-44 of the run's first term (terms only
+ * decrease moving away from the mode).  stop_rule = 0 sums the whole range. */
+static void run_sum(const perm_tables* t, const hg22* h, int64_t k0, int64_t kend, int dir, int stop_rule, double acc[64])
+{
+    const int64_t count = dir > 0 ? kend - k0 + 1 : k0 - kend + 1;
+    int64_t base;
+    double first = 0.0;
+    if (count <= 0) return;
+    first = pmf22(t, h, (uint32_t)k0);
+    for (base = 0; base < count; base += 64) {
+        int l;
+        double last = 0.0;
+        for (l = 0; l < 64 && base + l < count; ++l) {
+            const double term = pmf22(t, h, (uint32_t)(k0 + dir * (base + l)));
+            acc[l] += term;
+            last = term;
+        }
+        if (stop_rule && !(last >= first * 5.684341886080802e-14)) break;   /* 2^-44 */
+    }
+}
+
 /* P(S(k) >= S(k_obs)) under the hypergeometric null */
 static double ptail22(const perm_tables* t, const hg22* h, uint32_t kobs)
 {
     const int64_t sobs = stat22(t, h, kobs);
     uint32_t kc = (uint32_t)(((uint64_t)h->n * (uint64_t)h->K) / (uint64_t)h->N);   /* S decreases up to kc, increases after */
     int64_t klo, khi;   /* tail = [kmin, klo] U [khi, kmax] */
-    double var, clen, p;
+    double var, clen, p, acc[64];
+    int l;
     if (kc < h->kmin) kc = h->kmin;
     if (kc > h->kmax) kc = h->kmax;
     if (kobs <= kc) {
@@ -255,26 +297,15 @@ static double ptail22(const perm_tables* t, const hg22* h, uint32_t kobs)
     var = (double)h->n * (double)h->K * (double)(h->N - h->K) * (double)(h->N - h->n)
           / ((double)h->N * (double)h->N * (double)(h->N > 1 ? h->N - 1 : 1));
     clen = (double)(khi - klo - 1);
-    if (clen * clen <= 16.0 * var + 64.0) {
-        /* few values are less extreme: 1 - their mass */
-        double c = 0.0;
-        int64_t k;
-        for (k = klo + 1; k < khi; ++k) c += pmf22(t, h, (uint32_t)k);
-        p = 1.0 - c;
+    for (l = 0; l < 64; ++l) acc[l] = 0.0;
+    if (clen * clen <= 49.0 * var + 64.0) {
+        /* few values are less extreme (within ~7 sigma): 1 - their mass */
+        run_sum(t, h, klo + 1, khi - 1, +1, 0, acc);
+        p = 1.0 - butterfly64(acc);
     } else {
-        double acc = 0.0;
-        int64_t k;
-        for (k = klo; k >= (int64_t)h->kmin; --k) {
-            const double term = pmf22(t, h, (uint32_t)k);
-            acc += term;
-            if (term < acc * 2.168404344971009e-19) break;   /* 2^-62 */
-        }
-        for (k = khi; k <= (int64_t)h->kmax; ++k) {
-            const double term = pmf22(t, h, (uint32_t)k);
-            acc += term;
-            if (term < acc * 2.168404344971009e-19) break;
-        }
-        p = acc;
+        run_sum(t, h, klo, (int64_t)h->kmin, -1, 1, acc);
+        run_sum(t, h, khi, (int64_t)h->kmax, +1, 1, acc);
+        p = butterfly64(acc);
     }
     if (p > 1.0) p = 1.0;
     if (p < 0.0) p = 0.0;
