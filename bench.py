@@ -63,7 +63,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='north_star_dense_50kx200k', choices=sorted(WORKLOADS))
-    ap.add_argument('--shuffles', type=int, default=0)
+    ap.add_argument('--shuffles', type=int, default=1000)     # BASELINE.json configs[1]: 1000-shuffle permutation p
     ap.add_argument('--min-common', type=int, default=6)      # l-giremi CLI default (script/giremi.py:212-216)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()

@@ -125,7 +125,7 @@ struct lgmi_dresult {
     bool has_p = false, has_counts = false;
 };
 
-struct HostResult {  // owner_ of a host lgmi_result
+struct HostResult : ResultOwner {  // owner_ of a host lgmi_result
     std::vector<uint32_t> i, j, exceed, counts, npairs;
     std::vector<double> mi, p, mean;
 };
@@ -686,7 +686,7 @@ extern "C" int lgmi_dresult_device_ptrs(const lgmi_dresult* r, lgmi_result* v) {
 
 extern "C" void lgmi_result_free(lgmi_result* res) {
     if (!res) return;
-    delete static_cast<HostResult*>(res->owner_);
+    delete static_cast<ResultOwner*>(res->owner_);
     memset(res, 0, sizeof *res);
 }
 
@@ -723,7 +723,7 @@ extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out) {
     out->row_exceed = r->has_p ? h->exceed.data() : nullptr;
     out->row_counts = r->has_counts ? h->counts.data() : nullptr;
     out->site_mean_mi = h->mean.data(); out->site_n_pairs = h->npairs.data();
-    out->owner_ = h;
+    out->owner_ = static_cast<ResultOwner*>(h);
     guard.p = nullptr;
     return LGMI_OK;
 }

@@ -55,6 +55,9 @@ struct SiteMap {
 };
 static const uint32_t NONE = 0xFFFFFFFFu;
 
+// what lgmi_result.owner_ points to (api.cpp, comm.cpp); released by lgmi_result_free()
+struct ResultOwner { virtual ~ResultOwner() {} };
+
 static const int TILE = 64;      // tile edge in columns
 static const int KC = 8;         // 64-bit words staged per LDS stage
 static const double MEAN_SCALE = 1099511627776.0;  // 2^40 fixed point for mean MI

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_perm_general(
             GenStream g;
             g.c0 = s; g.c1 = row_i[r]; g.c2 = row_j[r];
             g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0;
-            uint32_t rr0 = R[0], rr1 = R[1], rr2 = R[2], pop_all = N;
+            uint32_t rr0 = R[0], rr1 = R[1], pop_all = N;
             long long ss = 0;
 #pragma unroll 1
             for (int b = 0; b < 3; ++b) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void k_perm_general(
                 const uint32_t x1 = hg_draw(LF, pop, rr1, cc, g, fixed);
                 cc -= x1;                        // the last row takes what is left of the column
                 const uint32_t x2 = cc;
-                rr0 -= x0; rr1 -= x1; rr2 -= x2;
+                rr0 -= x0; rr1 -= x1;
                 pop_all -= cb;
                 ss += G[x0] + G[x1] + G[x2];
             }

