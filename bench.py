@@ -29,7 +29,10 @@ WORKLOADS = {
     'small_dense_2kx20k': dict(n_sites=2_000, n_reads=20_000),
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 (= 157.3 TF fp32 / 2)
+# non-packed VALU: one wave64 instruction per 4 cycles per SIMD (MI355X_MICROARCH.md 'vector-instruction ISSUE
+# cost': v_add_f32 4 cyc; the 157.3 TF fp32 peak counts packed 2-wide FMAs).  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz.
+# Measured with tools/ubench_valu.hip: 40.4e12 lane-ops/s for v_and_b32 + v_add_u32 (profiles/r01_ubench_valu.txt).
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # 3.93e13
 WORD_OP_LANE_OPS = 4                  # one 64-bit AND+POPC = 2 v_and_b32 + 2 v_bcnt_u32_b32
 
 
