@@ -481,17 +481,23 @@ static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
             if (!c.nw) continue;
             ymin[q / TILE] = std::min(ymin[q / TILE], c.w0); ymax[q / TILE] = std::max(ymax[q / TILE], c.w0 + c.nw);
         }
-        for (uint32_t tx = 0; tx < ntx; ++tx) {
-            if (xmin[tx] >= xmax[tx]) continue;
-            const uint32_t x0 = tx * TILE, x1 = std::min(x0 + TILE, bp.nx);
+        // tile order: groups of XG x-tile rows sweep the y tiles together, so that the XG tiles that
+        // run side by side on an XCD (count.hip: xcd_remap) share one y tile in L2 and every y column is
+        // fetched from HBM once per group instead of once per x-tile row
+        const uint32_t XG = 8;
+        for (uint32_t tg = 0; tg < ntx; tg += XG) {
             for (uint32_t ty = 0; ty < nty; ++ty) {
                 if (ymin[ty] >= ymax[ty]) continue;
                 const uint32_t y0 = ty * TILE, y1 = std::min(y0 + TILE, bp.ny);
-                // x site rows against x site cols: only row rank < col rank is ever read
-                if (x1 <= nxs && y0 >= y_xpart && y1 <= y_xpart + nxs && x0 >= (y1 - 1 - y_xpart)) continue;
-                const uint32_t k0 = std::max(xmin[tx], ymin[ty]), k1 = std::min(xmax[tx], ymax[ty]);
-                if (k0 >= k1) continue;
-                pl.tiles.push_back(Tile{(uint32_t)b, x0, y0, k0, k1});
+                for (uint32_t tx = tg; tx < std::min(tg + XG, ntx); ++tx) {
+                    if (xmin[tx] >= xmax[tx]) continue;
+                    const uint32_t x0 = tx * TILE, x1 = std::min(x0 + TILE, bp.nx);
+                    // x site rows against x site cols: only row rank < col rank is ever read
+                    if (x1 <= nxs && y0 >= y_xpart && y1 <= y_xpart + nxs && x0 >= (y1 - 1 - y_xpart)) continue;
+                    const uint32_t k0 = std::max(xmin[tx], ymin[ty]), k1 = std::min(xmax[tx], ymax[ty]);
+                    if (k0 >= k1) continue;
+                    pl.tiles.push_back(Tile{(uint32_t)b, x0, y0, k0, k1});
+                }
             }
         }
     }

@@ -38,11 +38,15 @@ __device__ __forceinline__ uint4 ld_entry(const StageCol& c, uint32_t k) {
     return v;
 }
 
-#define LGMI_PAIR(xe, ye, i)                                   \
-    accN[i] += __popc(xe.x & ye.x) + __popc(xe.y & ye.y);      \
-    accR[i] += __popc(xe.z & ye.x) + __popc(xe.w & ye.y);      \
-    accC[i] += __popc(xe.x & ye.z) + __popc(xe.y & ye.w);      \
-    accA[i] += __popc(xe.z & ye.z) + __popc(xe.w & ye.w);
+// v_bcnt_u32_b32 dst, src0, src1 computes popcount(src0) + src1: one instruction per 32-bit half.
+// Written as inline asm because hipcc otherwise selects bcnt(a,0), bcnt(b,0) and a v_add3_u32
+// for `acc += popc(a) + popc(b)` — 25 % more VALU instructions in a VALU-bound loop.
+#define LGMI_CNT(acc, v) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(v));
+#define LGMI_PAIR(xe, ye, i)                                    \
+    LGMI_CNT(accN[i], xe.x & ye.x) LGMI_CNT(accN[i], xe.y & ye.y) \
+    LGMI_CNT(accR[i], xe.z & ye.x) LGMI_CNT(accR[i], xe.w & ye.y) \
+    LGMI_CNT(accC[i], xe.x & ye.z) LGMI_CNT(accC[i], xe.y & ye.w) \
+    LGMI_CNT(accA[i], xe.z & ye.z) LGMI_CNT(accA[i], xe.w & ye.w)
 
 __global__ __launch_bounds__(256) void k_count(
     uint32_t n_tiles, const Tile* __restrict__ tiles, const BlockPlan* __restrict__ plans,

@@ -252,82 +252,42 @@ __global__ __launch_bounds__(256) void k_perm_fast(
 }
 
 // ---------------------------------------------------------------- general tables
-struct GenStream { uint32_t c0, c1, c2, k0, k1, call; U4 buf; int have; };
-
-__device__ __forceinline__ double next_uniform(GenStream& g) {   // (0,1): (m + 0.5) * 2^-52
-    if (g.have == 0) {
-        g.buf = philox4x32_10(g.c0, g.c1, g.c2, TAG_PERMGEN + g.call, g.k0, g.k1);
-        g.call++;
-        g.have = 2;
-    }
-    const unsigned long long m = g.have == 2 ? (((unsigned long long)g.buf.x << 20) | (g.buf.y >> 12))
-                                             : (((unsigned long long)g.buf.z << 20) | (g.buf.w >> 12));
-    g.have--;
-    return ((double)m + 0.5) * 2.220446049250313e-16;
-}
-
+//
+// One wave per queued row; lane l runs shuffles l, l+64, ...  A shuffle is a chain of up to
+// four conditional hypergeometric draws, each a rejection loop of random length, so a
+// lock-step "draw by draw" loop would make every draw cost the slowest lane's retries.
+// Instead every lane runs its own state machine and one trip of the wave loop is ONE
+// candidate (HRUA) or ONE urn step for whatever draw the lane is in; a lane whose draw
+// finishes resolves the following trivially-determined draws, starts its next shuffle if
+// needed and sets up the next real draw inside the same trip.  The stream of uniforms of a
+// shuffle is consumed strictly in order, so the result is that of the sequential
+// specification (oracle/lgmi_perm_oracle.c: perm_one) whatever the interleaving.
 #define HRUA_D1 1.7155277699214135
 #define HRUA_D2 0.8989161620588988
 
-// HRUA set-up of one (pop, good, sample); hoisted out of the shuffle loop for the one draw
-// whose parameters do not depend on earlier draws (the values are what hg_draw computes)
-struct HrSetup { uint32_t pop, good, sample; double d6, d8, d10, d11; };
+struct HrBase { uint32_t pop, good; double d4, cvar, c9; };   // the three quotients of a (pop, good)
 
-__device__ __forceinline__ void hrua_setup(const double* __restrict__ LF, uint32_t pop, uint32_t good, uint32_t sample,
-                                           HrSetup& hs) {
-    const uint32_t bad = pop - good;
-    const uint32_t m = sample < pop - sample ? sample : pop - sample;
-    const uint32_t mn = good < bad ? good : bad, mx = good < bad ? bad : good;
-    const double d4 = (double)mn / (double)pop, d5 = 1.0 - d4;
-    hs.pop = pop; hs.good = good; hs.sample = sample;
-    hs.d6 = (double)m * d4 + 0.5;
-    const double d7 = det_sqrt((double)(pop - m) * (double)m * d4 * d5 / (double)(pop - 1u) + 0.5);
-    hs.d8 = HRUA_D1 * d7 + HRUA_D2;
-    const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * (double)(mn + 1u) / ((double)pop + 2.0));
-    hs.d10 = LF[d9] + LF[mn - d9] + LF[m - d9] + LF[mx - m + d9];
-    const double cap = (double)((m < mn ? m : mn) + 1u);
-    const double lim = floor(hs.d6 + 16.0 * d7);
-    hs.d11 = cap < lim ? cap : lim;
+__device__ __forceinline__ void hr_base(uint32_t pop, uint32_t good, HrBase& b) {
+    const uint32_t bad = pop - good, mn = good < bad ? good : bad;
+    b.pop = pop; b.good = good;
+    b.d4 = (double)mn / (double)pop;
+    b.cvar = b.d4 * (1.0 - b.d4) / (double)(pop - 1u);
+    b.c9 = (double)(mn + 1u) / ((double)pop + 2.0);
 }
 
-__device__ __noinline__ uint32_t hg_draw(const double* __restrict__ LF, uint32_t pop, uint32_t good, uint32_t sample,
-                                         GenStream& g, const HrSetup& cached) {
-    const uint32_t bad = pop - good;
-    const uint32_t m = sample < pop - sample ? sample : pop - sample;
-    uint32_t z;
-    if (sample == 0u || good == 0u) return 0u;
-    if (bad == 0u) return sample;
-    if (sample == pop) return good;
-    if (m < 10u) {
-        uint32_t rem_total = pop, rem_good = good, left = m;
-        while (left > 0u && rem_good > 0u && rem_total > rem_good) {
-            const double u = next_uniform(g);
-            if ((uint32_t)(u * (double)rem_total) < rem_good) rem_good--;
-            rem_total--;
-            left--;
-        }
-        if (rem_total == rem_good) rem_good -= left;
-        z = good - rem_good;
-    } else {
-        const uint32_t mn = good < bad ? good : bad, mx = good < bad ? bad : good;
-        HrSetup hs;
-        if (cached.pop == pop && cached.good == good && cached.sample == sample) hs = cached;
-        else hrua_setup(LF, pop, good, sample, hs);
-        for (;;) {
-            const double x = next_uniform(g), y = next_uniform(g);
-            const double w = hs.d6 + hs.d8 * (y - 0.5) / x;
-            if (w < 0.0 || w >= hs.d11) continue;
-            const uint32_t zc = (uint32_t)floor(w);
-            const double tt = hs.d10 - (LF[zc] + LF[mn - zc] + LF[m - zc] + LF[mx - m + zc]);
-            if (x * (4.0 - x) - 3.0 <= tt) { z = zc; break; }
-            if (x * (x - tt) >= 1.0) continue;
-            if (2.0 * det_log(x) <= tt) { z = zc; break; }
-        }
-        if (good > bad) z = m - z;
-    }
-    if (m < sample) z = good - z;
-    return z;
-}
+struct GState {
+    // Philox call index inside the current shuffle
+    uint32_t call;
+    // table being drawn
+    uint32_t s, rr0, rr1, pop_all, cc, pop, xa;
+    int d;                 // draw index: column d>>1, row d&1
+    long long ss;
+    // draw in flight
+    int phase;             // 1 HRUA candidate loop, 2 urn loop, 3 lane finished
+    uint32_t good, sample, m, mn, mx;
+    double d6, d8, d10, d11;
+    uint32_t rem_total, rem_good, left;
+};
 
 __global__ __launch_bounds__(256) void k_perm_general(
     const uint32_t* __restrict__ gen_list, const unsigned int* __restrict__ gen_count,
@@ -339,52 +299,130 @@ __global__ __launch_bounds__(256) void k_perm_general(
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_gen = *gen_count;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     for (uint32_t q = wave; q < n_gen; q += n_waves) {   // every wave reaches q >= n_gen: the grid drains
         const uint32_t r = gen_list[q];
-        uint32_t T[9], R[3], C[3], N = 0;
+        const uint32_t ci = row_i[r], cj = row_j[r];
+        uint32_t T[9], R0, R1, C0, C1, C2, N;
 #pragma unroll
         for (int k = 0; k < 9; ++k) T[k] = counts[9ull * r + k];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2];
-            C[a] = T[a] + T[3 + a] + T[6 + a];
-            N += R[a];
-        }
+        R0 = T[0] + T[1] + T[2]; R1 = T[3] + T[4] + T[5];
+        C0 = T[0] + T[3] + T[6]; C1 = T[1] + T[4] + T[7]; C2 = T[2] + T[5] + T[8];
+        N = C0 + C1 + C2;
         long long sobs = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) sobs += G[T[k]];
-        // the first draw that is not trivially determined has the same parameters in every shuffle
-        HrSetup fixed;
-        fixed.pop = 0u; fixed.good = 0u; fixed.sample = 0u; fixed.d6 = 0.0; fixed.d8 = 0.0; fixed.d10 = 0.0; fixed.d11 = 0.0;
-        {
-            const uint32_t cb = C[0] ? C[0] : (C[1] ? C[1] : C[2]);          // first non-empty column
-            uint32_t pop = N, good = R[0];
-            if (good == 0u) { good = R[1]; }                                  // row 0 empty: its draw is trivial
-            if (good == pop) { pop = 0u; }                                    // (cannot happen with >= 2 non-empty rows)
-            const uint32_t m = cb < pop - cb ? cb : pop - cb;
-            if (pop && good && good < pop && cb < pop && m >= 10u) hrua_setup(LF, pop, good, cb, fixed);
-        }
+        HrBase base0, base1;   // quotient caches for row-0 and row-1 draws (hits in the first column)
+        base0.pop = 0u; base0.good = 0u; base0.d4 = 0.0; base0.cvar = 0.0; base0.c9 = 0.0;
+        base1 = base0;
+
+        GState g;
+        g.s = lane; g.phase = 3; g.call = 0; g.d = 0; g.ss = 0;
+        g.rr0 = 0; g.rr1 = 0; g.pop_all = 0; g.cc = 0; g.pop = 0; g.xa = 0;
+        g.good = 0; g.sample = 0; g.m = 0; g.mn = 0; g.mx = 0; g.d6 = 0; g.d8 = 0; g.d10 = 0; g.d11 = 0;
+        g.rem_total = 0; g.rem_good = 0; g.left = 0;
         uint32_t exceed = 0;
-        for (uint32_t s = lane; s < n_shuffles; s += 64u) {
-            GenStream g;
-            g.c0 = s; g.c1 = row_i[r]; g.c2 = row_j[r];
-            g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0;
-            uint32_t rr0 = R[0], rr1 = R[1], pop_all = N;
-            long long ss = 0;
-#pragma unroll 1
-            for (int b = 0; b < 3; ++b) {
-                const uint32_t cb = b == 0 ? C[0] : (b == 1 ? C[1] : C[2]);
-                uint32_t cc = cb, pop = pop_all;
-                const uint32_t x0 = hg_draw(LF, pop, rr0, cc, g, fixed);
-                pop -= rr0; cc -= x0;
-                const uint32_t x1 = hg_draw(LF, pop, rr1, cc, g, fixed);
-                cc -= x1;                        // the last row takes what is left of the column
-                const uint32_t x2 = cc;
-                rr0 -= x0; rr1 -= x1;
-                pop_all -= cb;
-                ss += G[x0] + G[x1] + G[x2];
+        bool need_begin = g.s < n_shuffles;   // lane has a shuffle to start
+        bool have_z = false;
+        uint32_t z = 0;
+        if (need_begin) { g.rr0 = R0; g.rr1 = R1; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0; }
+
+        for (;;) {
+            // ---- (1) one candidate / urn step for the lanes that are inside a draw
+            // one Philox call per trip for every lane inside a draw (no divergent refills):
+            // words 0 and 1 make the two uniforms (w + 0.5) * 2^-32 of a candidate / the one of an urn step
+            const bool in_draw = !need_begin && g.phase != 3;
+            double ux = 0.5, uy = 0.5;
+            if (in_draw) {
+                const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+                g.call++;
+                ux = ((double)o.x + 0.5) * 2.3283064365386963e-10;
+                uy = ((double)o.y + 0.5) * 2.3283064365386963e-10;
             }
-            exceed += (ss >= sobs);
+            if (in_draw && g.phase == 1) {
+                const double x = ux, y = uy;
+                const double w = g.d6 + g.d8 * (y - 0.5) / x;
+                if (!(w < 0.0 || w >= g.d11)) {
+                    const uint32_t zc = (uint32_t)floor(w);
+                    const double tt = g.d10 - (LF[zc] + LF[g.mn - zc] + LF[g.m - zc] + LF[g.mx - g.m + zc]);
+                    bool acc = (x * (4.0 - x) - 3.0 <= tt);
+                    if (!acc && !(x * (x - tt) >= 1.0)) acc = (x * x <= det_exp(tt));   // 2 ln x <= tt
+                    if (acc) {
+                        z = zc;
+                        if (g.good > g.pop - g.good) z = g.m - z;   // z counted the minority kind
+                        if (g.m < g.sample) z = g.good - z;         // drew the complement
+                        have_z = true;
+                    }
+                }
+            } else if (in_draw && g.phase == 2) {
+                if (g.left > 0u && g.rem_good > 0u && g.rem_total > g.rem_good) {
+                    if ((uint32_t)(ux * (double)g.rem_total) < g.rem_good) g.rem_good--;
+                    g.rem_total--;
+                    g.left--;
+                }
+                if (!(g.left > 0u && g.rem_good > 0u && g.rem_total > g.rem_good)) {
+                    if (g.rem_total == g.rem_good) g.rem_good -= g.left;
+                    z = g.good - g.rem_good;
+                    if (g.m < g.sample) z = g.good - z;
+                    have_z = true;
+                }
+            }
+            // ---- (2) lanes whose draw just finished (or that start a shuffle): book the result,
+            //          resolve determined draws, set up the next real draw
+            if (have_z || need_begin) {
+                for (;;) {
+                    if (have_z) {
+                        have_z = false;
+                        const int b = g.d >> 1;
+                        if ((g.d & 1) == 0) {
+                            g.xa = z; g.pop -= g.rr0; g.cc -= z;
+                        } else {
+                            const uint32_t x1 = z, x2 = g.cc - z;   // the last row takes the rest of the column
+                            g.ss += G[g.xa] + G[x1] + G[x2];
+                            g.rr0 -= g.xa; g.rr1 -= x1;
+                            g.pop_all -= (b == 0 ? C0 : (b == 1 ? C1 : C2));
+                        }
+                        g.d++;
+                        if (g.d == 6) {   // table complete
+                            exceed += (g.ss >= sobs);
+                            g.s += 64u;
+                            if (g.s >= n_shuffles) { g.phase = 3; need_begin = false; break; }
+                            g.rr0 = R0; g.rr1 = R1; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
+                        }
+                    }
+                    need_begin = false;
+                    // parameters of draw g.d
+                    const int b = g.d >> 1;
+                    if ((g.d & 1) == 0) { g.cc = (b == 0 ? C0 : (b == 1 ? C1 : C2)); g.pop = g.pop_all; g.good = g.rr0; }
+                    else { g.good = g.rr1; }
+                    g.sample = g.cc;
+                    const uint32_t pop = g.pop, good = g.good, sample = g.sample, bad = pop - good;
+                    if (sample == 0u || good == 0u) { z = 0u; have_z = true; continue; }
+                    if (bad == 0u) { z = sample; have_z = true; continue; }
+                    if (sample == pop) { z = good; have_z = true; continue; }
+                    g.m = sample < pop - sample ? sample : pop - sample;
+                    if (g.m < 10u) {
+                        g.rem_total = pop; g.rem_good = good; g.left = g.m;
+                        g.phase = 2;
+                    } else {
+                        HrBase& hb = (g.d & 1) ? base1 : base0;
+                        if (hb.pop != pop || hb.good != good) hr_base(pop, good, hb);
+                        g.mn = good < bad ? good : bad;
+                        g.mx = good < bad ? bad : good;
+                        g.d6 = (double)g.m * hb.d4 + 0.5;
+                        const double d7 = det_sqrt((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5);
+                        g.d8 = HRUA_D1 * d7 + HRUA_D2;
+                        const uint32_t d9 = (uint32_t)floor((double)(g.m + 1u) * hb.c9);
+                        g.d10 = LF[d9] + LF[g.mn - d9] + LF[g.m - d9] + LF[g.mx - g.m + d9];
+                        const double cap = (double)((g.m < g.mn ? g.m : g.mn) + 1u);
+                        const double lim = floor(g.d6 + 16.0 * d7);
+                        g.d11 = cap < lim ? cap : lim;
+                        g.phase = 1;
+                    }
+                    break;
+                }
+            }
+            if (!__any(g.phase != 3)) break;   // wave-uniform exit: every lane has finished its shuffles
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) exceed += __shfl_xor(exceed, o);

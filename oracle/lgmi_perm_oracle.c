@@ -134,17 +134,14 @@ static int tables_init(perm_tables* t, uint32_t max_n)
 /* ------------------------------------------------------------------ uniform streams */
 typedef struct { uint32_t c0, c1, c2, k0, k1, call; uint32_t buf[4]; int have; } gen_stream;
 
-static double next_uniform(gen_stream* g)   /* (0,1), 52 bits: (m + 0.5) * 2^-52, exact in double */
+/* one Philox call per candidate / urn step: u[0], u[1] = ((word + 0.5) * 2^-32) of the first two
+ * words (exact in double, never 0 or 1); the other two words are not used */
+static void next_pair(gen_stream* g, double* u0, double* u1)
 {
-    uint64_t m;
-    if (g->have == 0) {
-        philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
-        g->call++;
-        g->have = 2;
-    }
-    m = g->have == 2 ? (((uint64_t)g->buf[0] << 20) | (g->buf[1] >> 12)) : (((uint64_t)g->buf[2] << 20) | (g->buf[3] >> 12));
-    g->have--;
-    return ((double)m + 0.5) * 2.220446049250313e-16;
+    philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
+    g->call++;
+    *u0 = ((double)g->buf[0] + 0.5) * 2.3283064365386963e-10;
+    *u1 = ((double)g->buf[1] + 0.5) * 2.3283064365386963e-10;
 }
 
 /* ------------------------------------------------------------------ hypergeometric draw */
@@ -164,7 +161,8 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
         /* urn scheme on the smaller of the sample and its complement */
         uint32_t rem_total = pop, rem_good = good, left = m;
         while (left > 0 && rem_good > 0 && rem_total > rem_good) {
-            const double u = next_uniform(g);
+            double u, unused;
+            next_pair(g, &u, &unused);
             if ((uint32_t)(u * (double)rem_total) < rem_good) rem_good--;
             rem_total--;
             left--;
@@ -173,26 +171,29 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
         z = good - rem_good;                           /* good items among the m drawn */
     } else {
         const uint32_t mn = good < bad ? good : bad, mx = good < bad ? bad : good;
-        const double d4 = (double)mn / (double)pop, d5 = 1.0 - d4;
+        /* the three quotients depend on (pop, good) only: the kernel keeps them across shuffles */
+        const double d4 = (double)mn / (double)pop;
+        const double cvar = d4 * (1.0 - d4) / (double)(pop - 1);
+        const double c9 = (double)(mn + 1) / ((double)pop + 2.0);
         const double d6 = (double)m * d4 + 0.5;
-        const double d7 = lgo_det_sqrt((double)(pop - m) * (double)m * d4 * d5 / (double)(pop - 1) + 0.5);
+        const double d7 = lgo_det_sqrt((double)(pop - m) * (double)m * cvar + 0.5);
         const double d8 = HRUA_D1 * d7 + HRUA_D2;
-        const uint32_t d9 = (uint32_t)floor((double)(m + 1) * (double)(mn + 1) / ((double)pop + 2.0));   /* mode */
+        const uint32_t d9 = (uint32_t)floor((double)(m + 1) * c9);   /* mode (may be off by one: harmless) */
         const double d10 = t->LF[d9] + t->LF[mn - d9] + t->LF[m - d9] + t->LF[mx - m + d9];
         const double cap = (double)((m < mn ? m : mn) + 1u);
         const double lim = floor(d6 + 16.0 * d7);
         const double d11 = cap < lim ? cap : lim;
         for (;;) {
-            const double x = next_uniform(g), y = next_uniform(g);
-            const double w = d6 + d8 * (y - 0.5) / x;
+            double x, y, w, tt;
             uint32_t zc;
-            double tt;
+            next_pair(g, &x, &y);
+            w = d6 + d8 * (y - 0.5) / x;
             if (w < 0.0 || w >= d11) continue;
             zc = (uint32_t)floor(w);
             tt = d10 - (t->LF[zc] + t->LF[mn - zc] + t->LF[m - zc] + t->LF[mx - m + zc]);
             if (x * (4.0 - x) - 3.0 <= tt) { z = zc; break; }
             if (x * (x - tt) >= 1.0) continue;
-            if (2.0 * lgo_det_log(x) <= tt) { z = zc; break; }
+            if (x * x <= lgo_det_exp(tt)) { z = zc; break; }   /* 2 ln x <= tt, without a log */
         }
         if (good > bad) z = m - z;   /* z counted the minority kind */
     }
