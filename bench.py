@@ -27,6 +27,8 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     'cfg2_dense_10kx50k': dict(n_sites=10_000, n_reads=50_000),
     'small_dense_2kx20k': dict(n_sites=2_000, n_reads=20_000),
+    # the long-read-like regime of SURVEY 8d: 25 (footprint, strand) blocks, each site sees ~70 reads
+    'north_star_banded_50kx200k': dict(n_sites=50_000, n_reads=200_000, regime='banded'),
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # non-packed VALU: one wave64 instruction per 4 cycles per SIMD (MI355X_MICROARCH.md 'vector-instruction ISSUE
@@ -43,6 +45,15 @@ def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
     from oracle import c_oracle
     n_reads = wl['n_reads']
     cores = c_oracle.load().lgo_num_threads()
+    if wl.get('regime') == 'banded':
+        from lgmi.synth import banded_chromosome
+        pb = banded_chromosome(wl['n_sites'], n_reads, seed=seed)
+        t0 = time.perf_counter()
+        out = c_oracle.run(pb, min_common=min_common, het_only=True, n_shuffles=n_shuffles, seed=seed, threads=cores)
+        dt = time.perf_counter() - t0
+        return {'value': out['n_examined'] / dt, 'unit': 'site-pairs/s', 'cores': cores, 'kind': 'port',
+                'sample': 'the whole banded workload: %d examined pairs, %d emitted, %.1f s wall'
+                          % (out['n_examined'], len(out['row_i']), dt)}
     # ~2.5e9 pair-words keeps 16 host cores busy for ~10-20 s
     target_pair_words = 2.5e9 * max(1, cores) / 16
     words = (n_reads + 63) // 64
@@ -91,8 +102,12 @@ def main():
     eng = lgmi.Engine(local_rank)
     wl = WORKLOADS[args.workload]
     seed = 20250808 + 1000 * rank
-    spec = lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed)
-    db = eng.synth_dense(spec)                                 # input resident in HBM before timing
+    if wl.get('regime') == 'banded':
+        from lgmi.synth import banded_chromosome
+        db = eng.upload(banded_chromosome(wl['n_sites'], wl['n_reads'], seed=seed))
+    else:
+        spec = lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed)
+        db = eng.synth_dense(spec)                             # input resident in HBM before timing
     if world > 1:
         eng.comm_init_torch(dist, rank, world)
 
@@ -142,7 +157,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u64 bit-planes / u32 counts / f64 MI', 'data': 'synthetic',
             'config': {'workload': args.workload, 'n_sites': wl['n_sites'], 'n_reads': wl['n_reads'],
-                       'regime': 'dense', 'het_every': 5, 'min_common': args.min_common,
+                       'regime': wl.get('regime', 'dense'), 'het_every': 5, 'min_common': args.min_common,
                        'n_shuffles': args.shuffles, 'examined_pairs_per_gpu': examined,
                        'emitted_pairs_per_gpu': info['n_rows'], 'parallelism': 'dp%d' % world},
             'stage_ms': {k: sum(i[k] for i in infos) / len(infos)

@@ -14,6 +14,8 @@
  *           (per-site mean of the kept rows; site_mean_mi / site_n_pairs)
  *   lgmi_site_mean
  *       src/giremi/mutual_information.py:48-60  for caller-supplied rows
+ *   lgmi_ecdf
+ *       src/giremi/stat.py:7-29 (ecdf), as used for `mip` at script/giremi.py:415-429
  *   permutation p-value (row_p / row_exceed)
  *       no reference counterpart (BASELINE.json north_star asks for it; the
  *       reference has no permutation test) — specified in DESIGN.md §5 and
@@ -200,6 +202,13 @@ void lgmi_result_free(lgmi_result* res);
 int  lgmi_site_mean(lgmi_ctx* ctx, uint64_t n_rows, const uint32_t* row_i,
                     const uint32_t* row_j, const double* row_mi, uint64_t n_sites,
                     double* mean_out, uint32_t* n_out);
+
+/* empirical CDF of a reference sample evaluated at query values — stat.ecdf
+ * (src/giremi/stat.py:7-29; the `mip` column, script/giremi.py:415-429):
+ * out[q] = #{ref < query[q]} / n_ref  (strict, searchsorted side='left'); NaN queries give
+ * NaN.  ref must not contain NaN; n_ref == 0 is LGMI_E_ARG (the reference divides by 0). */
+int  lgmi_ecdf(lgmi_ctx* ctx, uint64_t n_ref, const double* ref, uint64_t n_query,
+               const double* query, double* out);
 
 /* ---- multi-GPU: one process per GPU, RCCL used only for the final gather ---- */
 #define LGMI_UNIQUE_ID_BYTES 128

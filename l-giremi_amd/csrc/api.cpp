@@ -792,3 +792,32 @@ extern "C" int lgmi_site_mean(lgmi_ctx* ctx, uint64_t n_rows, const uint32_t* ro
     HIPCHK(hipStreamSynchronize(st));
     return LGMI_OK;
 }
+
+// ---------------------------------------------------------------- ECDF (the reference's `mip`)
+extern "C" int lgmi_ecdf(lgmi_ctx* ctx, uint64_t n_ref, const double* ref, uint64_t n_query, const double* query,
+                         double* out) {
+    if (!ctx || (n_query && (!query || !out))) return fail(LGMI_E_ARG, "NULL argument");
+    if (n_ref == 0 || !ref) return fail(LGMI_E_ARG, "empty reference sample (the reference's ecdf divides by zero)");
+    if (n_ref >= 0x7FFFFFFFull) return fail(LGMI_E_ARG, "reference sample too large");
+    for (uint64_t k = 0; k < n_ref; ++k) if (ref[k] != ref[k]) return fail(LGMI_E_ARG, "NaN in the reference sample");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    Pool& pool = ctx->pool;
+    std::vector<void*> scratch;
+    struct Guard { Pool& p; std::vector<void*>& s; ~Guard() { for (void* q : s) p.release(q); } } guard{pool, scratch};
+    auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
+    double *d_ref, *d_sorted, *d_q, *d_out; void* d_temp;
+    const size_t tb = ecdf_sort_temp_bytes((uint32_t)n_ref);
+    int rc;
+    if ((rc = salloc((void**)&d_ref, n_ref * 8))) return rc;
+    if ((rc = salloc((void**)&d_sorted, n_ref * 8))) return rc;
+    if ((rc = salloc((void**)&d_q, n_query * 8))) return rc;
+    if ((rc = salloc((void**)&d_out, n_query * 8))) return rc;
+    if ((rc = salloc(&d_temp, tb))) return rc;
+    HIPCHK(hipMemcpyAsync(d_ref, ref, n_ref * 8, hipMemcpyHostToDevice, st));
+    if (n_query) HIPCHK(hipMemcpyAsync(d_q, query, n_query * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(launch_ecdf(st, (uint32_t)n_ref, d_ref, d_sorted, d_temp, tb, n_query, d_q, d_out));
+    if (n_query) HIPCHK(hipMemcpyAsync(out, d_out, n_query * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return LGMI_OK;
+}

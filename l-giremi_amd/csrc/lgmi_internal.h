@@ -109,6 +109,11 @@ void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const u
                  const uint32_t* counts, const long long* G, const double* LF, uint32_t n_shuffles, uint64_t seed,
                  double* out_p, uint32_t* out_exceed, uint32_t* gen_list, unsigned int* gen_count);
 
+// ecdf.hip
+size_t ecdf_sort_temp_bytes(uint32_t n);
+hipError_t launch_ecdf(hipStream_t st, uint32_t n_ref, const double* ref, double* sorted, void* temp,
+                       size_t temp_bytes, uint64_t n_query, const double* query, double* out);
+
 // synth.hip: layout prep for uploaded batches and the dense synthetic generator
 void launch_tri_flags(hipStream_t st, uint32_t n_sites, const uint32_t* site_nw,
                       const uint64_t* site_plane_off, const uint64_t* planes, uint8_t* tri);

@@ -7,5 +7,7 @@ from .mutual_information import (mean_mismatch_pair_mutual_info, mismatch_pair_m
                                  region_pair_mi)
 from .engine import Engine, MIResult, default_engine, default_synth_spec, make_params  # noqa: F401
 from .pack import PackedBatch, pack_blocks  # noqa: F401
+from .stat import ecdf, mean_mi_to_mip  # noqa: F401
+from . import dist, synth  # noqa: F401
 
 __version__ = '0.1.0'

@@ -79,6 +79,7 @@ SYMBOLS = {
     'lgmi_run': (C.c_int, [VP, C.POINTER(Batch), C.POINTER(Params), C.POINTER(Result), C.POINTER(RunInfo)]),
     'lgmi_result_free': (None, [C.POINTER(Result)]),
     'lgmi_site_mean': (C.c_int, [VP, C.c_uint64, u32p, u32p, f64p, C.c_uint64, f64p, u32p]),
+    'lgmi_ecdf': (C.c_int, [VP, C.c_uint64, f64p, C.c_uint64, f64p, f64p]),
     'lgmi_comm_unique_id': (C.c_int, [VP]),
     'lgmi_comm_init': (C.c_int, [VP, VP, C.c_int, C.c_int]),
     'lgmi_comm_allgather_u64': (C.c_int, [VP, C.c_uint64, u64p]),

@@ -192,6 +192,20 @@ class Engine:
         return mean, cnt
 
 
+    def ecdf(self, ref, query):
+        """#{ref < q} / len(ref) for every q (NaN stays NaN) — stat.ecdf of the reference, on the GPU"""
+        self._alive()
+        r = np.ascontiguousarray(ref, np.float64).ravel()
+        q = np.ascontiguousarray(query, np.float64).ravel()
+        if r.size == 0:
+            raise ZeroDivisionError('division by zero')      # what stat.ecdf raises (1/n with n == 0)
+        out = np.empty(q.size, np.float64)
+
+        def p(a):
+            return a.ctypes.data_as(_lib.f64p) if a.size else C.cast(None, _lib.f64p)
+        _lib.check(self.lib.lgmi_ecdf(self.handle, r.size, p(r), q.size, p(q), p(out)))
+        return out
+
     # ---- multi-GPU: RCCL is used only for the final gather (csrc/comm.cpp)
     def comm_unique_id(self) -> bytes:
         buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)

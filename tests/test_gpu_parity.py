@@ -276,3 +276,43 @@ def test_rccl_single_rank_gather(engine):
     np.testing.assert_array_equal(g['row_p'], res.row_p)
     dr.free()
     db.free()
+
+
+def test_banded_chromosome_matches_oracle(engine):
+    """the long-read-like regime: several blocks, narrow bands, most tiles skipped"""
+    from lgmi.synth import banded_chromosome
+    from oracle import c_oracle
+    pb = banded_chromosome(6000, 24000, seed=77)
+    assert pb.n_blocks == 3 and pb.site_n_words.max() < 40
+    ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=50, seed=5)
+    res = engine.run(pb, min_common=6, het_only=True, n_shuffles=50, seed=5, emit_counts=True)
+    assert_same_as_oracle(res, ora)
+    assert_perm_same(res, ora, 50)
+    assert res.info['n_examined'] == ora['n_examined'] and res.n_rows < 0.2 * ora['n_examined']
+
+
+# ---------------------------------------------------------------- the reference's ECDF `mip` (stat.py:7-29)
+def test_ecdf_matches_reference_vectors(engine):
+    import lgmi
+    from conftest import load_golden
+    for c in load_golden('ecdf.json')['cases']:
+        f = lgmi.ecdf(c['sample'], engine=engine)
+        got = f(np.array(c['query']))
+        assert np.max(np.abs(got - np.array(c['value']))) <= 1e-12
+        assert abs(f(c['query'][0]) - c['value'][0]) <= 1e-12          # scalar call
+    with pytest.raises(ZeroDivisionError):
+        lgmi.ecdf([], engine=engine)
+
+
+def test_mip_column(engine):
+    import lgmi
+    from oracle import mi_oracle
+    rng = np.random.default_rng(1)
+    mean = rng.random(500)
+    mean[rng.random(500) < 0.2] = np.nan
+    typ = np.where(rng.random(500) < 0.3, 'het_snp', 'mismatch')
+    got = lgmi.mean_mi_to_mip(mean, typ, engine=engine)
+    f = mi_oracle.ecdf_strict([v for v, t in zip(mean, typ) if t == 'het_snp' and not np.isnan(v)])
+    for v, g in zip(mean, got):
+        assert (np.isnan(v) and np.isnan(g)) or abs(f(v) - g) <= 1e-12
+    assert np.isnan(lgmi.mean_mi_to_mip([np.nan, np.nan], np.array(['het_snp', 'snp']), engine=engine)).all()
