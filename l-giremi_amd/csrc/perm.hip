@@ -45,14 +45,24 @@ __device__ __forceinline__ double inv_n(int n) {   // 1/n, IEEE-rounded constant
     }
 }
 
-__device__ __forceinline__ double det_exp(double x) {   // x <= 0
+// exp(x) for x <= 0, relative error < 1e-12, made of fma, floor and exact scalings only
+__device__ __forceinline__ double det_exp(double x) {
     if (!(x > -745.0)) return 0.0;
     if (x > 0.0) x = 0.0;
-    const double k = floor(x * INV_LN2 + 0.5);
-    const double r = (x - k * LN2_HI) - k * LN2_LO;
-    double p = 1.0;
-#pragma unroll
-    for (int n = 11; n >= 1; --n) p = 1.0 + p * (r * inv_n(n));   // |r| <= 0.347: error < 1e-14
+    const double k = floor(fma(x, INV_LN2, 0.5));
+    double r = fma(-k, LN2_HI, x);
+    r = fma(-k, LN2_LO, r);
+    double p = 2.755731922398589e-07;
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
     const int ki = (int)k;
     if (ki >= -1000) return p * __longlong_as_double((long long)(ki + 1023) << 52);
     return (p * __longlong_as_double((long long)(-1000 + 1023) << 52)) *
@@ -76,12 +86,10 @@ __device__ __forceinline__ double det_sqrt(double a) {   // a > 0: division-free
     const unsigned long long b = (unsigned long long)__double_as_longlong(a);
     double y = __longlong_as_double((long long)(0x5FE6EB50C7B537A9ull - (b >> 1)));
 #pragma unroll
-    for (int n = 0; n < 5; ++n) {
-        double t = a * y;
-        t = t * y;
-        t = 0.5 * t;
-        t = 1.5 - t;
-        y = y * t;
+    for (int n = 0; n < 4; ++n) {
+        const double t = a * y;
+        const double h = fma(-t, y, 1.0);
+        y = fma(y * 0.5, h, y);
     }
     return a * y;
 }
@@ -156,9 +164,42 @@ __device__ __forceinline__ void run_sum_wave(const double* __restrict__ LF, cons
         if (stop_rule) {
             const long long rem = count - base - 1;
             const double last = __shfl(term, (int)(rem < 63 ? rem : 63));
-            if (!(last >= first * 5.684341886080802e-14)) break;
+            if (!(last > first * 5.684341886080802e-14)) break;   // also stops a run of zeros
         }
     }
+}
+
+// the complement (centre) run in 64 contiguous segments: first term of a lane's segment from the
+// log-factorials, the rest by the hypergeometric ratio (one division instead of an exp per term)
+__device__ __forceinline__ void centre_sum_wave(const double* __restrict__ LF, const HG22& h, long long k0,
+                                                long long kend_excl, uint32_t lane, double& acc) {
+    const long long count = kend_excl - k0;
+    if (count <= 0) return;
+    const long long seg = (count + 63) / 64;
+    const long long ks = k0 + (long long)lane * seg;
+    long long ke = ks + seg;
+    if (ke > kend_excl) ke = kend_excl;
+    double term = 0.0;
+    if (ks < kend_excl) {
+        term = pmf22(LF, h, (uint32_t)ks);
+        acc += term;
+    }
+    for (long long step = 1; step < seg; ++step) {      // wave-uniform trip count
+        const long long k = ks + step - 1;              // term k -> term k + 1
+        if (k + 1 < ke) {
+            const uint32_t ku = (uint32_t)k;
+            const double num = (double)(h.K - ku) * (double)(h.n - ku);
+            const double den = (double)(ku + 1u) * (double)(h.N - h.K - h.n + ku + 1u);
+            term = term * num / den;
+            acc += term;
+        }
+    }
+}
+
+// wave-uniform lane index -> v_readlane_b32 (no LDS round trip, unlike __shfl)
+__device__ __forceinline__ uint32_t bcast32(uint32_t v, int L) { return (uint32_t)__builtin_amdgcn_readlane((int)v, L); }
+__device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int L) {
+    return ((unsigned long long)bcast32((uint32_t)(v >> 32), L) << 32) | bcast32((uint32_t)v, L);
 }
 
 __global__ __launch_bounds__(256) void k_perm_fast(
@@ -208,16 +249,18 @@ __global__ __launch_bounds__(256) void k_perm_fast(
     double my_p = 1.0;
     unsigned long long todo = __ballot(kind == 2);
     while (todo) {
-        const int L = __ffsll((long long)todo) - 1;
+        const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         todo &= todo - 1ull;
         HG22 hb;
-        hb.N = __shfl(h.N, L); hb.K = __shfl(h.K, L); hb.n = __shfl(h.n, L);
-        hb.kmin = __shfl(h.kmin, L); hb.kmax = __shfl(h.kmax, L); hb.c0 = __shfl(h.c0, L);
-        const long long klo = __shfl(tb.klo, L), khi = __shfl(tb.khi, L);
-        const int centre = __shfl(tb.centre, L);
+        hb.N = bcast32(h.N, L); hb.K = bcast32(h.K, L); hb.n = bcast32(h.n, L);
+        hb.kmin = bcast32(h.kmin, L); hb.kmax = bcast32(h.kmax, L);
+        hb.c0 = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(h.c0), L));
+        const long long klo = (long long)bcast64((unsigned long long)tb.klo, L);
+        const long long khi = (long long)bcast64((unsigned long long)tb.khi, L);
+        const int centre = (int)bcast32((uint32_t)tb.centre, L);
         double acc = 0.0;
         if (centre) {
-            run_sum_wave(LF, hb, klo + 1, khi - 1, +1, 0, lane, acc);
+            centre_sum_wave(LF, hb, klo + 1, khi, lane, acc);
         } else {
             run_sum_wave(LF, hb, klo, (long long)hb.kmin, -1, 1, lane, acc);
             run_sum_wave(LF, hb, khi, (long long)hb.kmax, +1, 1, lane, acc);

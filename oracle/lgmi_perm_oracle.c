@@ -71,16 +71,28 @@ static const double INV_N[24] = {0.0, 1.0, 1.0 / 2.0, 1.0 / 3.0, 1.0 / 4.0, 1.0 
                                  1.0 / 16.0, 1.0 / 17.0, 1.0 / 18.0, 1.0 / 19.0, 1.0 / 20.0, 1.0 / 21.0, 1.0 / 22.0,
                                  1.0 / 23.0};
 
-double lgo_det_exp(double x)   /* x <= 0; relative error ~1e-14, identical on CPU and GPU */
+/* exp(x) for x <= 0, relative error < 1e-12 (all that a 2^-32 threshold needs), made of fma(),
+ * floor() and exact scalings only: the same bits on the CPU and on the GPU */
+double lgo_det_exp(double x)
 {
     double k, r, p;
-    int ki, n;
+    int ki;
     if (!(x > -745.0)) return 0.0;
     if (x > 0.0) x = 0.0;
-    k = floor(x * INV_LN2 + 0.5);
-    r = (x - k * LN2_HI) - k * LN2_LO;
-    p = 1.0;
-    for (n = 11; n >= 1; --n) p = 1.0 + p * (r * INV_N[n]);   /* Horner form of sum r^n/n!, |r| <= 0.347: error < 1e-14 */
+    k = floor(fma(x, INV_LN2, 0.5));
+    r = fma(-k, LN2_HI, x);
+    r = fma(-k, LN2_LO, r);                       /* |r| <= 0.347 */
+    p = 2.755731922398589e-07;                    /* 1/10! ... 1/2!, Horner */
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
     ki = (int)k;
     if (ki >= -1000) return p * bits_to_double((uint64_t)(ki + 1023) << 52);
     return (p * bits_to_double((uint64_t)(-1000 + 1023) << 52)) * bits_to_double((uint64_t)(ki + 1000 + 1023) << 52);
@@ -100,17 +112,15 @@ double lgo_det_log(double x)   /* x > 0, normal */
     return (double)e * LN2_HI + (2.0 * f * s + (double)e * LN2_LO);
 }
 
-double lgo_det_sqrt(double a)   /* a > 0: division-free Newton on 1/sqrt(a) from a bit-level guess, then a*y */
+double lgo_det_sqrt(double a)   /* a > 0: division-free Newton on y = 1/sqrt(a) from a bit-level guess, then a*y */
 {
     const uint64_t b = double_to_bits(a);
     double y = bits_to_double(0x5FE6EB50C7B537A9ull - (b >> 1));
     int n;
-    for (n = 0; n < 5; ++n) {
-        double t = a * y;
-        t = t * y;
-        t = 0.5 * t;
-        t = 1.5 - t;
-        y = y * t;
+    for (n = 0; n < 4; ++n) {
+        const double t = a * y;
+        const double h = fma(-t, y, 1.0);          /* 1 - a y^2 */
+        y = fma(y * 0.5, h, y);
     }
     return a * y;
 }
@@ -264,7 +274,34 @@ static void run_sum(const perm_tables* t, const hg22* h, int64_t k0, int64_t ken
             acc[l] += term;
             last = term;
         }
-        if (stop_rule && !(last >= first * 5.684341886080802e-14)) break;   /* 2^-44 */
+        if (stop_rule && !(last > first * 5.684341886080802e-14)) break;   /* 2^-44; also stops a run of zeros */
+    }
+}
+
+/* the complement (centre) run: its `count` terms are cut into 64 contiguous segments of
+ * seg = ceil(count / 64); accumulator l sums segment l — first term from the log-factorials,
+ * the following ones by the hypergeometric ratio  pmf(k+1) = pmf(k) (K-k)(n-k) / ((k+1)(N-K-n+k+1)) */
+static void centre_sum(const perm_tables* t, const hg22* h, int64_t k0, int64_t kend_excl, double acc[64])
+{
+    const int64_t count = kend_excl - k0;
+    int64_t seg;
+    int l;
+    if (count <= 0) return;
+    seg = (count + 63) / 64;
+    for (l = 0; l < 64; ++l) {
+        const int64_t ks = k0 + (int64_t)l * seg;
+        int64_t ke = ks + seg, k;
+        double term;
+        if (ks >= kend_excl) break;
+        if (ke > kend_excl) ke = kend_excl;
+        term = pmf22(t, h, (uint32_t)ks);
+        acc[l] += term;
+        for (k = ks; k + 1 < ke; ++k) {
+            const double num = (double)(h->K - (uint32_t)k) * (double)(h->n - (uint32_t)k);
+            const double den = (double)((uint32_t)k + 1u) * (double)(h->N - h->K - h->n + (uint32_t)k + 1u);
+            term = term * num / den;
+            acc[l] += term;
+        }
     }
 }
 
@@ -301,7 +338,7 @@ static double ptail22(const perm_tables* t, const hg22* h, uint32_t kobs)
     for (l = 0; l < 64; ++l) acc[l] = 0.0;
     if (clen * clen <= 49.0 * var + 64.0) {
         /* few values are less extreme (within ~7 sigma): 1 - their mass */
-        run_sum(t, h, klo + 1, khi - 1, +1, 0, acc);
+        centre_sum(t, h, klo + 1, khi, acc);
         p = 1.0 - butterfly64(acc);
     } else {
         run_sum(t, h, klo, (int64_t)h->kmin, -1, 1, acc);
