@@ -38,6 +38,17 @@ VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # 3.93e13
 WORD_OP_LANE_OPS = 4                  # one 64-bit AND+POPC = 2 v_and_b32 + 2 v_bcnt_u32_b32
 
 
+def pmc_traffic(workload):
+    """HBM bytes per k_count launch from the committed PMC passes (profiles/r01_pmc_k_count.json): rocprofv3
+    cannot be driven from inside this process, so the counters are collected by the separate --pmc runs
+    described in that file and looked up here by workload name."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_k_count.json')) as f:
+            return json.load(f).get(workload, {}).get('hbm_bytes')
+    except OSError:
+        return None
+
+
 def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
     """The CPU oracle (oracle/lgmi_oracle.c, OpenMP) timed on a bounded sample of the
     same workload: same read count, fewer sites, so it finishes in ~10-30 s."""
@@ -162,10 +173,13 @@ def main():
                        'emitted_pairs_per_gpu': info['n_rows'], 'parallelism': 'dp%d' % world},
             'stage_ms': {k: sum(i[k] for i in infos) / len(infos)
                          for k in ('ms_total', 'ms_prep', 'ms_count', 'ms_emit', 'ms_perm', 'ms_mean')},
-            'roofline': {'kernel': 'k_count', 'bound': 'hbm', 'achieved': alg_bytes / secs / 1e9,
+            'roofline': {'kernel': 'k_count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes,
+                         'achieved': alg_bytes / secs / 1e9,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
-                         'traffic': None,
-                         'note': 'k_count is VALU(popcount)-bound, not HBM-bound: see valu_roofline'},
+                         'traffic': pmc_traffic(args.workload),
+                         'note': 'bytes per launch; k_count is VALU(popcount)-bound, not HBM-bound: see '
+                                 'valu_roofline.  traffic = L2-miss bytes (FETCH_SIZE x2 + WRITE_SIZE, '
+                                 'profiles/r01_pmc_k_count.json): columns are re-read once per group of 8 x-tile rows'},
             'valu_roofline': {'kernel': 'k_count', 'bound': 'valu_popcount',
                               'achieved': word_ops / secs / 1e12, 'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12,
                               'unit': 'T word-ops/s (64-bit AND+POPC)',

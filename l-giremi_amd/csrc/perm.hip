@@ -346,15 +346,25 @@ __global__ __launch_bounds__(256) void k_perm_general(
     for (uint32_t q = wave; q < n_gen; q += n_waves) {   // every wave reaches q >= n_gen: the grid drains
         const uint32_t r = gen_list[q];
         const uint32_t ci = row_i[r], cj = row_j[r];
-        uint32_t T[9], R0, R1, C0, C1, C2, N;
+        uint32_t T[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) T[k] = counts[9ull * r + k];
-        R0 = T[0] + T[1] + T[2]; R1 = T[3] + T[4] + T[5];
-        C0 = T[0] + T[3] + T[6]; C1 = T[1] + T[4] + T[7]; C2 = T[2] + T[5] + T[8];
-        N = C0 + C1 + C2;
         long long sobs = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) sobs += G[T[k]];
+        // compact margins: non-empty rows / columns first, order kept.  Empty rows and columns and
+        // the last non-empty row / column are fully determined (their draws consume no random
+        // numbers in the sequential specification), so only (nr-1) x (nc-1) draws are real.
+        uint32_t Rr[3] = {T[0] + T[1] + T[2], T[3] + T[4] + T[5], T[6] + T[7] + T[8]};
+        uint32_t Cq[3] = {T[0] + T[3] + T[6], T[1] + T[4] + T[7], T[2] + T[5] + T[8]};
+        const uint32_t N = Rr[0] + Rr[1] + Rr[2];
+        uint32_t R0 = 0, R1 = 0, R2 = 0, C0 = 0, C1 = 0;
+        int nr = 0, nc = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (Rr[a]) { if (nr == 0) R0 = Rr[a]; else if (nr == 1) R1 = Rr[a]; else R2 = Rr[a]; nr++; }
+            if (Cq[a]) { if (nc == 0) C0 = Cq[a]; else if (nc == 1) C1 = Cq[a]; nc++; }
+        }
         HrBase base0, base1;   // quotient caches for row-0 and row-1 draws (hits in the first column)
         base0.pop = 0u; base0.good = 0u; base0.d4 = 0.0; base0.cvar = 0.0; base0.c9 = 0.0;
         base1 = base0;
@@ -364,16 +374,16 @@ __global__ __launch_bounds__(256) void k_perm_general(
         g.rr0 = 0; g.rr1 = 0; g.pop_all = 0; g.cc = 0; g.pop = 0; g.xa = 0;
         g.good = 0; g.sample = 0; g.m = 0; g.mn = 0; g.mx = 0; g.d6 = 0; g.d8 = 0; g.d10 = 0; g.d11 = 0;
         g.rem_total = 0; g.rem_good = 0; g.left = 0;
+        uint32_t rr2 = 0;
         uint32_t exceed = 0;
         bool need_begin = g.s < n_shuffles;   // lane has a shuffle to start
         bool have_z = false;
         uint32_t z = 0;
-        if (need_begin) { g.rr0 = R0; g.rr1 = R1; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0; }
+        if (need_begin) { g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0; }
 
         for (;;) {
-            // ---- (1) one candidate / urn step for the lanes that are inside a draw
-            // one Philox call per trip for every lane inside a draw (no divergent refills):
-            // words 0 and 1 make the two uniforms (w + 0.5) * 2^-32 of a candidate / the one of an urn step
+            // ---- (1) one candidate / urn step for the lanes that are inside a draw.  One Philox call
+            //          per trip (no divergent refills): words 0 and 1 make the uniforms (w + 0.5) * 2^-32
             const bool in_draw = !need_begin && g.phase != 3;
             double ux = 0.5, uy = 0.5;
             if (in_draw) {
@@ -410,33 +420,40 @@ __global__ __launch_bounds__(256) void k_perm_general(
                     have_z = true;
                 }
             }
-            // ---- (2) lanes whose draw just finished (or that start a shuffle): book the result,
-            //          resolve determined draws, set up the next real draw
+            // ---- (2) lanes whose draw just finished (or that start a shuffle): book the result, close the
+            //          column / the table when it is complete, set up the next real draw.
+            //          g.d = 2 * column + row (row 1 only exists when three rows are non-empty)
             if (have_z || need_begin) {
                 for (;;) {
                     if (have_z) {
                         have_z = false;
-                        const int b = g.d >> 1;
+                        bool column_done = false;
+                        uint32_t x0 = 0, x1 = 0, x2 = 0;
                         if ((g.d & 1) == 0) {
-                            g.xa = z; g.pop -= g.rr0; g.cc -= z;
+                            g.xa = z;
+                            if (nr == 3) { g.pop -= g.rr0; g.cc -= z; g.d++; }
+                            else { x0 = z; x1 = g.cc - z; column_done = true; }
                         } else {
-                            const uint32_t x1 = z, x2 = g.cc - z;   // the last row takes the rest of the column
-                            g.ss += G[g.xa] + G[x1] + G[x2];
-                            g.rr0 -= g.xa; g.rr1 -= x1;
-                            g.pop_all -= (b == 0 ? C0 : (b == 1 ? C1 : C2));
+                            x0 = g.xa; x1 = z; x2 = g.cc - z;       // the last row takes the rest of the column
+                            column_done = true;
                         }
-                        g.d++;
-                        if (g.d == 6) {   // table complete
-                            exceed += (g.ss >= sobs);
-                            g.s += 64u;
-                            if (g.s >= n_shuffles) { g.phase = 3; need_begin = false; break; }
-                            g.rr0 = R0; g.rr1 = R1; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
+                        if (column_done) {
+                            g.ss += G[x0] + G[x1] + G[x2];
+                            g.rr0 -= x0; g.rr1 -= x1; rr2 -= x2;
+                            g.pop_all -= ((g.d >> 1) == 0 ? C0 : C1);
+                            g.d = (g.d | 1) + 1;                     // first row of the next column
+                            if ((g.d >> 1) == nc - 1) {              // the last column takes what is left
+                                g.ss += G[g.rr0] + G[g.rr1] + G[rr2];
+                                exceed += (g.ss >= sobs);
+                                g.s += 64u;
+                                if (g.s >= n_shuffles) { g.phase = 3; need_begin = false; break; }
+                                g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
+                            }
                         }
                     }
                     need_begin = false;
                     // parameters of draw g.d
-                    const int b = g.d >> 1;
-                    if ((g.d & 1) == 0) { g.cc = (b == 0 ? C0 : (b == 1 ? C1 : C2)); g.pop = g.pop_all; g.good = g.rr0; }
+                    if ((g.d & 1) == 0) { g.cc = ((g.d >> 1) == 0 ? C0 : C1); g.pop = g.pop_all; g.good = g.rr0; }
                     else { g.good = g.rr1; }
                     g.sample = g.cc;
                     const uint32_t pop = g.pop, good = g.good, sample = g.sample, bad = pop - good;
