@@ -9,5 +9,6 @@ from .engine import Engine, MIResult, default_engine, default_synth_spec, make_p
 from .pack import PackedBatch, pack_blocks  # noqa: F401
 from .stat import ecdf, mean_mi_to_mip  # noqa: F401
 from . import dist, synth  # noqa: F401
+from .region import get_region_mismatches_with_filters, region_mismatch_analysis  # noqa: F401
 
 __version__ = '0.1.0'

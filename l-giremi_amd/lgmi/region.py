@@ -1,0 +1,272 @@
+"""The caller of the hot path: per-footprint site extraction + filters + MI block.
+
+Drop-in for ``get_region_mismatches_with_filters`` and ``region_mismatch_analysis``
+of the reference (src/giremi/mismatch.py:11-342 and :345-509), written from scratch.
+Same signatures, same three DataFrames (mismatch table, pair-MI table, removed table),
+same quirks (listed where they are reproduced); the MI block (:384-404) runs on the
+MI355X through ``region_pair_mi`` instead of the per-pair Python/sklearn loop.
+
+`sam` and `genome` are duck-typed like pysam's AlignmentFile / FastaFile:
+``sam.fetch(chrom, start, end)`` -> reads with ``query_name``, ``reference_start``,
+``is_reverse``, ``get_tag('cs')``; ``sam.pileup(contig=, start=, stop=)`` -> columns with
+``pos``, ``get_query_names()``, ``get_query_sequences()``; ``genome.fetch(chrom, a, b)``.
+Only ``mode='cs'`` (minimap2 ``--cs`` tags) is supported here; the CIGAR+MD conversion
+of the reference (src/giremi/cs.py:110-363) is not part of this path.
+"""
+from __future__ import annotations
+
+import re
+from collections import defaultdict
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+
+from .mutual_information import region_pair_mi
+
+_CS_TOKEN = re.compile(r'([:*+\-~])([0-9a-z]+)')
+_COMPLEMENT = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N'}
+_COMP4 = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A'}    # the filter stage knows no 'N' (KeyError, like mismatch.py:151)
+
+
+def cs_operations(cs_string: str) -> List[Tuple[int, int, str, str]]:
+    """minimap2 short cs tag -> [(low, high, op, value)] with reference offsets relative to the
+    alignment start (src/giremi/cs.py:8-41): ':' n matches, '*xy' one substitution x->y, '+seq'
+    insertion (no reference span), '-seq' deletion, '~aaNNbb' intron of NN bases."""
+    out, at = [], 0
+    for op, value in _CS_TOKEN.findall(cs_string):
+        if op == ':':
+            span = int(value)
+        elif op == '*':
+            span = 1
+        elif op == '+':
+            span = 0
+        elif op == '-':
+            span = len(value)
+        else:
+            span = int(''.join(ch for ch in value if ch.isdigit()))
+        out.append((at, at + span, op, value))
+        at += span
+    return out
+
+
+def _merge(intervals):
+    """src/giremi/utils.py:4-16 — sort by start, fuse when the next start is <= the running end"""
+    merged: List[List[int]] = []
+    for lo, hi in sorted(intervals, key=lambda iv: iv[0]):
+        if merged and lo <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], hi)
+        else:
+            merged.append([lo, hi])
+    return merged
+
+
+def _inside(positions, intervals) -> List[bool]:
+    """src/giremi/utils.py:19-29 — start <= pos < end of some interval, by the same two
+    right-bisections (a position counts when #starts<=pos exceeds #ends<=pos by exactly one);
+    like the reference it sorts the caller's interval list in place"""
+    if len(positions) == 0:
+        return []
+    intervals.sort(key=lambda iv: iv[0])
+    starts = [iv[0] for iv in intervals]
+    ends = [iv[1] for iv in intervals]
+    a = np.searchsorted(starts, positions, side='right')
+    b = np.searchsorted(ends, positions, side='right')
+    return [int(x) - int(y) == 1 for x, y in zip(a, b)]
+
+
+def _new_site(with_removed=False):
+    site = {'ref': '', 'type': 'mismatch', 'depth': defaultdict(int), 'nt': defaultdict(list),
+            'neighbor': defaultdict(int), 'up': '', 'down': ''}
+    if with_removed:
+        site['removed'] = ''
+    return site
+
+
+def get_region_mismatches_with_filters(chromosome, start_pos, end_pos, sam, genome,
+                                       keep_non_spliced_read=False, min_dist_from_splice=4,
+                                       min_allele_depth=3, min_allele_ratio=0.1, min_total_depth=6,
+                                       homopoly_length=5, simple_repeat_intervals=[], snp_positions=[],
+                                       read_strand_dict=None, min_het_snp_ratio=0.35, max_het_snp_ratio=0.65,
+                                       mismatch_window_size=100, max_window_mismatch=10,
+                                       max_window_mismatch_type=3, mode='cs'):
+    """-> (mismatches, removed_mismatches), each {'+': {pos: site}, '-': {pos: site}} (mismatch.py:11-342)."""
+    if mode != 'cs':
+        raise NotImplementedError("only mode='cs' is supported by lgmi.region")
+    # auto-creating maps, like the reference: merely LOOKING a position up creates an empty site, which
+    # the depth filter later reports as removed — reproduced on purpose (mismatch.py:29-62, :166)
+    kept = {s: defaultdict(_new_site) for s in '+-'}
+    dropped = {s: defaultdict(lambda: _new_site(True)) for s in '+-'}
+    if read_strand_dict is None:
+        read_strand_dict = {}
+
+    # ---- 1. substitutions of every (spliced) read, minus those next to a splice junction (:69-149)
+    for read in sam.fetch(chromosome, start_pos, end_pos):
+        strand = '-' if read.is_reverse else '+'
+        if read.query_name in read_strand_dict:
+            strand = read_strand_dict[read.query_name]
+        else:
+            read_strand_dict[read.query_name] = strand
+        ops = cs_operations(read.get_tag('cs'))
+        origin = read.reference_start
+        subs = sorted(([lo + origin, val] for lo, _hi, op, val in ops if op == '*'), key=lambda t: t[0])
+        introns = sorted(([lo + origin, hi + origin] for lo, hi, op, _v in ops if op == '~'), key=lambda t: t[0])
+        if not keep_non_spliced_read and not introns:
+            continue
+        if not subs:
+            continue
+        if introns and min_dist_from_splice > 0:
+            junctions = sorted([iv[0] for iv in introns] + [iv[1] for iv in introns])
+            near = _merge([[j - min_dist_from_splice, j + min_dist_from_splice] for j in junctions])
+            flags = _inside([t[0] for t in subs], near)
+        else:
+            flags = [False] * len(subs)
+        for (pos, refalt), close in zip(subs, flags):
+            if close:
+                continue
+            kept[strand][pos]['ref'] = refalt[0].upper()
+            kept[strand][pos]['nt'][refalt[1].upper()].append(read.query_name)
+
+    for strand in '+-':
+        sites = kept[strand]
+        gone = dropped[strand]
+        if len(sites) == 0:
+            continue
+        # ---- 2. reads that carry the reference base, from the pile-up (:160-190)
+        known = sorted(sites.keys())
+        for column in sam.pileup(contig=chromosome, start=start_pos, stop=end_pos):
+            pos = column.pos
+            ref = sites[pos]['ref']                      # creates an empty site for a new position
+            if pos in known and ref.upper() in _COMP4:
+                names = column.get_query_names()
+                bases = [b.upper() for b in column.get_query_sequences()]
+                same_strand = [read_strand_dict[n] == strand for n in names]      # KeyError for an unknown read
+                sites[pos]['nt'][ref].extend(n for n, b, ok in zip(names, bases, same_strand) if b == ref and ok)
+        # ---- 3. allele depths (:203-208)
+        for pos in sorted(sites.keys()):
+            for nt in list(sites[pos]['nt'].keys()):
+                sites[pos]['depth'][nt] = len(sites[pos]['nt'][nt])
+        # ---- 4. too many substitutions of too many kinds in the window (:211-240)
+        half = round(mismatch_window_size / 2)
+        snapshot = sorted(sites.keys())
+        for pos in snapshot:
+            around = [q for q in snapshot if q != pos and pos - half <= q < pos + half]
+            if not around:
+                continue
+            for q in around:
+                ref = sites[q]['ref']                    # a site removed earlier in this loop comes back empty
+                for nt in [a for a in sites[q]['depth'] if a != ref]:
+                    change = '%s>%s' % (ref, nt) if strand == '+' else '%s>%s' % (_COMP4[ref], _COMP4[nt])
+                    sites[pos]['neighbor'][change] += 1
+            if sum(sites[pos]['neighbor'].values()) > max_window_mismatch and \
+                    len(sites[pos]['neighbor']) > max_window_mismatch_type:
+                gone[pos] = sites.pop(pos)
+                gone[pos]['removed'] = 'too many window mismatches'
+        # ---- 5. shallow alleles, rare alleles (the depth dict keeps every allele: :243-266)
+        for pos in sorted(sites.keys()):
+            for nt in list(sites[pos]['nt'].keys()):
+                if sites[pos]['depth'][nt] < min_allele_depth:
+                    sites[pos]['nt'].pop(nt)
+        for pos in sorted(sites.keys()):
+            total = sum(sites[pos]['depth'].values())
+            for nt in list(sites[pos]['nt'].keys()):
+                if sites[pos]['depth'][nt] / total < min_allele_ratio:
+                    sites[pos]['nt'].pop(nt)
+        # ---- 6. shallow sites, single-allele sites (:268-290)
+        for pos in sorted(sites.keys()):
+            if sum(sites[pos]['depth'].values()) < min_total_depth:
+                gone[pos] = sites.pop(pos)
+                gone[pos]['removed'] = 'too few usable reads after filters'
+        for pos in sorted(sites.keys()):
+            if len(sites[pos]['nt']) < 2:
+                gone[pos] = sites.pop(pos)
+                gone[pos]['removed'] = 'not enough allele after filters'
+        # ---- 7. homopolymer context; flanking bases (:292-312)
+        k = int(homopoly_length / 2)
+        for pos in sorted(sites.keys()):
+            left = genome.fetch(chromosome, pos - homopoly_length, pos).upper()
+            right = genome.fetch(chromosome, pos + 1, pos + homopoly_length + 1).upper()
+            sites[pos]['up'] = left[-1].upper()
+            sites[pos]['down'] = right[0].upper()
+            if len(set(left)) == 1 or len(set(right)) == 1 or len(set(left[-k:] + right[0:k])) == 1:
+                gone[pos] = sites.pop(pos)
+                gone[pos]['removed'] = 'in homopoly regions'
+        # ---- 8. simple repeats (:314-323)
+        here = sorted(sites.keys())
+        for pos, hit in zip(here, _inside(here, simple_repeat_intervals)):
+            if hit:
+                gone[pos] = sites.pop(pos)
+                gone[pos]['removed'] = 'in simple repeat regions'
+        # ---- 9. depth = surviving alleles only; SNP typing (:325-340)
+        for pos in sorted(sites.keys()):
+            for nt in list(sites[pos]['depth'].keys()):
+                sites[pos]['depth'].pop(nt)
+            for nt in list(sites[pos]['nt'].keys()):
+                sites[pos]['depth'][nt] = len(sites[pos]['nt'][nt])
+        for pos in sorted(sites.keys()):
+            if pos in snp_positions:
+                total = sum(sites[pos]['depth'].values())
+                top = max(d / total for d in sites[pos]['depth'].values())
+                sites[pos]['type'] = 'het_snp' if min_het_snp_ratio <= top <= max_het_snp_ratio else 'snp'
+    return kept, dropped
+
+
+def region_mismatch_analysis(chromosome, start_pos, end_pos, sam, genome,
+                             keep_non_spliced_read=False, min_dist_from_splice=4, min_allele_depth=3,
+                             min_allele_ratio=0.1, min_total_depth=6, homopoly_length=5,
+                             simple_repeat_intervals=[], snp_positions=[], read_strand_dict=None,
+                             min_het_snp_ratio=0.35, max_het_snp_ratio=0.65, mismatch_window_size=100,
+                             max_window_mismatch=10, max_window_mismatch_type=3, mode='cs',
+                             min_common_reads=5, n_shuffles=0, seed=0, engine=None):
+    """-> (df_mismatches, df_mismatch_pair_mi, df_removed_mismatches) as mismatch.py:345-509.
+    With ``n_shuffles`` > 0 the pair table gains a ``p_perm`` column (permutation p-value, new)."""
+    sites, gone = get_region_mismatches_with_filters(
+        chromosome=chromosome, start_pos=start_pos, end_pos=end_pos, sam=sam, genome=genome,
+        keep_non_spliced_read=keep_non_spliced_read, min_dist_from_splice=min_dist_from_splice,
+        min_allele_depth=min_allele_depth, min_allele_ratio=min_allele_ratio, min_total_depth=min_total_depth,
+        homopoly_length=homopoly_length, simple_repeat_intervals=simple_repeat_intervals,
+        snp_positions=snp_positions, read_strand_dict=read_strand_dict, min_het_snp_ratio=min_het_snp_ratio,
+        max_het_snp_ratio=max_het_snp_ratio, mismatch_window_size=mismatch_window_size,
+        max_window_mismatch=max_window_mismatch, max_window_mismatch_type=max_window_mismatch_type, mode=mode)
+
+    # the MI block (:384-404) — one batched GPU call for both strands
+    records, mean_mi, pvals = region_pair_mi(sites, chromosome, min_common_reads, n_shuffles=n_shuffles, seed=seed,
+                                             engine=engine)
+    pair_cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
+    df_pairs = pd.DataFrame.from_records(records, columns=pair_cols)
+    if pvals is not None:
+        df_pairs['p_perm'] = pvals
+
+    rows = []
+    for strand in '+-':
+        means = mean_mi[strand]
+
+        def alt_ratio(site):
+            depth = site['depth']
+            total = sum(depth[nt] for nt in depth)
+            alts = sorted(([nt, depth[nt]] for nt in depth if nt != site['ref']), key=lambda t: t[1], reverse=True)
+            return alts[0][0], alts[0][1] / total, total
+
+        hets = [alt_ratio(s)[1] for s in sites[strand].values() if s['type'] == 'het_snp']
+        regional = sum(hets) / len(hets) if hets else 0.5           # :424-443
+        for pos, site in sites[strand].items():
+            alt, ratio, total = alt_ratio(site)
+            depth = dict(site['depth'])
+            ref = site['ref']
+            if strand == '+':
+                change, up, down = '%s>%s' % (ref, alt), site['up'], site['down']
+            else:
+                change = '%s>%s' % (_COMPLEMENT[ref], _COMPLEMENT[alt])
+                up, down = _COMPLEMENT[site['down']], _COMPLEMENT[site['up']]
+            if 'N' in change:
+                continue
+            acgt = '%s:%s:%s:%s' % tuple(depth.get(nt, 0) for nt in 'ACTG')     # A:C:T:G, defaultdict zeros
+            rows.append([site['type'], chromosome, strand, pos, ref, change, ratio, ratio - regional, total,
+                         acgt, up, down, means.get(pos, np.nan)])
+    df_sites = pd.DataFrame.from_records(
+        rows, columns=['type', 'chromosome', 'strand', 'pos', 'ref', 'change_type', 'ratio', 'allelic_ratio_diff',
+                       'depth', 'A:C:T:G', 'up_seq', 'down_seq', 'mean_mi'])
+    df_removed = pd.DataFrame.from_records(
+        [[chromosome, s, pos, gone[s][pos]['removed']] for s in '+-' for pos in gone[s]],
+        columns=['chromosome', 'strand', 'pos', 'removed'])
+    return df_sites, df_pairs, df_removed

@@ -271,6 +271,66 @@ def ecdf_cases():
     return out
 
 
+def load_ref_mismatch():
+    """giremi.mismatch imports giremi.cs / utils / mutual_information but not pysam; the package itself
+    cannot be imported (src/giremi/__init__.py:3 needs pip metadata), so register an empty stub package
+    whose __path__ points at the reference sources"""
+    import importlib
+    import types
+    if 'giremi' not in sys.modules:
+        pkg = types.ModuleType('giremi')
+        pkg.__path__ = [REF]
+        sys.modules['giremi'] = pkg
+    return importlib.import_module('giremi.mismatch')
+
+
+REGION_CASES = [
+    # name, simulate_region kwargs, region_mismatch_analysis kwargs
+    ('default', dict(seed=11), dict()),
+    ('more_reads', dict(seed=12, n_reads=150), dict(min_common_reads=6)),
+    ('keep_non_spliced_no_splice_filter', dict(seed=13), dict(keep_non_spliced_read=True, min_dist_from_splice=0)),
+    ('noisy_window_filter', dict(seed=14, n_reads=80, err=0.05),
+     dict(mismatch_window_size=60, max_window_mismatch=4, max_window_mismatch_type=2, min_allele_depth=2)),
+    ('lowercase_genome_repeats', dict(seed=15, lower_case_ref=True),
+     dict(simple_repeat_intervals=[[100, 140], [400, 430]], homopoly_length=4)),
+    ('strand_override', dict(seed=16, n_reads=90), dict(strand_override=True, min_allele_ratio=0.05)),
+    ('strict_filters', dict(seed=17, n_reads=120), dict(min_allele_depth=5, min_total_depth=20, min_het_snp_ratio=0.4,
+                                                         max_het_snp_ratio=0.6, min_common_reads=10)),
+]
+
+
+def frame_json(df):
+    """full-precision records (DataFrame.to_json would round floats to 10 digits); NaN stays NaN"""
+    def py(v):
+        if isinstance(v, (np.integer,)):
+            return int(v)
+        if isinstance(v, (np.floating,)):
+            return float(v)
+        return v
+    return {'columns': list(df.columns), 'data': [[py(v) for v in row] for row in df.values.tolist()]}
+
+
+def region_cases():
+    import hashlib
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from fakes import FakeGenome, FakeSam, simulate_region
+    ref_mm = load_ref_mismatch()
+    out = []
+    for name, sim_kw, kw in REGION_CASES:
+        reads, genome, snps, (a, b) = simulate_region(**sim_kw)
+        kw = dict(kw)
+        strand_dict = None
+        if kw.pop('strand_override', False):
+            strand_dict = {r.query_name: '+' for r in reads[::3]}
+        dfs = ref_mm.region_mismatch_analysis('chrS', a, b, FakeSam(reads), FakeGenome(genome), snp_positions=snps,
+                                              read_strand_dict=strand_dict, **kw)
+        digest = hashlib.sha256(('|'.join(r.query_name + r._cs for r in reads) + genome).encode()).hexdigest()
+        out.append({'name': name, 'sim': sim_kw, 'kwargs': {k: v for k, v in kw.items()},
+                    'strand_override': strand_dict is not None, 'input_sha256': digest,
+                    'mismatch': frame_json(dfs[0]), 'pair_mi': frame_json(dfs[1]), 'removed': frame_json(dfs[2])})
+    return out
+
+
 def main():
     import sklearn
     import scipy
@@ -285,6 +345,8 @@ def main():
         json.dump({'meta': meta, 'cases': [case('cfg1_banded_500x2000', mm, 6)]}, f)
     with open(os.path.join(HERE, 'ecdf.json'), 'w') as f:
         json.dump({'meta': meta, 'cases': ecdf_cases()}, f)
+    with open(os.path.join(HERE, 'region.json'), 'w') as f:
+        json.dump({'meta': meta, 'cases': region_cases()}, f)
     if '--time' in sys.argv:
         time_reference(os.path.join(HERE, 'reference_timing.json'))
 
