@@ -62,9 +62,48 @@ def mean_mismatch_pair_mutual_info(mismatch_pair_mi, engine: Optional[Engine] = 
     return [[pos, float(mean[k])] for pos, k in index.items()]
 
 
+def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None):
+    """The MI block (mismatch.py:384-418) of MANY footprints in ONE launch sequence.
+
+    ``regions`` is a sequence of ``(mismatches_by_strand, chromosome)``; every (footprint, strand) becomes one
+    block of a single batch, so thousands of small footprints cost one upload, one count launch and one
+    fetch instead of thousands.  Returns one ``(records, mean_mi, p_values)`` triple per region, each exactly
+    what ``region_pair_mi`` returns for that region alone."""
+    strands = ('+', '-')
+    regions = list(regions)
+    out = [([], {'+': {}, '-': {}}, ([] if n_shuffles else None)) for _ in regions]
+    blocks = []
+    for mm, _chrom in regions:
+        blocks.extend(mm.get(s, {}) for s in strands)
+    if not any(len(b) > 1 for b in blocks):
+        return out
+    eng = engine or default_engine()
+    batch = pack_blocks(blocks)
+    res = eng.run(batch, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True)
+    if batch.bad_sites.any() and res.n_rows:
+        if batch.bad_sites[res.row_i].any() or batch.bad_sites[res.row_j].any():
+            raise IndexError('list index out of range')
+    bsb = batch.block_site_begin.astype(np.int64)
+    pos, names = batch.site_pos.tolist(), batch.type_names
+    row_block = np.searchsorted(bsb, res.row_i.astype(np.int64), side='right') - 1
+    ri, rj, rmi = res.row_i.tolist(), res.row_j.tolist(), res.row_mi.tolist()
+    rp = res.row_p.tolist() if n_shuffles else None
+    for k, b in enumerate(row_block.tolist()):
+        records, _means, pvals = out[b >> 1]
+        i, j = ri[k], rj[k]
+        records.append([regions[b >> 1][1], strands[b & 1], pos[i], names[i], pos[j], names[j], rmi[k]])
+        if pvals is not None:
+            pvals.append(rp[k])
+    npairs, mean = res.site_n_pairs, res.site_mean_mi
+    for s in np.nonzero(npairs)[0].tolist():
+        b = int(np.searchsorted(bsb, s, side='right') - 1)
+        out[b >> 1][1][strands[b & 1]][pos[s]] = float(mean[s])
+    return out
+
+
 def region_pair_mi(mismatches_by_strand: dict, chromosome: str, min_common_reads=5, n_shuffles=0, seed=0,
                    engine: Optional[Engine] = None):
-    """Batched MI block of ``region_mismatch_analysis`` (mismatch.py:384-418).
+    """Batched MI block of ``region_mismatch_analysis`` (mismatch.py:384-418) for one footprint.
 
     Returns ``(records, mean_mi, p_values)``: ``records`` are the rows of
     ``df_mismatch_pair_mi`` — ``[chromosome, strand, p1, type1, p2, type2, mi]``, '+'
@@ -72,26 +111,4 @@ def region_pair_mi(mismatches_by_strand: dict, chromosome: str, min_common_reads
     -> mean MI (what ``mean_mismatch_pair_mutual_info`` feeds the mismatch table);
     ``p_values`` is None unless ``n_shuffles`` > 0 (then one permutation p per record).
     """
-    strands = ('+', '-')
-    blocks = [mismatches_by_strand.get(s, {}) for s in strands]
-    records, means, pvals = [], {'+': {}, '-': {}}, ([] if n_shuffles else None)
-    if not any(len(b) > 1 for b in blocks):
-        return records, means, pvals
-    eng = engine or default_engine()
-    batch = pack_blocks(blocks)
-    res = eng.run(batch, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True)
-    if batch.bad_sites.any() and res.n_rows:
-        if batch.bad_sites[res.row_i].any() or batch.bad_sites[res.row_j].any():
-            raise IndexError('list index out of range')
-    bsb = batch.block_site_begin
-    pos, names = batch.site_pos.tolist(), batch.type_names
-    for k, (i, j, mi) in enumerate(zip(res.row_i.tolist(), res.row_j.tolist(), res.row_mi.tolist())):
-        strand = strands[0] if i < int(bsb[1]) else strands[1]
-        records.append([chromosome, strand, pos[i], names[i], pos[j], names[j], mi])
-        if pvals is not None:
-            pvals.append(float(res.row_p[k]))
-    for b, strand in enumerate(strands):
-        for s in range(int(bsb[b]), int(bsb[b + 1])):
-            if res.site_n_pairs[s]:
-                means[strand][pos[s]] = float(res.site_mean_mi[s])
-    return records, means, pvals
+    return regions_pair_mi([(mismatches_by_strand, chromosome)], min_common_reads, n_shuffles, seed, engine)[0]

@@ -22,7 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import pandas as pd
 
-from .mutual_information import region_pair_mi
+from .mutual_information import region_pair_mi, regions_pair_mi
 
 _CS_TOKEN = re.compile(r'([:*+\-~])([0-9a-z]+)')
 _COMPLEMENT = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N'}
@@ -232,6 +232,37 @@ def region_mismatch_analysis(chromosome, start_pos, end_pos, sam, genome,
     # the MI block (:384-404) — one batched GPU call for both strands
     records, mean_mi, pvals = region_pair_mi(sites, chromosome, min_common_reads, n_shuffles=n_shuffles, seed=seed,
                                              engine=engine)
+    return _frames(chromosome, sites, gone, records, mean_mi, pvals)
+
+
+def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
+                              concat=False, **filter_kwargs):
+    """``region_mismatch_analysis`` over many footprints with ONE GPU batch for all their MI blocks — the shape the
+    reference's per-chunk loop (src/giremi/script/giremi.py:32-88) takes when the MI step is a device call.
+
+    ``footprints``: iterable of dicts with ``chromosome``, ``start``, ``end`` and optionally the per-footprint inputs
+    ``snp_positions``, ``simple_repeat_intervals``, ``read_strand_dict``; ``filter_kwargs`` are the common filter
+    parameters of ``region_mismatch_analysis``.  Returns a list of (df_sites, df_pairs, df_removed) in footprint order,
+    or with ``concat=True`` the three frames concatenated the way script/giremi.py:79-88 concatenates them."""
+    staged = []
+    for fp in footprints:
+        sites, gone = get_region_mismatches_with_filters(
+            chromosome=fp['chromosome'], start_pos=fp['start'], end_pos=fp['end'], sam=sam, genome=genome,
+            snp_positions=fp.get('snp_positions', []), simple_repeat_intervals=fp.get('simple_repeat_intervals', []),
+            read_strand_dict=fp.get('read_strand_dict'), **filter_kwargs)
+        staged.append((fp['chromosome'], sites, gone))
+    blocks = regions_pair_mi([(sites, chrom) for chrom, sites, _gone in staged], min_common_reads,
+                             n_shuffles=n_shuffles, seed=seed, engine=engine)
+    frames = [_frames(chrom, sites, gone, *blk) for (chrom, sites, gone), blk in zip(staged, blocks)]
+    if not concat:
+        return frames
+    if not frames:
+        return _frames('', {'+': {}, '-': {}}, {'+': {}, '-': {}}, [], {'+': {}, '-': {}}, [] if n_shuffles else None)
+    return tuple(pd.concat([f[k] for f in frames], axis=0) for k in range(3))
+
+
+def _frames(chromosome, sites, gone, records, mean_mi, pvals):
+    """the three DataFrames of mismatch.py:406-509 from the filtered sites and the MI block's output"""
     pair_cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
     df_pairs = pd.DataFrame.from_records(records, columns=pair_cols)
     if pvals is not None:
