@@ -36,15 +36,16 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Measured with tools/ubench_valu.hip: 40.4e12 lane-ops/s for v_and_b32 + v_add_u32 (profiles/r01_ubench_valu.txt).
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # 3.93e13
 WORD_OP_LANE_OPS = 4                  # one 64-bit AND+POPC = 2 v_and_b32 + 2 v_bcnt_u32_b32
+MFMA_I8_PEAK_TOPS = 5000.0            # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (2.5 PF dense) per clock
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, mfma=False):
     """HBM bytes per k_count launch from the committed PMC passes (profiles/r01_pmc_k_count.json): rocprofv3
     cannot be driven from inside this process, so the counters are collected by the separate --pmc runs
     described in that file and looked up here by workload name."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_k_count.json')) as f:
-            return json.load(f).get(workload, {}).get('hbm_bytes')
+            return json.load(f).get(workload + ('_mfma' if mfma else ''), {}).get('hbm_bytes')
     except OSError:
         return None
 
@@ -156,6 +157,7 @@ def main():
         # dominant kernel: k_count.  Algorithmic HBM bytes per launch:
         # every column's planes once (16 B per 64-read word) + site metadata + the 4 count planes
         # of every computed slot (16 B).
+        mfma = info.get('n_mfma_tiles', 0) > 0
         alg_bytes = info['bytes_in'] + 16 * info['n_tile_pairs']
         word_ops = 4 * info['word_pairs']                      # 4 mandatory AND+POPC per pair-word
         secs = ms_count * 1e-3
@@ -173,18 +175,28 @@ def main():
                        'emitted_pairs_per_gpu': info['n_rows'], 'parallelism': 'dp%d' % world},
             'stage_ms': {k: sum(i[k] for i in infos) / len(infos)
                          for k in ('ms_total', 'ms_prep', 'ms_count', 'ms_emit', 'ms_perm', 'ms_mean')},
-            'roofline': {'kernel': 'k_count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes,
-                         'achieved': alg_bytes / secs / 1e9,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic(args.workload),
-                         'note': 'bytes per launch; k_count is VALU(popcount)-bound, not HBM-bound: see '
-                                 'valu_roofline.  traffic = L2-miss bytes (FETCH_SIZE x2 + WRITE_SIZE, '
-                                 'profiles/r01_pmc_k_count.json): columns are re-read once per group of 8 x-tile rows'},
-            'valu_roofline': {'kernel': 'k_count', 'bound': 'valu_popcount',
-                              'achieved': word_ops / secs / 1e12, 'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12,
-                              'unit': 'T word-ops/s (64-bit AND+POPC)',
-                              'frac': word_ops / secs / (VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS)},
         }
+        hbm = {'kernel': 'count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes, 'achieved': alg_bytes / secs / 1e9,
+               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
+               'traffic': pmc_traffic(args.workload, mfma),
+               'note': 'bytes per launch; the count kernel is compute-bound, not HBM-bound.  traffic = L2-miss bytes '
+                       '(FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_k_count.json)'}
+        valu = {'kernel': 'k_count', 'bound': 'valu_popcount', 'achieved': word_ops / secs / 1e12,
+                'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12, 'unit': 'T word-ops/s (64-bit AND+POPC)',
+                'frac': word_ops / secs / (VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS)}
+        if mfma:
+            # k_count_mfma: the four counts of a pair-word are 4 x 64 int8 multiply-accumulates = 512 ops
+            ops = 512.0 * info['word_pairs']
+            out['roofline'] = {'kernel': 'k_count_mfma', 'bound': 'mfma', 'achieved': ops / secs / 1e12,
+                               'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s (int8, dense)',
+                               'frac': ops / secs / 1e12 / MFMA_I8_PEAK_TOPS, 'traffic': hbm['traffic'],
+                               'algorithmic_ops': ops,
+                               'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2); '
+                                       'v_mfma_i32_32x32x32_i8, operands expanded from bit planes in registers'}
+            out['hbm_roofline'] = hbm
+        else:
+            out['roofline'] = hbm
+            out['valu_roofline'] = valu
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, args.shuffles, seed)
     db.free()

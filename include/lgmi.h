@@ -142,7 +142,7 @@ typedef struct lgmi_run_info {
     float ms_perm;          /* permutation p-values                                */
     float ms_mean;          /* per-site mean MI                                    */
     uint32_t n_count_launches;
-    uint32_t reserved;
+    uint32_t n_mfma_tiles;  /* 128 x 128 tiles computed on the int8 matrix cores (0: VALU popcount only) */
 } lgmi_run_info;
 
 /* device-side synthetic chromosome generator (SURVEY 8d "dense" regime):

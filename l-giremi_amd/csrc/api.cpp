@@ -424,11 +424,17 @@ struct Plan {
     std::vector<BlockPlan> plans;
     std::vector<uint32_t> xlist, ylist;
     std::vector<SiteMap> smap;
-    std::vector<Tile> tiles;
+    std::vector<Tile> tiles;        // 64 x 64 tiles for k_count (VALU popcount)
+    std::vector<Tile> mtiles;       // 128 x 128 tiles for k_count_mfma (int8 matrix cores)
     uint64_t total_slots = 0, n_examined = 0, bytes_in = 0;
 };
 
 static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
+    int count_kernel_choice = 0;   // 0 auto, 1 VALU popcount only, 2 matrix cores only
+    if (const char* e = getenv("LGMI_COUNT_KERNEL")) {
+        if (!strcmp(e, "valu")) count_kernel_choice = 1;
+        else if (!strcmp(e, "mfma")) count_kernel_choice = 2;
+    }
     const uint64_t ns = db->d.n_sites;
     pl.smap.assign(ns, SiteMap{NONE, NONE, NONE, NONE, 0, 0});
     pl.plans.resize(db->d.n_blocks);
@@ -468,35 +474,44 @@ static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
         for (uint32_t s = sb; s < se; ++s)
             pl.n_examined += (pl.smap[s].xrow != NONE) ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
         if (bp.nx == 0) continue;
-        // tiles: union band per 64-column group of each list
-        const uint32_t ntx = (bp.nx + TILE - 1) / TILE, nty = (bp.ny + TILE - 1) / TILE;
+        // which count kernel: the matrix-core kernel pays off on blocks with many columns and many reads
+        // (its 128 x 128 tile has a 256-store epilogue per lane); small or shallow blocks keep the
+        // VALU popcount kernel.  LGMI_COUNT_KERNEL=valu|mfma forces one of them (tests, A/B runs).
+        const uint32_t block_words = (db->block_n_reads[b] + 63u) / 64u;
+        bool use_mfma = bp.nx >= 96 && bp.ny >= 96 && block_words >= 32;
+        if (count_kernel_choice == 1) use_mfma = false;
+        if (count_kernel_choice == 2) use_mfma = true;
+        const uint32_t edge = use_mfma ? 128u : (uint32_t)TILE;
+        std::vector<Tile>& out_tiles = use_mfma ? pl.mtiles : pl.tiles;
+        // tiles: union band per `edge`-column group of each list
+        const uint32_t ntx = (bp.nx + edge - 1) / edge, nty = (bp.ny + edge - 1) / edge;
         xmin.assign(ntx, 0xFFFFFFFFu); xmax.assign(ntx, 0); ymin.assign(nty, 0xFFFFFFFFu); ymax.assign(nty, 0);
         for (uint32_t r = 0; r < bp.nx; ++r) {
             const Col& c = db->cols[pl.xlist[bp.xl_off + r]];
             if (!c.nw) continue;
-            xmin[r / TILE] = std::min(xmin[r / TILE], c.w0); xmax[r / TILE] = std::max(xmax[r / TILE], c.w0 + c.nw);
+            xmin[r / edge] = std::min(xmin[r / edge], c.w0); xmax[r / edge] = std::max(xmax[r / edge], c.w0 + c.nw);
         }
         for (uint32_t q = 0; q < bp.ny; ++q) {
             const Col& c = db->cols[pl.ylist[bp.yl_off + q]];
             if (!c.nw) continue;
-            ymin[q / TILE] = std::min(ymin[q / TILE], c.w0); ymax[q / TILE] = std::max(ymax[q / TILE], c.w0 + c.nw);
+            ymin[q / edge] = std::min(ymin[q / edge], c.w0); ymax[q / edge] = std::max(ymax[q / edge], c.w0 + c.nw);
         }
         // tile order: groups of XG x-tile rows sweep the y tiles together, so that the XG tiles that
-        // run side by side on an XCD (count.hip: xcd_remap) share one y tile in L2 and every y column is
+        // run side by side on an XCD (xcd_remap in the kernels) share one y tile in L2 and every y column is
         // fetched from HBM once per group instead of once per x-tile row
-        const uint32_t XG = 8;
+        const uint32_t XG = use_mfma ? 4 : 8;
         for (uint32_t tg = 0; tg < ntx; tg += XG) {
             for (uint32_t ty = 0; ty < nty; ++ty) {
                 if (ymin[ty] >= ymax[ty]) continue;
-                const uint32_t y0 = ty * TILE, y1 = std::min(y0 + TILE, bp.ny);
+                const uint32_t y0 = ty * edge, y1 = std::min(y0 + edge, bp.ny);
                 for (uint32_t tx = tg; tx < std::min(tg + XG, ntx); ++tx) {
                     if (xmin[tx] >= xmax[tx]) continue;
-                    const uint32_t x0 = tx * TILE, x1 = std::min(x0 + TILE, bp.nx);
+                    const uint32_t x0 = tx * edge, x1 = std::min(x0 + edge, bp.nx);
                     // x site rows against x site cols: only row rank < col rank is ever read
                     if (x1 <= nxs && y0 >= y_xpart && y1 <= y_xpart + nxs && x0 >= (y1 - 1 - y_xpart)) continue;
                     const uint32_t k0 = std::max(xmin[tx], ymin[ty]), k1 = std::min(xmax[tx], ymax[ty]);
                     if (k0 >= k1) continue;
-                    pl.tiles.push_back(Tile{(uint32_t)b, x0, y0, k0, k1});
+                    out_tiles.push_back(Tile{(uint32_t)b, x0, y0, k0, k1});
                 }
             }
         }
@@ -550,7 +565,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     Plan pl;
     build_plan(db, prm->het_only != 0, pl);
-    if (pl.tiles.size() >= 0x7FFFFFFFull) return fail(LGMI_E_ARG, "too many tiles");
+    if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull) return fail(LGMI_E_ARG, "too many tiles");
 
     lgmi_dresult* res = new lgmi_dresult();
     res->ctx = ctx;
@@ -565,7 +580,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     } guard{pool, scratch, res};
     auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
 
-    BlockPlan* d_plans; uint32_t* d_xlist; uint32_t* d_ylist; SiteMap* d_smap; Tile* d_tiles;
+    BlockPlan* d_plans; uint32_t* d_xlist; uint32_t* d_ylist; SiteMap* d_smap; Tile* d_tiles; Tile* d_mtiles;
     uint32_t *sN, *sR, *sC, *sA, *d_rowcnt; uint64_t* d_rowstart; unsigned long long* d_sum; uint32_t* d_cnt;
     int* d_err; unsigned long long* d_wordpairs;
     if ((rc = salloc((void**)&d_plans, pl.plans.size() * sizeof(BlockPlan)))) return rc;
@@ -573,6 +588,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if ((rc = salloc((void**)&d_ylist, pl.ylist.size() * 4))) return rc;
     if ((rc = salloc((void**)&d_smap, pl.smap.size() * sizeof(SiteMap)))) return rc;
     if ((rc = salloc((void**)&d_tiles, pl.tiles.size() * sizeof(Tile)))) return rc;
+    if ((rc = salloc((void**)&d_mtiles, pl.mtiles.size() * sizeof(Tile)))) return rc;
     if ((rc = salloc((void**)&sN, pl.total_slots * 4))) return rc;
     if ((rc = salloc((void**)&sR, pl.total_slots * 4))) return rc;
     if ((rc = salloc((void**)&sC, pl.total_slots * 4))) return rc;
@@ -595,11 +611,14 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(h2d(d_ylist, pl.ylist.data(), pl.ylist.size() * 4));
     HIPCHK(h2d(d_smap, pl.smap.data(), pl.smap.size() * sizeof(SiteMap)));
     HIPCHK(h2d(d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)));
+    HIPCHK(h2d(d_mtiles, pl.mtiles.data(), pl.mtiles.size() * sizeof(Tile)));
     HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 16, st));
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
 
     HIPCHK(hipEventRecord(ctx->ev[1], st));
+    launch_count_mfma(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols,
+                      db->d.d_cplanes, sN, sR, sC, sA);
     launch_count(st, (uint32_t)pl.tiles.size(), d_tiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
                  sN, sR, sC, sA);
     HIPCHK(hipGetLastError());
@@ -655,11 +674,12 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     lgmi_run_info& inf = res->info;
     inf.n_rows = n_rows;
     inf.n_examined = pl.n_examined;
-    inf.n_tile_pairs = (uint64_t)pl.tiles.size() * TILE * TILE;
+    inf.n_tile_pairs = (uint64_t)pl.tiles.size() * TILE * TILE + (uint64_t)pl.mtiles.size() * 128 * 128;
     inf.word_pairs = wp;
     inf.bytes_in = pl.bytes_in;
     inf.bytes_out = n_rows * (16ull + (want_p ? 8ull : 0ull) + (want_counts ? 36ull : 0ull));
-    inf.n_count_launches = pl.tiles.empty() ? 0 : 1;
+    inf.n_count_launches = (pl.tiles.empty() ? 0 : 1) + (pl.mtiles.empty() ? 0 : 1);
+    inf.n_mfma_tiles = (uint32_t)std::min<size_t>(pl.mtiles.size(), 0xFFFFFFFFu);
     HIPCHK(hipEventElapsedTime(&inf.ms_prep, ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&inf.ms_count, ctx->ev[1], ctx->ev[2]));
     HIPCHK(hipEventElapsedTime(&inf.ms_emit, ctx->ev[2], ctx->ev[3]));

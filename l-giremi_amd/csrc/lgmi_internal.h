@@ -77,6 +77,11 @@ void launch_count(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const Blo
                   const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
                   const ulonglong2* cplanes, uint32_t* sN, uint32_t* sR, uint32_t* sC, uint32_t* sA);
 
+// count_mfma.hip (128 x 128 tiles on the int8 matrix cores; same slot planes)
+void launch_count_mfma(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
+                       const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
+                       const ulonglong2* cplanes, uint32_t* sN, uint32_t* sR, uint32_t* sC, uint32_t* sA);
+
 // emit.hip
 struct EmitArgs {
     uint32_t n_sites;

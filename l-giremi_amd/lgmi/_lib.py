@@ -41,7 +41,7 @@ class RunInfo(C.Structure):
                 ('word_pairs', C.c_uint64), ('bytes_in', C.c_uint64), ('bytes_out', C.c_uint64),
                 ('ms_total', C.c_float), ('ms_prep', C.c_float), ('ms_count', C.c_float),
                 ('ms_emit', C.c_float), ('ms_perm', C.c_float), ('ms_mean', C.c_float),
-                ('n_count_launches', C.c_uint32), ('reserved', C.c_uint32)]
+                ('n_count_launches', C.c_uint32), ('n_mfma_tiles', C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}

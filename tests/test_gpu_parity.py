@@ -316,3 +316,38 @@ def test_mip_column(engine):
     for v, g in zip(mean, got):
         assert (np.isnan(v) and np.isnan(g)) or abs(f(v) - g) <= 1e-12
     assert np.isnan(lgmi.mean_mi_to_mip([np.nan, np.nan], np.array(['het_snp', 'snp']), engine=engine)).all()
+
+
+# ---------------------------------------------------------------- the two count kernels (VALU popcount / int8 matrix cores)
+@pytest.mark.parametrize('kernel', ['valu', 'mfma'])
+@pytest.mark.parametrize('seed', range(6))
+def test_both_count_kernels_match_oracle(engine, monkeypatch, kernel, seed):
+    from oracle import c_oracle
+    from util_synth import pack_class_matrix, random_block
+    monkeypatch.setenv('LGMI_COUNT_KERNEL', kernel)
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    shapes = [(130, 300), (257, 4100), (64, 64), (200, 1000), (129, 129), (40, 5000)]
+    P, R = shapes[seed]
+    blocks = [random_block(rng, P, R, banded=bool(seed % 2), tri_frac=0.15, het_frac=0.5),
+              random_block(rng, 10 + seed, 70, tri_frac=0.2, het_frac=0.5)]
+    pb = pack_class_matrix(blocks)
+    for het_only in (True, False):
+        ora = c_oracle.run(pb, min_common=3, het_only=het_only)
+        res = engine.run(pb, min_common=3, het_only=het_only, emit_counts=True)
+        assert_same_as_oracle(res, ora)
+        assert (res.info['n_mfma_tiles'] > 0) == (kernel == 'mfma')
+
+
+def test_auto_kernel_choice_uses_matrix_cores_on_large_dense_blocks(engine):
+    import lgmi
+    from oracle import c_oracle
+    spec = lgmi.default_synth_spec(700, 6000, seed=9)
+    spec.tri_per_1024 = 100
+    db = engine.synth_dense(spec)
+    dr = engine.run_device(db, min_common=6, het_only=True, emit_counts=True)
+    assert dr.info()['n_mfma_tiles'] > 0
+    res = dr.fetch()
+    ora = c_oracle.run(db.download(), min_common=6, het_only=True)
+    assert_same_as_oracle(res, ora)
+    dr.free()
+    db.free()
