@@ -9,10 +9,11 @@
 // One 256-thread workgroup (4 waves, 2 x 2) computes a 128 x 128 tile of a block's slot matrix;
 // each wave owns 64 x 64 column pairs = 4 x-fragments (2 column groups x {C, A} plane) times
 // 4 y-fragments, i.e. 16 accumulator tiles of 32 x 32 (256 registers).  Bit planes are staged
-// through LDS exactly as in count.hip (16-byte (C, A) entries); a lane expands the 16 bits of
-// its row and k-half into 16 int8 {0,1} in registers (3 VALU ops per 4 bytes:
-// bfe, mul_u24 by 0x204081, and 0x01010101) and feeds them straight to the MFMA — the 8x larger
-// byte matrix never exists in HBM or LDS.
+// loaded from HBM as 16-byte (C, A) words by the thread that owns the column; that thread expands
+// each 64-read word into 128 int8 {0,1} (3 VALU ops per 4 bytes: bfe, mul_u24 by 0x204081, and
+// 0x01010101) and writes them to LDS in MFMA operand order, once per workgroup — every expanded
+// fragment is consumed by the two waves that share the column group.  The 8x larger byte matrix
+// exists only in LDS, two words deep.
 //
 // Lane maps (checked with exact integer data, tools/mfma_i8_probe.hip):
 //   A operand: lane l holds A[row = l & 31][k = 16 (l >> 5) + j], j = 0..15 (bytes of 4 dwords)
@@ -26,7 +27,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 static const int MT = 128;     // tile edge in columns
-static const int MKC = 8;      // 64-bit words staged per LDS stage
+static const int MCH = 8;      // 64-bit words a thread keeps in registers between global loads
 
 __device__ __forceinline__ uint32_t xcd_remap_m(uint32_t b, uint32_t n) {
     uint32_t q = n / 8, r = n % 8, xcd = b % 8, idx = b / 8;
@@ -52,7 +53,19 @@ __device__ __forceinline__ uint4 m_ld_entry(const MStageCol& c, uint32_t k) {
     return v;
 }
 
+#ifndef LGMI_ABL
+#define LGMI_ABL 0      // timing-only ablations: 1 no expansion, 2 no per-word barrier, 4 no MFMA
+#endif
+#if LGMI_ABL & 4
+#define LGMI_MFMA(acc, a, b) acc[0] += a.x + b.y
+#else
 #define LGMI_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0)
+#endif
+
+// LDS image of one word: [half h][fragment f][lane] of 16 bytes, where fragment f = side*8 + group*2 + plane
+// (side 0 = x columns, 1 = y columns; group = 32-column group of the 128; plane 0 = C, 1 = A) and the entry
+// of lane l = (k-half q = l >> 5, row r = l & 31) is exactly that lane's MFMA operand.
+typedef uint4 ByteWord[2][16][64];   // 32 KB
 
 __global__ __launch_bounds__(256, 1) void k_count_mfma(
     uint32_t n_tiles, const Tile* __restrict__ tiles, const BlockPlan* __restrict__ plans,
@@ -61,16 +74,14 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
     uint32_t* __restrict__ sN, uint32_t* __restrict__ sR, uint32_t* __restrict__ sC,
     uint32_t* __restrict__ sA)
 {
-    // [buf][k][slot]: slots 0..127 = x columns of the tile, 128..255 = y columns; (C_lo, C_hi, A_lo, A_hi)
-    __shared__ uint4 lds[2][MKC][2 * MT];
+    __shared__ ByteWord byt[2];   // double buffer: word w is read while word w + 1 is written
 
     const Tile t = tiles[xcd_remap_m(blockIdx.x, n_tiles)];
     const BlockPlan bp = plans[t.block];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t wx = wave >> 1, wy = wave & 1u;        // 2 x 2 waves over the 128 x 128 tile
-    const uint32_t r32 = lane & 31u, q16 = (lane >> 5) * 16u;
 
-    // ---- staging role: thread tid stages column slot tid, all MKC words of a stage
+    // ---- producer role: thread tid owns column slot tid (0..127 x columns, 128..255 y columns)
     MStageCol sc;
     {
         uint32_t col = NONE;
@@ -81,6 +92,10 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
             sc.base = cplanes + ci.off - ci.w0; sc.w0 = ci.w0; sc.w1 = ci.w0 + ci.nw;
         } else { sc.base = cplanes; sc.w0 = 1u; sc.w1 = 0u; }
     }
+    // where this thread's 8 entries of a word go: fragment pair (C, A) of its side and column group, row r
+    const uint32_t pf = (tid >> 7) * 8u + ((tid & 127u) >> 5) * 2u, pr = tid & 31u;
+    // ---- consumer role: fragments of this wave
+    const uint32_t fa = (2u * wx) * 2u, fb = 8u + (2u * wy) * 2u;   // first x / y fragment (C plane of group 0)
 
     v16i acc[2][2][4];     // [x group][y group][N, R, C, A]
 #pragma unroll
@@ -92,75 +107,74 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0;
 
-    const uint32_t n_stage = (t.k1 - t.k0 + MKC - 1) / MKC;
-    uint4 st[MKC];
-#pragma unroll
-    for (int k = 0; k < MKC; ++k) st[k] = m_ld_entry(sc, t.k0 + k);
-#pragma unroll
-    for (int k = 0; k < MKC; ++k) lds[0][k][tid] = st[k];
-    __syncthreads();
-
-    // Software pipeline inside the wave (one wave per SIMD, so nothing else hides the expansion):
-    // while the 16 MFMAs of one 32-read half run on the matrix pipe, the VALU expands the fragments
-    // of the next half (an MFMA holds vector issue for 8 of its 32 cycles: ~6 VALU slots per MFMA,
-    // 96 per half = the 8 x 12 expansion instructions).  sched_group_barrier pins the 2 MFMA : 12 VALU
-    // interleave that the source order suggests.
-    const uint32_t xs0 = 64u * wx + r32, ys0 = MT + 64u * wy + r32;
-#define LGMI_EXPAND8(F, X0, X1, Y0, Y1, LO)                                                   \
-    F##ac0 = expand16(LO ? X0.x : X0.y, q16); F##aa0 = expand16(LO ? X0.z : X0.w, q16);        \
-    F##ac1 = expand16(LO ? X1.x : X1.y, q16); F##aa1 = expand16(LO ? X1.z : X1.w, q16);        \
-    F##bc0 = expand16(LO ? Y0.x : Y0.y, q16); F##ba0 = expand16(LO ? Y0.z : Y0.w, q16);        \
-    F##bc1 = expand16(LO ? Y1.x : Y1.y, q16); F##ba1 = expand16(LO ? Y1.z : Y1.w, q16);
-#define LGMI_MFMA16(F)                                                                         \
-    LGMI_MFMA(acc[0][0][0], F##ac0, F##bc0); LGMI_MFMA(acc[0][0][1], F##aa0, F##bc0);          \
-    LGMI_MFMA(acc[0][0][2], F##ac0, F##ba0); LGMI_MFMA(acc[0][0][3], F##aa0, F##ba0);          \
-    LGMI_MFMA(acc[0][1][0], F##ac0, F##bc1); LGMI_MFMA(acc[0][1][1], F##aa0, F##bc1);          \
-    LGMI_MFMA(acc[0][1][2], F##ac0, F##ba1); LGMI_MFMA(acc[0][1][3], F##aa0, F##ba1);          \
-    LGMI_MFMA(acc[1][0][0], F##ac1, F##bc0); LGMI_MFMA(acc[1][0][1], F##aa1, F##bc0);          \
-    LGMI_MFMA(acc[1][0][2], F##ac1, F##ba0); LGMI_MFMA(acc[1][0][3], F##aa1, F##ba0);          \
-    LGMI_MFMA(acc[1][1][0], F##ac1, F##bc1); LGMI_MFMA(acc[1][1][1], F##aa1, F##bc1);          \
-    LGMI_MFMA(acc[1][1][2], F##ac1, F##ba1); LGMI_MFMA(acc[1][1][3], F##aa1, F##ba1);
-#define LGMI_INTERLEAVE()                                                                      \
-    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   /* 2 MFMA  */                     \
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  /* 12 VALU */                     \
+#define LGMI_PRODUCE(BUF, E)                                                                          \
+    {                                                                                                 \
+        byt[BUF][0][pf][pr] = __builtin_bit_cast(uint4, expand16((E).x, 0u));                           \
+        byt[BUF][0][pf][32u + pr] = __builtin_bit_cast(uint4, expand16((E).x, 16u));                    \
+        byt[BUF][1][pf][pr] = __builtin_bit_cast(uint4, expand16((E).y, 0u));                           \
+        byt[BUF][1][pf][32u + pr] = __builtin_bit_cast(uint4, expand16((E).y, 16u));                    \
+        byt[BUF][0][pf + 1u][pr] = __builtin_bit_cast(uint4, expand16((E).z, 0u));                      \
+        byt[BUF][0][pf + 1u][32u + pr] = __builtin_bit_cast(uint4, expand16((E).z, 16u));               \
+        byt[BUF][1][pf + 1u][pr] = __builtin_bit_cast(uint4, expand16((E).w, 0u));                      \
+        byt[BUF][1][pf + 1u][32u + pr] = __builtin_bit_cast(uint4, expand16((E).w, 16u));               \
     }
-    v4i p_ac0, p_aa0, p_ac1, p_aa1, p_bc0, p_ba0, p_bc1, p_ba1;   // fragments of the half in flight
-    v4i n_ac0, n_aa0, n_ac1, n_aa1, n_bc0, n_ba0, n_bc1, n_ba1;   // fragments being expanded
-    for (uint32_t s = 0; s < n_stage; ++s) {
-        const uint32_t buf = s & 1u;
-        const bool more = (s + 1 < n_stage);
-        if (more) {
+#define LGMI_CONSUME_HALF(BUF, H)                                                                     \
+    {                                                                                                 \
+        const v4i ac0 = __builtin_bit_cast(v4i, byt[BUF][H][fa][lane]);                                 \
+        const v4i aa0 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 1u][lane]);                            \
+        const v4i ac1 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 2u][lane]);                            \
+        const v4i aa1 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 3u][lane]);                            \
+        const v4i bc0 = __builtin_bit_cast(v4i, byt[BUF][H][fb][lane]);                                 \
+        const v4i ba0 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 1u][lane]);                            \
+        const v4i bc1 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 2u][lane]);                            \
+        const v4i ba1 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 3u][lane]);                            \
+        LGMI_MFMA(acc[0][0][0], ac0, bc0); LGMI_MFMA(acc[0][0][1], aa0, bc0);                           \
+        LGMI_MFMA(acc[0][0][2], ac0, ba0); LGMI_MFMA(acc[0][0][3], aa0, ba0);                           \
+        LGMI_MFMA(acc[0][1][0], ac0, bc1); LGMI_MFMA(acc[0][1][1], aa0, bc1);                           \
+        LGMI_MFMA(acc[0][1][2], ac0, ba1); LGMI_MFMA(acc[0][1][3], aa0, ba1);                           \
+        LGMI_MFMA(acc[1][0][0], ac1, bc0); LGMI_MFMA(acc[1][0][1], aa1, bc0);                           \
+        LGMI_MFMA(acc[1][0][2], ac1, ba0); LGMI_MFMA(acc[1][0][3], aa1, ba0);                           \
+        LGMI_MFMA(acc[1][1][0], ac1, bc1); LGMI_MFMA(acc[1][1][1], aa1, bc1);                           \
+        LGMI_MFMA(acc[1][1][2], ac1, ba1); LGMI_MFMA(acc[1][1][3], aa1, ba1);                           \
+    }
+
+    // words are taken MCH at a time: while chunk c is expanded and multiplied, chunk c + 1 is in flight from HBM
+    const uint32_t n_words = t.k1 - t.k0;
+    const uint32_t n_chunk = (n_words + MCH - 1) / MCH;
+    uint4 cur[MCH], nxt[MCH];
 #pragma unroll
-            for (int k = 0; k < MKC; ++k) st[k] = m_ld_entry(sc, t.k0 + (s + 1) * MKC + k);
-        }
-        uint4 x0 = lds[buf][0][xs0], x1 = lds[buf][0][xs0 + 32u];
-        uint4 y0 = lds[buf][0][ys0], y1 = lds[buf][0][ys0 + 32u];
-        LGMI_EXPAND8(p_, x0, x1, y0, y1, true)
-#pragma unroll 1
-        for (int k = 0; k < MKC; ++k) {
-            const int kn = (k + 1 < MKC) ? k + 1 : k;       // the last word re-reads itself (result unused)
-            const uint4 nx0 = lds[buf][kn][xs0], nx1 = lds[buf][kn][xs0 + 32u];
-            const uint4 ny0 = lds[buf][kn][ys0], ny1 = lds[buf][kn][ys0 + 32u];
-            // reads 0..31 of word k on the matrix pipe, reads 32..63 expanded meanwhile
-            LGMI_EXPAND8(n_, x0, x1, y0, y1, false)
-            LGMI_MFMA16(p_)
-            LGMI_INTERLEAVE()
-            // reads 32..63 of word k on the matrix pipe, reads 0..31 of word k + 1 expanded meanwhile
-            LGMI_EXPAND8(p_, nx0, nx1, ny0, ny1, true)
-            LGMI_MFMA16(n_)
-            LGMI_INTERLEAVE()
-            x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1;
-        }
-        if (more) {
+    for (int k = 0; k < MCH; ++k) cur[k] = m_ld_entry(sc, t.k0 + k);
+    LGMI_PRODUCE(0, cur[0])
+    __syncthreads();
+    for (uint32_t c = 0; c < n_chunk; ++c) {
+        const uint32_t kb = t.k0 + (c + 1) * MCH;           // words past k1 are outside every band -> zeros
 #pragma unroll
-            for (int k = 0; k < MKC; ++k) lds[buf ^ 1u][k][tid] = st[k];
+        for (int k = 0; k < MCH; ++k) nxt[k] = m_ld_entry(sc, kb + k);
+#pragma unroll
+        for (int k = 0; k < MCH; ++k) {
+            // word k of the chunk sits in byt[k & 1]; produce the following word into the other buffer
+#if !(LGMI_ABL & 1)
+            if (k + 1 < MCH) { LGMI_PRODUCE((k + 1) & 1, cur[k + 1]) } else { LGMI_PRODUCE(0, nxt[0]) }
+#endif
+            LGMI_CONSUME_HALF(k & 1, 0)
+            LGMI_CONSUME_HALF(k & 1, 1)
+            // spread the producer's expansion VALU between the 32 MFMAs of the word (an MFMA holds vector
+            // issue for 8 of its 32 cycles) instead of one ~140-instruction run in front of them
+#pragma unroll
+            for (int g_ = 0; g_ < 32; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU
+            }
+#if !(LGMI_ABL & 2)
+            __syncthreads();
+#endif
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MCH; ++k) cur[k] = nxt[k];
     }
 
     // ---- epilogue: reg r of lane l is (x row (r&3) + 8 (r>>2) + 4 (l>>5), y col l&31) of its 32 x 32 tile
-    const uint32_t lh = lane >> 5;
+    const uint32_t lh = lane >> 5, r32 = lane & 31u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
