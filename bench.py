@@ -188,7 +188,7 @@ def main():
             # k_count_mfma: the four counts of a pair-word are 4 x 64 int8 multiply-accumulates = 512 ops
             ops = 512.0 * info['word_pairs']
             out['roofline'] = {'kernel': 'k_count_mfma', 'bound': 'mfma', 'achieved': ops / secs / 1e12,
-                               'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s (int8, dense)',
+                               'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s', 'op_kind': 'int8 multiply-add ops (tera-ops/s), dense MFMA peak',
                                'frac': ops / secs / 1e12 / MFMA_I8_PEAK_TOPS, 'traffic': hbm['traffic'],
                                'algorithmic_ops': ops,
                                'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2); '

@@ -9,6 +9,7 @@ from .engine import Engine, MIResult, default_engine, default_synth_spec, make_p
 from .pack import PackedBatch, pack_blocks  # noqa: F401
 from .stat import ecdf, mean_mi_to_mip  # noqa: F401
 from . import dist, synth  # noqa: F401
+from .splice import site_splice_mi, site_splice_pairs  # noqa: F401
 from .region import (get_region_mismatches_with_filters, region_mismatch_analysis,  # noqa: F401
                      regions_mismatch_analysis)
 

@@ -331,6 +331,57 @@ def region_cases():
     return out
 
 
+def splice_tables(seed, n_reads, n_sites, n_splice, dup=False):
+    """synthetic read-site / read-splice tables for calculate_site_splice_mi.py"""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    reads = ['rd%04d' % i for i in range(n_reads)]
+    rows = []
+    for c in ('chr1', 'chr2'):
+        for s in range(n_sites):
+            pos = 100 + 37 * s
+            for r in reads:
+                if rng.random() < 0.5:
+                    rows.append([r, c, pos, str(rng.choice(['A', 'G', 'T'], p=[0.5, 0.4, 0.1]))])
+                    if dup and rng.random() < 0.05:
+                        rows.append([r, c, pos, str(rng.choice(['A', 'G']))])
+    site = pd.DataFrame(rows, columns=['read_name', 'chromosome', 'pos', 'seq'])
+    rows = []
+    for c in ('chr1', 'chr2'):
+        for r in reads:
+            for k in range(n_splice):
+                if rng.random() < 0.4:
+                    rows.append([r, c, 1000 + k * 50 + int(rng.integers(0, 3)), 'l', 1000 + k * 50, 'annot'])
+    splice = pd.DataFrame(rows, columns=['read_name', 'chromosome', 'pos', 'type', 'corrected_pos', 'annotation'])
+    return site, splice
+
+
+def splice_cases():
+    """the reference utility is a script (argparse + main): run it with runpy on TSV files"""
+    import runpy
+    import tempfile
+    import warnings
+    import pandas as pd
+    warnings.simplefilter('ignore')
+    cases = []
+    for name, kw in (('small', dict(seed=1, n_reads=30, n_sites=3, n_splice=2)),
+                     ('dups', dict(seed=2, n_reads=50, n_sites=4, n_splice=3, dup=True)),
+                     ('two_chunks', dict(seed=3, n_reads=700, n_sites=2, n_splice=20))):
+        site, splice = splice_tables(**kw)
+        d = tempfile.mkdtemp()
+        site.to_csv(d + '/site.tsv', sep='\t', index=False)
+        splice.to_csv(d + '/splice.tsv', sep='\t', index=False)
+        argv, sys.argv = sys.argv, ['x', '-m', d + '/site.tsv', '-s', d + '/splice.tsv', '-o', d + '/out']
+        try:
+            runpy.run_path(os.path.join(REF, 'script', 'calculate_site_splice_mi.py'), run_name='__main__')
+        finally:
+            sys.argv = argv
+        out = pd.read_table(d + '/out.site_splice_pair', sep='\t')
+        cases.append({'name': name, 'site': site.values.tolist(), 'splice': splice.values.tolist(),
+                      'out': {'columns': list(out.columns), 'data': out.values.tolist()}})
+    return cases
+
+
 def main():
     import sklearn
     import scipy
@@ -345,6 +396,8 @@ def main():
         json.dump({'meta': meta, 'cases': [case('cfg1_banded_500x2000', mm, 6)]}, f)
     with open(os.path.join(HERE, 'ecdf.json'), 'w') as f:
         json.dump({'meta': meta, 'cases': ecdf_cases()}, f)
+    with open(os.path.join(HERE, 'splice.json'), 'w') as f:
+        json.dump({'meta': meta, 'cases': splice_cases()}, f)
     with open(os.path.join(HERE, 'region.json'), 'w') as f:
         json.dump({'meta': meta, 'cases': region_cases()}, f)
     if '--time' in sys.argv:
