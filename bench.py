@@ -92,6 +92,12 @@ def main():
     ap.add_argument('--shuffles', type=int, default=1000)     # BASELINE.json configs[1]: 1000-shuffle permutation p
     ap.add_argument('--min-common', type=int, default=6)      # l-giremi CLI default (script/giremi.py:212-216)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path '
+                         'with several ranks on one GPU: set LGMI_BENCH_DEVICE=0)')
+    ap.add_argument('--lib-comm', action='store_true',
+                    help='final gather through liblgmi\'s own RCCL communicator (lgmi_comm_*) instead of '
+                         'torch.distributed (which is RCCL too); only exercised with one rank so far')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -108,10 +114,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+    tdev = 'cuda' if args.backend == 'nccl' else 'cpu'
+    device = int(os.environ.get('LGMI_BENCH_DEVICE', local_rank))
 
-    eng = lgmi.Engine(local_rank)
+    eng = lgmi.Engine(device)
     wl = WORKLOADS[args.workload]
     seed = 20250808 + 1000 * rank
     if wl.get('regime') == 'banded':
@@ -120,7 +131,7 @@ def main():
     else:
         spec = lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed)
         db = eng.synth_dense(spec)                             # input resident in HBM before timing
-    if world > 1:
+    if world > 1 and args.lib_comm:
         eng.comm_init_torch(dist, rank, world)
 
     def sync():
@@ -132,8 +143,14 @@ def main():
     def step():
         dr = eng.run_device(db, min_common=args.min_common, n_shuffles=args.shuffles, seed=seed, het_only=True)
         info = dr.info()
-        if world > 1:
-            info['world_rows'] = eng.comm_allgather_u64(info['n_rows'])   # final gather (RCCL over xGMI)
+        if world > 1:                                                      # final gather (RCCL over xGMI)
+            if args.lib_comm:
+                info['world_rows'] = eng.comm_allgather_u64(info['n_rows'])
+            else:
+                mine = torch.tensor([info['n_rows']], dtype=torch.int64, device=tdev)
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                info['world_rows'] = [int(t.item()) for t in allr]
         dr.free()
         return info
 
@@ -145,7 +162,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -197,12 +214,13 @@ def main():
         else:
             out['roofline'] = hbm
             out['valu_roofline'] = valu
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
             out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, args.shuffles, seed)
     db.free()
-    eng.close()
     if dist is not None:
         dist.barrier()
+    eng.close()
+    if dist is not None:
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
