@@ -1,0 +1,155 @@
+"""``l-giremi``-compatible command line for the ``--mi_calculation_only`` path.
+
+Same flags and the same three outputs as the reference's entry point
+(src/giremi/script/giremi.py:140-321 flags, :396-409 outputs):
+
+    PREFIX.strand.txt    read_name, original_read_strand, corrected_read_strand
+    PREFIX.mi.txt        chromosome, strand, site1_pos, site1_type, site2_pos, site2_type, mi
+    PREFIX.removed.txt   chromosome, strand, pos, removed
+
+What differs by design: the reference maps ``footprint_bulk_calculation`` over a process pool and calls
+the MI step inside the workers (:375-380) — a HIP context does not survive that fork and per-footprint
+launches are tiny — so here the site extraction runs footprint by footprint on the host and the MI blocks
+of ALL footprints go to the GPU as one batch (``lgmi.region.regions_mismatch_analysis``).
+
+Not covered: the GLM scoring after the MI step (stat.py:32-143) and the GTF-based strand correction
+(strand.py): run with ``--mi_calculation_only --skip_strand_correction``; anything else exits with a
+message instead of producing partial output.  New flags: ``--n_shuffles``/``--seed`` (permutation
+p-value column ``p_perm``), ``--device``.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import sys
+from collections import defaultdict
+
+import pandas as pd
+
+from . import __version__
+from .io import open_alignment, open_fasta, open_variants
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(
+        description='L-GIREMI site-pair MI step on MI355X (l-giremi compatible flags; --mi_calculation_only path)')
+    p.add_argument('-b', '--bam_file', type=str, default=None, required=True,
+                   help='input bam file, with cs tags, sorted and indexed')
+    p.add_argument('-c', '--chromosomes', nargs='*', type=str,
+                   default=['chr%s' % c for c in list(range(1, 23)) + ['X', 'Y']], help='chromosomes to be analyzed')
+    p.add_argument('-o', '--output_prefix', type=str, default='out', help='prefix of output file')
+    p.add_argument('-t', '--thread', type=int, default=1, help='accepted for compatibility (the MI step runs on the GPU)')
+    p.add_argument('--annotation_gtf', type=str, default=None)
+    p.add_argument('--genome_fasta', type=str, default=None)
+    p.add_argument('--homopoly_length', type=int, default=5)
+    p.add_argument('--keep_non_spliced_read', action='store_true')
+    p.add_argument('--max_het_snp_ratio', type=float, default=0.65)
+    p.add_argument('--mi_calculation_only', action='store_true')
+    p.add_argument('--mi_min_common_read', type=int, default=6)
+    p.add_argument('--mi_p_threshold', type=float, default=0.05)
+    p.add_argument('--min_allele_depth', type=int, default=3)
+    p.add_argument('--min_allele_ratio', type=float, default=0.05)
+    p.add_argument('--min_het_snp_ratio', type=float, default=0.35)
+    p.add_argument('--min_total_depth', type=int, default=2)
+    p.add_argument('--min_dist_from_splice', type=int, default=4)
+    p.add_argument('--mismatch_window_size', type=int, default=100)
+    p.add_argument('--max_window_mismatch', type=int, default=10)
+    p.add_argument('--max_window_mismatch_type', type=int, default=3)
+    p.add_argument('--mode', type=str, default='cs')
+    p.add_argument('--model', type=str, default='lm')
+    p.add_argument('--padding_exon', type=int, default=10)
+    p.add_argument('--padding_gene', type=int, default=500)
+    p.add_argument('--repeat_txt', type=str, default=None)
+    p.add_argument('--skip_strand_correction', action='store_true')
+    p.add_argument('--snp_bcf', type=str, default=None)
+    p.add_argument('--n_shuffles', type=int, default=0, help='permutation shuffles per pair (0: no p_perm column)')
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--device', type=int, default=None, help='GPU index (default: LGMI_DEVICE / LOCAL_RANK / 0)')
+    p.add_argument('--version', action='version', version='lgmi %s' % __version__)
+    return p.parse_args(argv)
+
+
+def get_footprints(sam, chromosomes, min_read_count=2):
+    """[chromosome, start, end, read_count] of merged read intervals with enough reads
+    (src/giremi/footprint.py:6-50: sort by start, fuse while the next start <= the running end)"""
+    out = []
+    for chrom in chromosomes:
+        try:
+            spans = sorted(([r.reference_start, r.reference_end] for r in sam.fetch(chrom)), key=lambda iv: iv[0])
+        except (ValueError, KeyError):           # contig absent from the BAM
+            continue
+        merged, counts = [], []
+        for lo, hi in spans:
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+                counts[-1] += 1
+            else:
+                merged.append([lo, hi])
+                counts.append(1)
+        out.extend([chrom, iv[0], iv[1], n] for iv, n in zip(merged, counts) if n >= min_read_count)
+    return out
+
+
+def read_repeats(path):
+    """chrom -> [[start, end]] sorted by start (src/giremi/fileio.py:4-21)"""
+    table = defaultdict(list)
+    if path:
+        with open(path) as f:
+            for line in f:
+                if line.startswith('#'):
+                    continue
+                c = line.split('\t')
+                table[c[0]].append([int(c[1]), int(c[2])])
+        for v in table.values():
+            v.sort(key=lambda iv: iv[0])
+    return table
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    logging.basicConfig(format='%(asctime)s %(levelname)s %(message)s', level=logging.INFO)
+    if not args.mi_calculation_only:
+        sys.exit('lgmi covers the MI step: run with --mi_calculation_only (GLM scoring, stat.py:32-143, is not part of it)')
+    if not args.skip_strand_correction:
+        sys.exit('GTF-based strand correction (strand.py) is not part of lgmi: run with --skip_strand_correction')
+    if not args.genome_fasta:
+        sys.exit('--genome_fasta is required')
+
+    from .engine import Engine
+    from .region import regions_mismatch_analysis
+    sam = open_alignment(args.bam_file)
+    genome = open_fasta(args.genome_fasta)
+    vcf = open_variants(args.snp_bcf) if args.snp_bcf else None
+    repeats = read_repeats(args.repeat_txt)
+
+    logging.info('Get regions that are covered by enough reads.')
+    footprints = get_footprints(sam, args.chromosomes, args.min_total_depth)
+    logging.info('Calculate mismatches in each region.')
+    jobs = []
+    for chrom, start, end, _n in footprints:
+        snps = sorted(r.start for r in vcf.fetch(chrom, start, end)) if vcf is not None else []
+        # the reference keeps the repeat intervals that lie OUTSIDE the footprint (script/giremi.py:55-59)
+        reps = [[a, b] for a, b in repeats.get(chrom, []) if a > end or b < start]
+        jobs.append({'chromosome': chrom, 'start': start, 'end': end, 'snp_positions': snps,
+                     'simple_repeat_intervals': reps, 'read_strand_dict': None})
+    engine = Engine(args.device)
+    df_sites, df_mi, df_removed = regions_mismatch_analysis(
+        jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
+        engine=engine, concat=True, keep_non_spliced_read=args.keep_non_spliced_read,
+        min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
+        min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
+        homopoly_length=args.homopoly_length, min_het_snp_ratio=args.min_het_snp_ratio,
+        max_het_snp_ratio=args.max_het_snp_ratio, mismatch_window_size=args.mismatch_window_size,
+        max_window_mismatch=args.max_window_mismatch, max_window_mismatch_type=args.max_window_mismatch_type,
+        mode=args.mode)
+    strand_df = pd.DataFrame.from_records([], columns=['read_name', 'original_read_strand', 'corrected_read_strand'])
+    strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
+    df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
+    df_removed.to_csv(args.output_prefix + '.removed.txt', sep='\t', index=False)
+    engine.close()
+    logging.info('All done!')
+    return df_sites, df_mi, df_removed
+
+
+if __name__ == '__main__':
+    main()
