@@ -27,7 +27,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 static const int MT = 128;     // tile edge in columns
-static const int MCH = 8;      // 64-bit words a thread keeps in registers between global loads
+static const int MCH = 6;      // 64-bit words a thread keeps in registers between global loads (multiple of 2 and 3)
 
 __device__ __forceinline__ uint32_t xcd_remap_m(uint32_t b, uint32_t n) {
     uint32_t q = n / 8, r = n % 8, xcd = b % 8, idx = b / 8;
@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
     uint32_t* __restrict__ sN, uint32_t* __restrict__ sR, uint32_t* __restrict__ sC,
     uint32_t* __restrict__ sA)
 {
-    __shared__ ByteWord byt[2];   // double buffer: word w is read while word w + 1 is written
+    // three word buffers: while word w is multiplied, word w + 1 is already complete (its operands are
+    // prefetched one half ahead, so no LDS wait ever blocks the single wave of a SIMD) and word w + 2 is written
+    __shared__ ByteWord byt[3];
 
     const Tile t = tiles[xcd_remap_m(blockIdx.x, n_tiles)];
     const BlockPlan bp = plans[t.block];
@@ -118,48 +120,54 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
         byt[BUF][1][pf + 1u][pr] = __builtin_bit_cast(uint4, expand16((E).w, 0u));                      \
         byt[BUF][1][pf + 1u][32u + pr] = __builtin_bit_cast(uint4, expand16((E).w, 16u));               \
     }
-#define LGMI_CONSUME_HALF(BUF, H)                                                                     \
-    {                                                                                                 \
-        const v4i ac0 = __builtin_bit_cast(v4i, byt[BUF][H][fa][lane]);                                 \
-        const v4i aa0 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 1u][lane]);                            \
-        const v4i ac1 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 2u][lane]);                            \
-        const v4i aa1 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 3u][lane]);                            \
-        const v4i bc0 = __builtin_bit_cast(v4i, byt[BUF][H][fb][lane]);                                 \
-        const v4i ba0 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 1u][lane]);                            \
-        const v4i bc1 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 2u][lane]);                            \
-        const v4i ba1 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 3u][lane]);                            \
-        LGMI_MFMA(acc[0][0][0], ac0, bc0); LGMI_MFMA(acc[0][0][1], aa0, bc0);                           \
-        LGMI_MFMA(acc[0][0][2], ac0, ba0); LGMI_MFMA(acc[0][0][3], aa0, ba0);                           \
-        LGMI_MFMA(acc[0][1][0], ac0, bc1); LGMI_MFMA(acc[0][1][1], aa0, bc1);                           \
-        LGMI_MFMA(acc[0][1][2], ac0, ba1); LGMI_MFMA(acc[0][1][3], aa0, ba1);                           \
-        LGMI_MFMA(acc[1][0][0], ac1, bc0); LGMI_MFMA(acc[1][0][1], aa1, bc0);                           \
-        LGMI_MFMA(acc[1][0][2], ac1, ba0); LGMI_MFMA(acc[1][0][3], aa1, ba0);                           \
-        LGMI_MFMA(acc[1][1][0], ac1, bc1); LGMI_MFMA(acc[1][1][1], aa1, bc1);                           \
-        LGMI_MFMA(acc[1][1][2], ac1, ba1); LGMI_MFMA(acc[1][1][3], aa1, ba1);                           \
-    }
+#define LGMI_FETCH(F, BUF, H)                                                                         \
+    F##ac0 = __builtin_bit_cast(v4i, byt[BUF][H][fa][lane]);                                            \
+    F##aa0 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 1u][lane]);                                       \
+    F##ac1 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 2u][lane]);                                       \
+    F##aa1 = __builtin_bit_cast(v4i, byt[BUF][H][fa + 3u][lane]);                                       \
+    F##bc0 = __builtin_bit_cast(v4i, byt[BUF][H][fb][lane]);                                            \
+    F##ba0 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 1u][lane]);                                       \
+    F##bc1 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 2u][lane]);                                       \
+    F##ba1 = __builtin_bit_cast(v4i, byt[BUF][H][fb + 3u][lane]);
+#define LGMI_MFMA16(F)                                                                                \
+    LGMI_MFMA(acc[0][0][0], F##ac0, F##bc0); LGMI_MFMA(acc[0][0][1], F##aa0, F##bc0);                   \
+    LGMI_MFMA(acc[0][0][2], F##ac0, F##ba0); LGMI_MFMA(acc[0][0][3], F##aa0, F##ba0);                   \
+    LGMI_MFMA(acc[0][1][0], F##ac0, F##bc1); LGMI_MFMA(acc[0][1][1], F##aa0, F##bc1);                   \
+    LGMI_MFMA(acc[0][1][2], F##ac0, F##ba1); LGMI_MFMA(acc[0][1][3], F##aa0, F##ba1);                   \
+    LGMI_MFMA(acc[1][0][0], F##ac1, F##bc0); LGMI_MFMA(acc[1][0][1], F##aa1, F##bc0);                   \
+    LGMI_MFMA(acc[1][0][2], F##ac1, F##ba0); LGMI_MFMA(acc[1][0][3], F##aa1, F##ba0);                   \
+    LGMI_MFMA(acc[1][1][0], F##ac1, F##bc1); LGMI_MFMA(acc[1][1][1], F##aa1, F##bc1);                   \
+    LGMI_MFMA(acc[1][1][2], F##ac1, F##ba1); LGMI_MFMA(acc[1][1][3], F##aa1, F##ba1);
 
     // words are taken MCH at a time: while chunk c is expanded and multiplied, chunk c + 1 is in flight from HBM
     const uint32_t n_words = t.k1 - t.k0;
     const uint32_t n_chunk = (n_words + MCH - 1) / MCH;
     uint4 cur[MCH], nxt[MCH];
+    v4i p_ac0, p_aa0, p_ac1, p_aa1, p_bc0, p_ba0, p_bc1, p_ba1;   // operands of reads 0..31 of the current word
+    v4i q_ac0, q_aa0, q_ac1, q_aa1, q_bc0, q_ba0, q_bc1, q_ba1;   // operands of reads 32..63
 #pragma unroll
     for (int k = 0; k < MCH; ++k) cur[k] = m_ld_entry(sc, t.k0 + k);
     LGMI_PRODUCE(0, cur[0])
+    LGMI_PRODUCE(1, cur[1])
     __syncthreads();
+    LGMI_FETCH(p_, 0, 0)
     for (uint32_t c = 0; c < n_chunk; ++c) {
         const uint32_t kb = t.k0 + (c + 1) * MCH;           // words past k1 are outside every band -> zeros
 #pragma unroll
         for (int k = 0; k < MCH; ++k) nxt[k] = m_ld_entry(sc, kb + k);
 #pragma unroll
         for (int k = 0; k < MCH; ++k) {
-            // word k of the chunk sits in byt[k & 1]; produce the following word into the other buffer
+            // word w = c * MCH + k lives in byt[k % 3] (MCH is a multiple of 3); word w + 1 is complete,
+            // word w + 2 is produced now into the buffer word w - 1 left at the last barrier
+            LGMI_FETCH(q_, k % 3, 1)
 #if !(LGMI_ABL & 1)
-            if (k + 1 < MCH) { LGMI_PRODUCE((k + 1) & 1, cur[k + 1]) } else { LGMI_PRODUCE(0, nxt[0]) }
+            if (k + 2 < MCH) { LGMI_PRODUCE((k + 2) % 3, cur[k + 2]) } else { LGMI_PRODUCE((k + 2) % 3, nxt[k + 2 - MCH]) }
 #endif
-            LGMI_CONSUME_HALF(k & 1, 0)
-            LGMI_CONSUME_HALF(k & 1, 1)
+            LGMI_MFMA16(p_)
+            LGMI_FETCH(p_, (k + 1) % 3, 0)
+            LGMI_MFMA16(q_)
             // spread the producer's expansion VALU between the 32 MFMAs of the word (an MFMA holds vector
-            // issue for 8 of its 32 cycles) instead of one ~140-instruction run in front of them
+            // issue for 8 of its 32 cycles).  Pinning the LDS reads / writes as well measured slower.
 #pragma unroll
             for (int g_ = 0; g_ < 32; ++g_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
