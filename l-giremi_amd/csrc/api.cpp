@@ -553,6 +553,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     *out = nullptr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
     for (uint8_t r : prm->reserved) if (r) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
+    if (prm->n_shuffles > 0x7FFFFFFFu) return fail(LGMI_E_ARG, "n_shuffles must be < 2^31");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     Pool& pool = ctx->pool;

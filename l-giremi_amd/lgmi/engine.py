@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -65,6 +66,7 @@ def default_synth_spec(n_sites, n_reads, seed=20250808) -> _lib.SynthSpec:
 class DeviceBatch:
     def __init__(self, engine, handle):
         self.engine, self.handle = engine, handle
+        engine._children.add(self)
 
     def download(self) -> PackedBatch:
         b = _lib.Batch()
@@ -72,9 +74,9 @@ class DeviceBatch:
         return PackedBatch.from_struct(b)
 
     def free(self):
-        if self.handle:
-            self.engine.lib.lgmi_dbatch_free(self.handle)
-            self.handle = None
+        if self.handle and self.engine.handle and os.getpid() == self.engine.pid:
+            self.engine.lib.lgmi_dbatch_free(self.handle)   # the C object points into its context
+        self.handle = None
 
     def __del__(self):
         try:
@@ -86,6 +88,7 @@ class DeviceBatch:
 class DeviceResult:
     def __init__(self, engine, handle):
         self.engine, self.handle = engine, handle
+        engine._children.add(self)
 
     def info(self) -> dict:
         ri = _lib.RunInfo()
@@ -101,9 +104,9 @@ class DeviceResult:
             self.engine.lib.lgmi_result_free(C.byref(res))
 
     def free(self):
-        if self.handle:
+        if self.handle and self.engine.handle and os.getpid() == self.engine.pid:
             self.engine.lib.lgmi_dresult_free(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
@@ -125,6 +128,7 @@ class Engine:
         _lib.check(self.lib.lgmi_ctx_create(int(device), C.byref(h)))
         self.handle, self.device, self.pid = h, int(device), os.getpid()
         self.rank, self.world = 0, 1
+        self._children = weakref.WeakSet()     # resident batches / results: freed before the context goes
 
     def _alive(self):
         if not self.handle:
@@ -134,6 +138,8 @@ class Engine:
 
     def close(self):
         if self.handle and os.getpid() == self.pid:
+            for child in list(self._children):
+                child.free()
             self.lib.lgmi_ctx_destroy(self.handle)
         self.handle = None
 

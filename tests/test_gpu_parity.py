@@ -351,3 +351,50 @@ def test_auto_kernel_choice_uses_matrix_cores_on_large_dense_blocks(engine):
     assert_same_as_oracle(res, ora)
     dr.free()
     db.free()
+
+
+# ---------------------------------------------------------------- API robustness
+def test_bad_arguments_are_rejected(engine):
+    import ctypes as C
+    from lgmi import _lib
+    pb = random_batch(5, n_blocks=1)
+    st = pb.as_struct()
+    lib = engine.lib
+    # malformed batch: band beyond the block's reads
+    bad = pb.site_n_words.copy()
+    bad[0] = 10_000
+    st2 = pb.as_struct()
+    st2.site_n_words = bad.ctypes.data_as(_lib.u32p)
+    h = C.c_void_p()
+    assert lib.lgmi_batch_upload(engine.handle, C.byref(st2), C.byref(h)) == _lib.E_ARG
+    assert b'band' in lib.lgmi_last_error()
+    # positions must increase inside a block
+    pos = pb.site_pos.copy()
+    if len(pos) > 1:
+        pos[1] = pos[0]
+        st3 = pb.as_struct()
+        st3.site_pos = pos.ctypes.data_as(_lib.i64p)
+        assert lib.lgmi_batch_upload(engine.handle, C.byref(st3), C.byref(h)) == _lib.E_ARG
+    # reserved bytes / absurd shuffle counts
+    prm = lgmi_params(n_shuffles=2**31)
+    res, info = _lib.Result(), _lib.RunInfo()
+    assert lib.lgmi_run(engine.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)) == _lib.E_ARG
+    assert lib.lgmi_run(None, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)) == _lib.E_ARG
+
+
+def lgmi_params(**kw):
+    import lgmi
+    return lgmi.make_params(**kw)
+
+
+def test_engine_close_releases_resident_objects():
+    import lgmi
+    eng = lgmi.Engine(0)
+    db = eng.upload(random_batch(6, n_blocks=1))
+    dr = eng.run_device(db, min_common=2)
+    eng.close()                      # frees db and dr first
+    assert db.handle is None and dr.handle is None
+    db.free()
+    dr.free()                        # idempotent, no use-after-free
+    with pytest.raises(RuntimeError):
+        eng.run(random_batch(6, n_blocks=1))
