@@ -332,12 +332,23 @@ struct GState {
     uint32_t rem_total, rem_good, left;
 };
 
-__global__ __launch_bounds__(256) void k_perm_general(
+// Per-row state in LDS (one wave per workgroup, so __syncthreads() is a wave barrier):
+//   tab_thr[e]   inverse-CDF thresholds of the first real draw of a shuffle.  Its parameters are the same in every
+//                shuffle of the row, so it is drawn with one 32-bit word and a binary search instead of a
+//                rejection loop (window of at most FIRST_MAX values around the mode, else the HRUA path stays)
+//   next_s       the next shuffle index nobody has taken: a lane that finishes a shuffle takes the next one, so
+//                the wave drains together whatever the lanes' rejection counts were (the exceed count is a sum
+//                over shuffles and every shuffle has its own Philox stream: who runs which one does not matter)
+static const uint32_t FIRST_MAX = 2032;
+
+__global__ __launch_bounds__(64) void k_perm_general(
     const uint32_t* __restrict__ gen_list, const unsigned int* __restrict__ gen_count,
     const uint32_t* __restrict__ row_i, const uint32_t* __restrict__ row_j, const uint32_t* __restrict__ counts,
     const long long* __restrict__ G, const double* __restrict__ LF, uint32_t n_shuffles, uint64_t seed,
     double* __restrict__ out_p, uint32_t* __restrict__ out_exceed)
 {
+    __shared__ uint32_t tab_thr[FIRST_MAX];
+    __shared__ uint32_t next_s;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -368,6 +379,65 @@ __global__ __launch_bounds__(256) void k_perm_general(
         HrBase base0, base1;   // quotient caches for row-0 and row-1 draws (hits in the first column)
         base0.pop = 0u; base0.good = 0u; base0.d4 = 0.0; base0.cvar = 0.0; base0.c9 = 0.0;
         base1 = base0;
+
+        // ---- per-row threshold table of the first draw (wave-uniform control flow; integer prefix sums, so the
+        //      result does not depend on the order of the additions — see the CPU specification)
+        bool tab_ok = false;
+        uint32_t tab_klo = 0, tab_n = 0;
+        {
+            const uint32_t pop = N, good = R0, sample = C0;
+            const uint32_t m = sample < pop - sample ? sample : pop - sample;
+            if (m >= 10u) {
+                const uint32_t kmin = sample + good > pop ? sample + good - pop : 0u, kmax = good < sample ? good : sample;
+                const double pg = (double)good / (double)pop;
+                const double var = (double)sample * pg * (1.0 - pg) * (double)(pop - sample) / (double)(pop - 1u);
+                const double sd = det_sqrt(var + 1.0);
+                const uint32_t w = (uint32_t)floor(6.5 * sd) + 4u;
+                uint32_t mode = (uint32_t)(((unsigned long long)(sample + 1u) * (unsigned long long)(good + 1u)) /
+                                           ((unsigned long long)pop + 2ull));
+                if (mode < kmin) mode = kmin;
+                if (mode > kmax) mode = kmax;
+                tab_klo = mode - kmin > w ? mode - w : kmin;
+                const uint32_t khi = kmax - mode > w ? mode + w : kmax;
+                tab_n = khi - tab_klo + 1u;
+                tab_ok = tab_n <= FIRST_MAX;
+            }
+            __syncthreads();                           // the previous row's table reads are over
+            if (lane == 0) next_s = 64u;
+            if (tab_ok) {
+                double c0 = LF[good];
+                c0 += LF[pop - good];
+                c0 += LF[sample];
+                c0 += LF[pop - sample];
+                c0 -= LF[pop];
+                const uint32_t seg = (tab_n + 63u) / 64u;
+                const uint32_t e0 = lane * seg < tab_n ? lane * seg : tab_n;
+                const uint32_t e1 = e0 + seg < tab_n ? e0 + seg : tab_n;
+                unsigned long long loc = 0ull;         // running sum of pmf * 2^52 inside the lane's segment
+                for (uint32_t e = e0; e < e1; ++e) {
+                    const uint32_t k = tab_klo + e;
+                    double x = c0;
+                    x -= LF[k];
+                    x -= LF[good - k];
+                    x -= LF[sample - k];
+                    x -= LF[pop - good - sample + k];
+                    loc += (unsigned long long)(det_exp(x) * 4503599627370496.0);
+                    tab_thr[e] = (uint32_t)(loc >> 20);
+                }
+                unsigned long long incl = loc;         // inclusive scan of the segment totals over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned long long v = __shfl_up(incl, o);
+                    if (lane >= (uint32_t)o) incl += v;
+                }
+                const unsigned long long before = (incl - loc) >> 20;
+                for (uint32_t e = e0; e < e1; ++e) {
+                    const unsigned long long t = (unsigned long long)tab_thr[e] + before;
+                    tab_thr[e] = t >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+                }
+            }
+            __syncthreads();
+        }
 
         GState g;
         g.s = lane; g.phase = 3; g.call = 0; g.d = 0; g.ss = 0;
@@ -445,7 +515,7 @@ __global__ __launch_bounds__(256) void k_perm_general(
                             if ((g.d >> 1) == nc - 1) {              // the last column takes what is left
                                 g.ss += G[g.rr0] + G[g.rr1] + G[rr2];
                                 exceed += (g.ss >= sobs);
-                                g.s += 64u;
+                                g.s = atomicAdd(&next_s, 1u);
                                 if (g.s >= n_shuffles) { g.phase = 3; need_begin = false; break; }
                                 g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
                             }
@@ -460,6 +530,19 @@ __global__ __launch_bounds__(256) void k_perm_general(
                     if (sample == 0u || good == 0u) { z = 0u; have_z = true; continue; }
                     if (bad == 0u) { z = sample; have_z = true; continue; }
                     if (sample == pop) { z = good; have_z = true; continue; }
+                    if (tab_ok && g.d == 0) {
+                        // the first real draw of the shuffle: one 32-bit word, inverse CDF on the row's table
+                        const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+                        g.call++;
+                        uint32_t lo = 0u, hi = tab_n - 1u;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
+                        }
+                        z = tab_klo + lo;
+                        have_z = true;
+                        continue;
+                    }
                     g.m = sample < pop - sample ? sample : pop - sample;
                     if (g.m < 10u) {
                         g.rem_total = pop; g.rem_good = good; g.left = g.m;
@@ -471,9 +554,9 @@ __global__ __launch_bounds__(256) void k_perm_general(
                         g.mx = good < bad ? bad : good;
                         g.d6 = (double)g.m * hb.d4 + 0.5;
                         const double d7 = det_sqrt((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5);
-                        g.d8 = HRUA_D1 * d7 + HRUA_D2;
                         const uint32_t d9 = (uint32_t)floor((double)(g.m + 1u) * hb.c9);
                         g.d10 = LF[d9] + LF[g.mn - d9] + LF[g.m - d9] + LF[g.mx - g.m + d9];
+                        g.d8 = HRUA_D1 * d7 + HRUA_D2;
                         const double cap = (double)((g.m < g.mn ? g.m : g.mn) + 1u);
                         const double lim = floor(g.d6 + 16.0 * d7);
                         g.d11 = cap < lim ? cap : lim;
@@ -500,8 +583,9 @@ void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const u
     if (!n_rows) return;
     hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, n_rows, out_i, out_j,
                        counts, G, LF, n_shuffles, seed, out_p, out_exceed, gen_list, gen_count);
-    // a fixed grid (8 blocks per CU) whose waves stride over the queued rows
-    hipLaunchKernelGGL(k_perm_general, dim3(2048), dim3(256), 0, st, gen_list, gen_count, out_i, out_j, counts, G, LF,
+    // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
+    // stride over the queued rows
+    hipLaunchKernelGGL(k_perm_general, dim3(256 * 16), dim3(64), 0, st, gen_list, gen_count, out_i, out_j, counts, G, LF,
                        n_shuffles, seed, out_p, out_exceed);
 }
 

@@ -158,8 +158,69 @@ static void next_pair(gen_stream* g, double* u0, double* u1)
 static const double HRUA_D1 = 1.7155277699214135;   /* 2*sqrt(2/e)     */
 static const double HRUA_D2 = 0.8989161620588988;   /* 3 - 2*sqrt(3/e) */
 
+/* The first draw of a shuffle that is not trivially determined has the same parameters in every shuffle
+ * of a row.  When its distribution fits a window of at most FIRST_MAX values (mode +- (6.5 sd + 4)) it is
+ * drawn by inverse CDF instead of rejection: one 32-bit Philox word u, result = the smallest k of the window
+ * with u < thr[k - klo] (the last k of the window when there is none: the window misses < 1e-10 of the mass).
+ * The thresholds are integer prefix sums, so they do not depend on the order of the additions:
+ *     q[e]   = trunc(pmf(klo + e) * 2^52)                                 (u64)
+ *     the window is cut into 64 contiguous segments of seg = ceil(n / 64) entries (one per GPU lane);
+ *     thr[e] = min(2^32 - 1, (sum of q over the entries of e's segment up to e) >> 20
+ *                            + (sum of q over all earlier segments) >> 20)
+ * i.e. floor(2^32 * CDF) to within 2 units (the two shifts are taken separately so that a lane only has to
+ * keep 32 bits per entry). */
+#define FIRST_MAX 2032
+typedef struct { int valid; uint32_t pop, good, sample, klo, n; uint32_t thr[FIRST_MAX]; } first_table;
+
+static void first_table_build(const perm_tables* t, uint32_t pop, uint32_t good, uint32_t sample, first_table* ft)
+{
+    const uint32_t m = sample < pop - sample ? sample : pop - sample;
+    const uint32_t kmin = sample + good > pop ? sample + good - pop : 0, kmax = good < sample ? good : sample;
+    double c0, var, sd, p;
+    uint32_t mode, w, khi, seg, e, l;
+    uint64_t earlier = 0;
+    ft->valid = 0;
+    if (sample == 0 || good == 0 || good == pop || sample == pop || m < 10) return;
+    p = (double)good / (double)pop;
+    var = (double)sample * p * (1.0 - p) * (double)(pop - sample) / (double)(pop - 1);
+    sd = lgo_det_sqrt(var + 1.0);
+    w = (uint32_t)floor(6.5 * sd) + 4u;
+    mode = (uint32_t)(((uint64_t)(sample + 1) * (uint64_t)(good + 1)) / ((uint64_t)pop + 2));
+    if (mode < kmin) mode = kmin;
+    if (mode > kmax) mode = kmax;
+    ft->klo = mode - kmin > w ? mode - w : kmin;
+    khi = kmax - mode > w ? mode + w : kmax;
+    ft->n = khi - ft->klo + 1;
+    if (ft->n > FIRST_MAX) return;
+    c0 = t->LF[good];
+    c0 += t->LF[pop - good];
+    c0 += t->LF[sample];
+    c0 += t->LF[pop - sample];
+    c0 -= t->LF[pop];
+    seg = (ft->n + 63u) / 64u;
+    for (l = 0; l < 64; ++l) {
+        uint64_t loc = 0;
+        for (e = l * seg; e < ft->n && e < (l + 1) * seg; ++e) {
+            const uint32_t k = ft->klo + e;
+            uint64_t thr;
+            double x = c0;
+            x -= t->LF[k];
+            x -= t->LF[good - k];
+            x -= t->LF[sample - k];
+            x -= t->LF[pop - good - sample + k];
+            loc += (uint64_t)(lgo_det_exp(x) * 4503599627370496.0);
+            thr = (uint64_t)(uint32_t)(loc >> 20) + (earlier >> 20);
+            ft->thr[e] = thr >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
+        }
+        earlier += loc;
+    }
+    ft->pop = pop; ft->good = good; ft->sample = sample;
+    ft->valid = 1;
+}
+
 /* number of "good" items in `sample` draws without replacement from pop = good + bad */
-static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint32_t sample, gen_stream* g)
+static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint32_t sample, gen_stream* g,
+                        const first_table* ft)
 {
     const uint32_t bad = pop - good;
     const uint32_t m = sample < pop - sample ? sample : pop - sample;
@@ -167,6 +228,18 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
     if (sample == 0 || good == 0) return 0;
     if (bad == 0) return sample;
     if (sample == pop) return good;
+    if (ft && ft->valid && g->call == 0 && ft->pop == pop && ft->good == good && ft->sample == sample) {
+        /* the first real draw of the shuffle: inverse CDF on the row's table */
+        uint32_t lo = 0, hi = ft->n - 1, u;
+        philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
+        g->call++;
+        u = g->buf[0];
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (u < ft->thr[mid]) hi = mid; else lo = mid + 1;
+        }
+        return ft->klo + lo;
+    }
     if (m < 10) {
         /* urn scheme on the smaller of the sample and its complement */
         uint32_t rem_total = pop, rem_good = good, left = m;
@@ -389,6 +462,8 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
     }
     {
         const int64_t sobs = stat9(t, T);
+        first_table ft;
+        first_table_build(t, N, R[nzr[0]], C[nzc[0]], &ft);   /* the first non-empty row and column */
         for (s = 0; s < n_shuffles; ++s) {
             gen_stream g;
             uint32_t rr[3] = {R[0], R[1], R[2]}, Ts[9], pop_all = N;
@@ -397,7 +472,7 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
                 /* column b: distribute C[b] reads over the rows' remaining capacities */
                 uint32_t cc = C[b], pop = pop_all;
                 for (a = 0; a < 3; ++a) {
-                    const uint32_t x = hg_draw(t, pop, rr[a], cc, &g);
+                    const uint32_t x = hg_draw(t, pop, rr[a], cc, &g, &ft);
                     Ts[3 * a + b] = x;
                     pop -= rr[a];
                     cc -= x;
@@ -440,18 +515,39 @@ int lgo_perm_rows(uint64_t n_rows, const uint32_t* row_i, const uint32_t* row_j,
 }
 
 /* ---- hooks for the statistical tests of this specification (tests/test_perm_oracle.py) ---- */
-int lgo_hg_draw_many(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed, uint32_t n, uint32_t* out)
+int lgo_hg_draw_many2(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed, uint32_t n, uint32_t* out, int use_table)
 {
     perm_tables t;
+    first_table ft;
     uint32_t i;
     if (tables_init(&t, pop)) return -1;
+    ft.valid = 0;
+    if (use_table) first_table_build(&t, pop, good, sample, &ft);
+    if (use_table && !ft.valid) { free(t.G); free(t.LF); return -2; }
     for (i = 0; i < n; ++i) {
         gen_stream g;
         g.c0 = i; g.c1 = 1; g.c2 = 2; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0;
-        out[i] = hg_draw(&t, pop, good, sample, &g);
+        out[i] = hg_draw(&t, pop, good, sample, &g, use_table ? &ft : NULL);
     }
     free(t.G); free(t.LF);
     return 0;
+}
+
+/* the threshold table of the first draw: returns the window length (0: no table), klo and thr[] */
+int lgo_first_table(uint32_t pop, uint32_t good, uint32_t sample, uint32_t* klo, uint32_t* thr)
+{
+    perm_tables t;
+    first_table ft;
+    int n = 0;
+    if (tables_init(&t, pop)) return -1;
+    first_table_build(&t, pop, good, sample, &ft);
+    if (ft.valid) {
+        n = (int)ft.n;
+        *klo = ft.klo;
+        memcpy(thr, ft.thr, sizeof(uint32_t) * ft.n);
+    }
+    free(t.G); free(t.LF);
+    return n;
 }
 
 int lgo_perm_ptail(const uint32_t T[9], double* ptail)
@@ -464,4 +560,9 @@ int lgo_perm_ptail(const uint32_t T[9], double* ptail)
     (void)perm_one(&t, T, 0, 1, 0, 0, ptail);
     free(t.G); free(t.LF);
     return 0;
+}
+
+int lgo_hg_draw_many(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed, uint32_t n, uint32_t* out)
+{
+    return lgo_hg_draw_many2(pop, good, sample, seed, n, out, 0);
 }

@@ -229,15 +229,18 @@ def test_permutation_p_matches_cpu_specification(engine, seed):
     assert_perm_same(res, ora, S)
 
 
-def test_permutation_p_large_counts_and_tri_sites(engine):
-    """thousands of common reads: HRUA draws, exact-tail sums in both the centre and the tail form"""
+@pytest.mark.parametrize('n_reads,S', [(40000, 64), (200000, 150), (420000, 70)])
+def test_permutation_p_large_counts_and_tri_sites(engine, n_reads, S):
+    """thousands of common reads: HRUA draws, exact-tail sums in both the centre and the tail form; the first
+    draw of a general table comes from the threshold table (windows of ~660 and ~1460 entries) or, at 420k
+    reads, from the rejection sampler because the window would not fit; S > 64 makes lanes take further
+    shuffles from the shared counter"""
     import lgmi
     from oracle import c_oracle
-    spec = lgmi.default_synth_spec(60, 40000, seed=5)
+    spec = lgmi.default_synth_spec(60 if n_reads == 40000 else 36, n_reads, seed=5)
     spec.tri_per_1024 = 250
     db = engine.synth_dense(spec)
     pb = db.download()
-    S = 64
     res = engine.run_device(db, min_common=6, het_only=True, n_shuffles=S, seed=1234).fetch()
     ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=S, seed=1234)
     assert_perm_same(res, ora, S)

@@ -19,6 +19,10 @@ def lib():
     lib = c_oracle.load()
     lib.lgo_hg_draw_many.restype = C.c_int
     lib.lgo_hg_draw_many.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, u32p]
+    lib.lgo_hg_draw_many2.restype = C.c_int
+    lib.lgo_hg_draw_many2.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_int]
+    lib.lgo_first_table.restype = C.c_int
+    lib.lgo_first_table.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     lib.lgo_perm_ptail.restype = C.c_int
     lib.lgo_perm_ptail.argtypes = [u32p, f64p]
     return lib
@@ -32,11 +36,52 @@ HG_CASES = [  # (pop, good, sample): urn path, HRUA path, complements, good > ba
 ]
 
 
-@pytest.mark.parametrize('pop,good,sample', HG_CASES)
-def test_hypergeometric_sampler_matches_scipy(lib, pop, good, sample):
-    n = 40000
+def _draws(lib, pop, good, sample, n, use_table):
     out = np.zeros(n, np.uint32)
-    assert lib.lgo_hg_draw_many(pop, good, sample, 1234 + pop, n, out.ctypes.data_as(u32p)) == 0
+    rc = lib.lgo_hg_draw_many2(pop, good, sample, 1234 + pop, n, out.ctypes.data_as(u32p), int(use_table))
+    return rc, out
+
+
+# first-draw threshold table: windows of a few to ~1500 entries, clipped at either support end, and too wide
+TABLE_CASES = [(50, 25, 25), (300, 40, 150), (300, 260, 150), (5000, 2500, 2500), (5000, 100, 4000),
+               (5000, 4900, 1000), (160000, 80000, 48000), (200000, 100000, 100000), (200000, 66000, 120000),
+               (160000, 8000, 150000), (2000, 1990, 1000), (64, 54, 54), (21, 11, 10)]
+
+
+@pytest.mark.parametrize('pop,good,sample', TABLE_CASES)
+def test_first_draw_thresholds_are_the_scaled_cdf(lib, pop, good, sample):
+    thr = np.zeros(4096, np.uint32)
+    klo = C.c_uint32(0)
+    n = lib.lgo_first_table(pop, good, sample, C.byref(klo), thr.ctypes.data_as(u32p))
+    assert 0 < n <= 2032
+    ks = klo.value + np.arange(n)
+    lo, hi = max(0, sample + good - pop), min(good, sample)
+    assert ks[0] >= lo and ks[-1] <= hi
+    cdf = stats.hypergeom.cdf(ks, pop, good, sample)
+    below = stats.hypergeom.cdf(klo.value - 1, pop, good, sample) if klo.value > lo else 0.0
+    # the window drops < 1e-10 of the mass on either side; inside it thr = floor(2^32 * windowed CDF) +- 2
+    assert below < 1e-10 and 1.0 - cdf[-1] < 1e-10
+    want = (cdf - below) * 2.0 ** 32
+    assert np.all(np.diff(thr[:n].astype(np.int64)) >= 0)
+    assert np.max(np.abs(thr[:n].astype(np.float64) - np.minimum(want, 2.0 ** 32 - 1))) < 3.0 + 2.0 ** 32 * 1e-11
+
+
+def test_first_draw_table_limits(lib):
+    thr = np.zeros(4096, np.uint32)
+    klo = C.c_uint32(0)
+    for pop, good, sample in [(1000, 3, 9), (20, 7, 5), (400000, 200000, 200000), (1000, 0, 10), (1000, 1000, 10)]:
+        # urn-sized, trivially determined, or wider than FIRST_MAX: no table, the rejection path stays
+        assert lib.lgo_first_table(pop, good, sample, C.byref(klo), thr.ctypes.data_as(u32p)) == 0
+
+
+@pytest.mark.parametrize('use_table', [False, True])
+@pytest.mark.parametrize('pop,good,sample', HG_CASES)
+def test_hypergeometric_sampler_matches_scipy(lib, pop, good, sample, use_table):
+    n = 40000
+    rc, out = _draws(lib, pop, good, sample, n, use_table)
+    if use_table and rc == -2:
+        pytest.skip('no threshold table for these parameters')
+    assert rc == 0
     lo, hi = max(0, sample + good - pop), min(good, sample)
     assert out.min() >= lo and out.max() <= hi
     ks = np.arange(lo, hi + 1)
