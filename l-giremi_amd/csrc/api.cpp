@@ -309,7 +309,9 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     db->d.n_pairs16 = off;
     if ((rc = dev_copy_new(&db->d.d_cols, db->cols.data(), db->cols.size(), st))) return rc;
     if ((rc = dev_copy_new(&d_pseudo, db->pseudo_site.data(), db->pseudo_site.size(), st))) return rc;
-    if (off) HIPCHK(hipMalloc((void**)&db->d.d_cplanes, off * sizeof(ulonglong2)));
+    // one all-zero entry after the last column: k_count_mfma reads it for words outside a column's band
+    HIPCHK(hipMalloc((void**)&db->d.d_cplanes, (off + 1) * sizeof(ulonglong2)));
+    HIPCHK(hipMemsetAsync(db->d.d_cplanes + off, 0, sizeof(ulonglong2), st));
     launch_prep_cols(st, (uint32_t)db->d.n_cols, (uint32_t)ns, db->d.d_cols, d_pseudo, d_poff, d_planes, db->d.d_cplanes);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -361,7 +363,8 @@ extern "C" int lgmi_synth_dense(lgmi_ctx* ctx, const lgmi_synth_spec* sp, lgmi_d
     if ((rc = dev_copy_new(&db->d.d_type, db->type.data(), ns, st))) return rc;
     if ((rc = dev_copy_new(&db->d.d_tri, db->tri.data(), ns, st))) return rc;
     if ((rc = dev_copy_new(&db->d.d_cols, db->cols.data(), db->cols.size(), st))) return rc;
-    HIPCHK(hipMalloc((void**)&db->d.d_cplanes, db->d.n_pairs16 * sizeof(ulonglong2)));
+    HIPCHK(hipMalloc((void**)&db->d.d_cplanes, (db->d.n_pairs16 + 1) * sizeof(ulonglong2)));
+    HIPCHK(hipMemsetAsync(db->d.d_cplanes + db->d.n_pairs16, 0, sizeof(ulonglong2), st));
     uint32_t* d_depth = nullptr; uint32_t* d_pos_ = nullptr;
     struct Tmp { uint32_t** a; uint32_t** b; ~Tmp() { (void)hipFree(*a); (void)hipFree(*b); } } tmp{&d_depth, &d_pos_};
     HIPCHK(hipMalloc((void**)&d_depth, (size_t)ns * 3 * sizeof(uint32_t)));
@@ -481,6 +484,7 @@ static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
         bool use_mfma = bp.nx >= 96 && bp.ny >= 96 && block_words >= 32;
         if (count_kernel_choice == 1) use_mfma = false;
         if (count_kernel_choice == 2) use_mfma = true;
+        if (db->block_n_reads[b] >= (1u << 26)) use_mfma = false;   // its accumulators hold 64 * count in 32 bits
         const uint32_t edge = use_mfma ? 128u : (uint32_t)TILE;
         std::vector<Tile>& out_tiles = use_mfma ? pl.mtiles : pl.tiles;
         // tiles: union band per `edge`-column group of each list
@@ -619,7 +623,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
 
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     launch_count_mfma(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols,
-                      db->d.d_cplanes, sN, sR, sC, sA);
+                      db->d.d_cplanes, db->d.d_cplanes + db->d.n_pairs16, sN, sR, sC, sA);
     launch_count(st, (uint32_t)pl.tiles.size(), d_tiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
                  sN, sR, sC, sA);
     HIPCHK(hipGetLastError());

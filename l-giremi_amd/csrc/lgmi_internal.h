@@ -80,7 +80,8 @@ void launch_count(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const Blo
 // count_mfma.hip (128 x 128 tiles on the int8 matrix cores; same slot planes)
 void launch_count_mfma(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
                        const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
-                       const ulonglong2* cplanes, uint32_t* sN, uint32_t* sR, uint32_t* sC, uint32_t* sA);
+                       const ulonglong2* cplanes, const ulonglong2* zero_entry, uint32_t* sN, uint32_t* sR,
+                       uint32_t* sC, uint32_t* sA);
 
 // emit.hip
 struct EmitArgs {
