@@ -97,63 +97,86 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0;
 
-#define LGMI_MFMA16(ac0, aa0, ac1, aa1, bc0, ba0, bc1, ba1)                                           \
-    LGMI_MFMA(acc[0][0][0], ac0, bc0); LGMI_MFMA(acc[0][0][1], aa0, bc0);                               \
-    LGMI_MFMA(acc[0][0][2], ac0, ba0); LGMI_MFMA(acc[0][0][3], aa0, ba0);                               \
-    LGMI_MFMA(acc[0][1][0], ac0, bc1); LGMI_MFMA(acc[0][1][1], aa0, bc1);                               \
-    LGMI_MFMA(acc[0][1][2], ac0, ba1); LGMI_MFMA(acc[0][1][3], aa0, ba1);                               \
-    LGMI_MFMA(acc[1][0][0], ac1, bc0); LGMI_MFMA(acc[1][0][1], aa1, bc0);                               \
-    LGMI_MFMA(acc[1][0][2], ac1, ba0); LGMI_MFMA(acc[1][0][3], aa1, ba0);                               \
-    LGMI_MFMA(acc[1][1][0], ac1, bc1); LGMI_MFMA(acc[1][1][1], aa1, bc1);                               \
-    LGMI_MFMA(acc[1][1][2], ac1, ba1); LGMI_MFMA(acc[1][1][3], aa1, ba1);
-    // raw entries of one 4-word step: [column][word of this lane's half] = (C lo, C hi, A lo, A hi)
-#define LGMI_LOAD(E, KW)                                                                              \
-    E[0][0] = m_ld_entry(cx0, (KW), zero_entry); E[0][1] = m_ld_entry(cx0, (KW) + 1u, zero_entry);                              \
-    E[1][0] = m_ld_entry(cx1, (KW), zero_entry); E[1][1] = m_ld_entry(cx1, (KW) + 1u, zero_entry);                              \
-    E[2][0] = m_ld_entry(cy0, (KW), zero_entry); E[2][1] = m_ld_entry(cy0, (KW) + 1u, zero_entry);                              \
-    E[3][0] = m_ld_entry(cy1, (KW), zero_entry); E[3][1] = m_ld_entry(cy1, (KW) + 1u, zero_entry);
+    // operand set of one k-step: x fragments (C, A of column group 0, C, A of group 1), y fragments likewise
+    struct Ops { v4i a[4], b[4]; };
+    // raw words of one 256-read step: x[c] / y[c] = plane quads (C0, A0, C1, A1) of this lane's 128-read half;
+    // y is kept with the bits of every byte reversed
+    struct Raw { v4i x[4], y[4]; };
+
+#define LGMI_MFMA16(O)                                                                                \
+    LGMI_MFMA(acc[0][0][0], O.a[0], O.b[0]); LGMI_MFMA(acc[0][0][1], O.a[1], O.b[0]);                   \
+    LGMI_MFMA(acc[0][0][2], O.a[0], O.b[1]); LGMI_MFMA(acc[0][0][3], O.a[1], O.b[1]);                   \
+    LGMI_MFMA(acc[0][1][0], O.a[0], O.b[2]); LGMI_MFMA(acc[0][1][1], O.a[1], O.b[2]);                   \
+    LGMI_MFMA(acc[0][1][2], O.a[0], O.b[3]); LGMI_MFMA(acc[0][1][3], O.a[1], O.b[3]);                   \
+    LGMI_MFMA(acc[1][0][0], O.a[2], O.b[0]); LGMI_MFMA(acc[1][0][1], O.a[3], O.b[0]);                   \
+    LGMI_MFMA(acc[1][0][2], O.a[2], O.b[1]); LGMI_MFMA(acc[1][0][3], O.a[3], O.b[1]);                   \
+    LGMI_MFMA(acc[1][1][0], O.a[2], O.b[2]); LGMI_MFMA(acc[1][1][1], O.a[3], O.b[2]);                   \
+    LGMI_MFMA(acc[1][1][2], O.a[2], O.b[3]); LGMI_MFMA(acc[1][1][3], O.a[3], O.b[3]);
+    // operands of bit I (0..6) of every byte: x * 2^I and y * 2^(6 - I)
+#define LGMI_ANDS(O, X, YR, I)                                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+        O.a[q_] = X[q_] & (0x01010101 << (I));                                                          \
+        O.b[q_] = YR[q_] & (0x01010101 << (6 - (I)));                                                   \
+    }
+    // the two words of this lane's half of column C at step word KW -> plane quads (C, A)
+#define LGMI_LOAD2(QC, QA, C, KW)                                                                     \
+    {                                                                                                 \
+        const uint4 e0_ = m_ld_entry(C, (KW), zero_entry), e1_ = m_ld_entry(C, (KW) + 1u, zero_entry);    \
+        QC = v4i{(int)e0_.x, (int)e0_.y, (int)e1_.x, (int)e1_.y};                                       \
+        QA = v4i{(int)e0_.z, (int)e0_.w, (int)e1_.z, (int)e1_.w};                                       \
+    }
+    // one slot = the 16 MFMAs of a k-step with V VALU operations of the next steps' preparation between them
+    // (an MFMA holds vector issue for 8 of its 32 cycles); nothing moves across a slot boundary
+#define LGMI_SLOT_END(V)                                                                              \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+        __builtin_amdgcn_sched_group_barrier(0x002, (V), 0);                                            \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+    // One 256-read step: k-steps for bits 0..6 then bit 7 of the CUR words; meanwhile the NXT words are loaded
+    // (slots 0, 1), bit-reversed (slot 5) and turned into the first operands of the next step (slot 7).
+    // On entry P holds the operands of bit 0 of CUR and YR = (CUR.y >> 1) & 0x7F7F7F7F; on exit the same for NXT.
+#define LGMI_STEP(CUR, NXT, KW)                                                                       \
+    LGMI_LOAD2(NXT.x[0], NXT.x[1], cx0, (KW)) LGMI_LOAD2(NXT.x[2], NXT.x[3], cx1, (KW))                 \
+    LGMI_ANDS(Q, CUR.x, yr, 1) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                          \
+    LGMI_LOAD2(NXT.y[0], NXT.y[1], cy0, (KW)) LGMI_LOAD2(NXT.y[2], NXT.y[3], cy1, (KW))                 \
+    LGMI_ANDS(P, CUR.x, yr, 2) LGMI_MFMA16(Q) LGMI_SLOT_END(4)                                          \
+    LGMI_ANDS(Q, CUR.x, yr, 3) LGMI_MFMA16(P) LGMI_SLOT_END(2)                                          \
+    LGMI_ANDS(P, CUR.x, yr, 4) LGMI_MFMA16(Q) LGMI_SLOT_END(2)                                          \
+    LGMI_ANDS(Q, CUR.x, yr, 5) LGMI_MFMA16(P) LGMI_SLOT_END(2)                                          \
+    LGMI_ANDS(P, CUR.x, yr, 6) LGMI_MFMA16(Q)                                                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                    \
+        NXT.y[q_] = v4i{(int)rev_in_bytes((uint32_t)NXT.y[q_].x), (int)rev_in_bytes((uint32_t)NXT.y[q_].y),  \
+                        (int)rev_in_bytes((uint32_t)NXT.y[q_].z), (int)rev_in_bytes((uint32_t)NXT.y[q_].w)}; \
+    LGMI_SLOT_END(4)                                                                                  \
+    /* bit 7 of every byte: x * 64 (shifted down one place), y * 1 (bit 0 of the reversed form) */       \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+        Q.a[q_] = (CUR.x[q_] >> 1) & 0x40404040;                                                        \
+        Q.b[q_] = CUR.y[q_] & 0x01010101;                                                               \
+    }                                                                                                 \
+    LGMI_MFMA16(P) LGMI_SLOT_END(3)                                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) yr[q_] = (NXT.y[q_] >> 1) & 0x7F7F7F7F;            \
+    LGMI_ANDS(P, NXT.x, yr, 0) LGMI_MFMA16(Q) LGMI_SLOT_END(4)
 
     const uint32_t n_words = t.k1 - t.k0;
-    const uint32_t n_step = (n_words + 3u) / 4u;          // words past k1 are outside every band -> zeros
-    uint4 cur[4][2], nxt[4][2];
-    LGMI_LOAD(cur, t.k0 + 2u * lh)
-    for (uint32_t s = 0; s < n_step; ++s) {
-        LGMI_LOAD(nxt, t.k0 + 4u * (s + 1u) + 2u * lh)
-        // plane quads: 128 reads of this lane's half
-        const v4i xc0 = {(int)cur[0][0].x, (int)cur[0][0].y, (int)cur[0][1].x, (int)cur[0][1].y};
-        const v4i xa0 = {(int)cur[0][0].z, (int)cur[0][0].w, (int)cur[0][1].z, (int)cur[0][1].w};
-        const v4i xc1 = {(int)cur[1][0].x, (int)cur[1][0].y, (int)cur[1][1].x, (int)cur[1][1].y};
-        const v4i xa1 = {(int)cur[1][0].z, (int)cur[1][0].w, (int)cur[1][1].z, (int)cur[1][1].w};
-        v4i yc0 = {(int)rev_in_bytes(cur[2][0].x), (int)rev_in_bytes(cur[2][0].y), (int)rev_in_bytes(cur[2][1].x), (int)rev_in_bytes(cur[2][1].y)};
-        v4i ya0 = {(int)rev_in_bytes(cur[2][0].z), (int)rev_in_bytes(cur[2][0].w), (int)rev_in_bytes(cur[2][1].z), (int)rev_in_bytes(cur[2][1].w)};
-        v4i yc1 = {(int)rev_in_bytes(cur[3][0].x), (int)rev_in_bytes(cur[3][0].y), (int)rev_in_bytes(cur[3][1].x), (int)rev_in_bytes(cur[3][1].y)};
-        v4i ya1 = {(int)rev_in_bytes(cur[3][0].z), (int)rev_in_bytes(cur[3][0].w), (int)rev_in_bytes(cur[3][1].z), (int)rev_in_bytes(cur[3][1].w)};
-        {
-            // bit 7 of every byte: x * 64 (shifted down one place), y * 1 (bit 0 of the reversed form)
-            const v4i a0 = (xc0 >> 1) & 0x40404040, a1 = (xa0 >> 1) & 0x40404040;
-            const v4i a2 = (xc1 >> 1) & 0x40404040, a3 = (xa1 >> 1) & 0x40404040;
-            const v4i b0 = yc0 & 0x01010101, b1 = ya0 & 0x01010101, b2 = yc1 & 0x01010101, b3 = ya1 & 0x01010101;
-            LGMI_MFMA16(a0, a1, a2, a3, b0, b1, b2, b3)
-        }
-        // reversed form shifted down: read bit i (0..6) now sits at bit 6 - i of its byte
-        yc0 = (yc0 >> 1) & 0x7F7F7F7F; ya0 = (ya0 >> 1) & 0x7F7F7F7F;
-        yc1 = (yc1 >> 1) & 0x7F7F7F7F; ya1 = (ya1 >> 1) & 0x7F7F7F7F;
+    const uint32_t n_pair = (n_words + 7u) / 8u;          // steps go in pairs; words past k1 are outside every band -> zeros
+    Raw ra, rb;
+    Ops P, Q;
+    v4i yr[4];
+    uint32_t kw = t.k0 + 2u * lh;                         // first of this lane's two words of the step
+    LGMI_LOAD2(ra.x[0], ra.x[1], cx0, kw) LGMI_LOAD2(ra.x[2], ra.x[3], cx1, kw)
+    LGMI_LOAD2(ra.y[0], ra.y[1], cy0, kw) LGMI_LOAD2(ra.y[2], ra.y[3], cy1, kw)
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int mx = 0x01010101 << i, my = 0x01010101 << (6 - i);
-            const v4i a0 = xc0 & mx, a1 = xa0 & mx, a2 = xc1 & mx, a3 = xa1 & mx;
-            const v4i b0 = yc0 & my, b1 = ya0 & my, b2 = yc1 & my, b3 = ya1 & my;
-            LGMI_MFMA16(a0, a1, a2, a3, b0, b1, b2, b3)
-        }
-        // spread the operand VALU between the 128 MFMAs of the step (an MFMA holds vector issue for 8 of its
-        // 32 cycles)
-#pragma unroll
-        for (int g_ = 0; g_ < 128; ++g_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { cur[c][0] = nxt[c][0]; cur[c][1] = nxt[c][1]; }
+    for (int q_ = 0; q_ < 4; ++q_) {
+        ra.y[q_] = v4i{(int)rev_in_bytes((uint32_t)ra.y[q_].x), (int)rev_in_bytes((uint32_t)ra.y[q_].y),
+                       (int)rev_in_bytes((uint32_t)ra.y[q_].z), (int)rev_in_bytes((uint32_t)ra.y[q_].w)};
+        yr[q_] = (ra.y[q_] >> 1) & 0x7F7F7F7F;
+    }
+    LGMI_ANDS(P, ra.x, yr, 0)
+    for (uint32_t s = 0; s < n_pair; ++s) {
+        LGMI_STEP(ra, rb, kw + 4u)
+        LGMI_STEP(rb, ra, kw + 8u)
+        kw += 8u;
     }
 
     // ---- epilogue: reg r of lane l is (x row (r&3) + 8 (r>>2) + 4 (l>>5), y col l&31) of its 32 x 32 tile;
