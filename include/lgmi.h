@@ -97,7 +97,7 @@ typedef struct lgmi_batch {
 
 typedef struct lgmi_params {
     uint32_t min_common;   /* mutual_information.py:19 (library default 5, CLI 6) */
-    uint32_t n_shuffles;   /* S; 0 = no permutation p (row_p = NaN)               */
+    uint32_t n_shuffles;   /* S <= 2^24; 0 = no permutation p (row_p = NaN)       */
     uint64_t seed;         /* Philox key for the permutation draws                */
     uint8_t  het_only;     /* 1: only pairs with >=1 het_snp side (mismatch.py:392-396);
                               0: all P(P-1)/2 pairs (mutual_information.py:12)   */

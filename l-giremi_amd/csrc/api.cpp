@@ -557,7 +557,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     *out = nullptr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
     for (uint8_t r : prm->reserved) if (r) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
-    if (prm->n_shuffles > 0x7FFFFFFFu) return fail(LGMI_E_ARG, "n_shuffles must be < 2^31");
+    if (prm->n_shuffles > (1u << 24)) return fail(LGMI_E_ARG, "n_shuffles must be <= 2^24");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     Pool& pool = ctx->pool;
@@ -566,7 +566,8 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     const bool want_counts = prm->emit_counts != 0;
     int rc;
 
-    if (want_p && (rc = ensure_perm_tables(ctx, db->max_reads))) return rc;   // first use only
+    // the log-factorial table also serves the binomial draw of the 2 x 2 path: LF[0 .. n_shuffles]
+    if (want_p && (rc = ensure_perm_tables(ctx, std::max(db->max_reads, prm->n_shuffles)))) return rc;   // first use only
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     Plan pl;
     build_plan(db, prm->het_only != 0, pl);

@@ -196,6 +196,63 @@ __device__ __forceinline__ void centre_sum_wave(const double* __restrict__ LF, c
     }
 }
 
+// The number of "as or more extreme" shuffles of a 2 x 2 table is Binomial(n_shuffles, P_tail): one binomial
+// variate instead of n_shuffles Bernoulli trials (the CPU specification is binom_draw in
+// oracle/lgmi_perm_oracle.c).  thr = trunc(P * 2^32).  n p < 10: sequential inversion (BINV), otherwise
+// Hoermann's transformed rejection (BTRS) tested against the exact log-factorials.  One lane per row.
+__device__ uint32_t binom_draw(const double* __restrict__ LF, uint32_t n, unsigned long long thr, uint32_t ci,
+                               uint32_t cj, uint32_t k0, uint32_t k1) {
+    if (thr == 0ull || n == 0u) return 0u;
+    if (thr >= 4294967296ull) return n;
+    const bool flip = thr > 2147483648ull;
+    const uint32_t tt = flip ? (uint32_t)(4294967296ull - thr) : (uint32_t)thr;
+    const double p = (double)tt * 2.3283064365386963e-10;
+    const double q = 1.0 - p;
+    const double np = (double)n * p;
+    uint32_t call = 0u, k = 0u;
+    if (np < 10.0) {
+        const double qn = det_exp((double)n * det_log(q));
+        const double lim = np + 10.0 * det_sqrt(np * q + 1.0);
+        const uint32_t bound = lim < (double)n ? (uint32_t)lim : n;
+        for (;;) {
+            const U4 o = philox4x32_10(call++, ci, cj, TAG_PERM2X2, k0, k1);
+            double u = ((double)(((unsigned long long)o.x << 20) | (unsigned long long)(o.y >> 12)) + 0.5) * 2.220446049250313e-16;
+            double px = qn;
+            uint32_t x = 0u;
+            while (u > px && x <= bound) {
+                ++x;
+                u -= px;
+                px = ((double)(n - x + 1u) * p * px) / ((double)x * q);
+            }
+            if (x <= bound) { k = x; break; }
+        }
+    } else {
+        const double spq = det_sqrt(np * q);
+        const double b = 1.15 + 2.53 * spq;
+        const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+        const double c = np + 0.5;
+        const double vr = 0.92 - 4.2 / b;
+        const double alpha = (2.83 + 5.1 / b) * spq;
+        const uint32_t m = (uint32_t)floor((double)(n + 1u) * p);
+        const double lr = det_log(p / q);
+        const double hm = LF[m] + LF[n - m];
+        for (;;) {
+            const U4 o = philox4x32_10(call++, ci, cj, TAG_PERM2X2, k0, k1);
+            const double u = ((double)o.x + 0.5) * 2.3283064365386963e-10 - 0.5;
+            double v = ((double)o.y + 0.5) * 2.3283064365386963e-10;
+            const double us = 0.5 - fabs(u);
+            const double kf = floor((2.0 * a / us + b) * u + c);
+            if (kf < 0.0 || kf > (double)n) continue;
+            k = (uint32_t)kf;
+            if (us >= 0.07 && v <= vr) break;
+            v = v * alpha / (a / (us * us) + b);
+            const double h = hm - LF[k] - LF[n - k] + ((double)k - (double)m) * lr;
+            if (v <= det_exp(h)) break;
+        }
+    }
+    return flip ? n - k : k;
+}
+
 // wave-uniform lane index -> v_readlane_b32 (no LDS round trip, unlike __shfl)
 __device__ __forceinline__ uint32_t bcast32(uint32_t v, int L) { return (uint32_t)__builtin_amdgcn_readlane((int)v, L); }
 __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int L) {
@@ -280,15 +337,7 @@ __global__ __launch_bounds__(256) void k_perm_fast(
     } else {
         unsigned long long thr = (unsigned long long)(my_p * 4294967296.0);
         if (thr > 4294967296ull) thr = 4294967296ull;
-        const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), ci = row_i[r], cj = row_j[r];
-        exceed = 0;
-        for (uint32_t s = 0; s < n_shuffles; s += 4u) {
-            const U4 o = philox4x32_10(s >> 2, ci, cj, TAG_PERM2X2, k0, k1);
-            exceed += ((unsigned long long)o.x < thr);
-            if (s + 1u < n_shuffles) exceed += ((unsigned long long)o.y < thr);
-            if (s + 2u < n_shuffles) exceed += ((unsigned long long)o.z < thr);
-            if (s + 3u < n_shuffles) exceed += ((unsigned long long)o.w < thr);
-        }
+        exceed = binom_draw(LF, n_shuffles, thr, row_i[r], row_j[r], (uint32_t)seed, (uint32_t)(seed >> 32));
     }
     out_exceed[r] = exceed;
     out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);

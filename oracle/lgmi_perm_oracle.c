@@ -423,6 +423,73 @@ static double ptail22(const perm_tables* t, const hg22* h, uint32_t kobs)
     return p;
 }
 
+/* ------------------------------------------------------------------ binomial draw (2 x 2 tables)
+ * For a 2 x 2 table the probability that a shuffle is "as or more extreme" is known exactly (ptail22), so the
+ * number of such shuffles among n_shuffles is Binomial(n_shuffles, P) and is drawn as ONE binomial variate
+ * instead of n_shuffles Bernoulli trials.  P enters as thr = trunc(P * 2^32) in units of 2^-32.
+ *   thr == 0 -> 0;  thr >= 2^32 -> n;  thr > 2^31: n - Binomial(n, 1 - p)  (1 - p is exact)
+ *   n p < 10 : sequential inversion from 0 (BINV; restart with fresh uniforms beyond np + 10 sqrt(npq + 1))
+ *   else     : Hoermann's transformed rejection BTRS (1993), the acceptance test taken against the exact
+ *              log-factorial table: v alpha / (a / us^2 + b) <= f(k) / f(m)
+ * Uniforms: Philox4x32-10, counter (call, row_i, row_j, TAG_PERM2X2), call = 0, 1, ... one call per BTRS
+ * candidate (words 0 and 1 -> (w + 0.5) 2^-32) or per inversion run (words 0, 1 -> 52 bits + half an ulp). */
+static uint32_t binom_draw(const perm_tables* t, uint32_t n, uint64_t thr, uint32_t row_i, uint32_t row_j,
+                           uint32_t k0, uint32_t k1)
+{
+    uint32_t out[4], call = 0, k, tt;
+    int flip;
+    double p, q, np;
+    if (thr == 0 || n == 0) return 0;
+    if (thr >= 4294967296ull) return n;
+    flip = thr > 2147483648ull;
+    tt = flip ? (uint32_t)(4294967296ull - thr) : (uint32_t)thr;
+    p = (double)tt * 2.3283064365386963e-10;
+    q = 1.0 - p;
+    np = (double)n * p;
+    if (np < 10.0) {
+        const double qn = lgo_det_exp((double)n * lgo_det_log(q));
+        const double lim = np + 10.0 * lgo_det_sqrt(np * q + 1.0);
+        const uint32_t bound = lim < (double)n ? (uint32_t)lim : n;
+        for (;;) {
+            double px = qn, u;
+            uint32_t x = 0;
+            philox(call++, row_i, row_j, TAG_PERM2X2, k0, k1, out);
+            u = ((double)(((uint64_t)out[0] << 20) | (out[1] >> 12)) + 0.5) * 2.220446049250313e-16;
+            while (u > px && x <= bound) {
+                ++x;
+                u -= px;
+                px = ((double)(n - x + 1u) * p * px) / ((double)x * q);
+            }
+            if (x <= bound) { k = x; break; }
+        }
+    } else {
+        const double spq = lgo_det_sqrt(np * q);
+        const double b = 1.15 + 2.53 * spq;
+        const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+        const double c = np + 0.5;
+        const double vr = 0.92 - 4.2 / b;
+        const double alpha = (2.83 + 5.1 / b) * spq;
+        const uint32_t m = (uint32_t)floor((double)(n + 1u) * p);
+        const double lr = lgo_det_log(p / q);
+        const double hm = t->LF[m] + t->LF[n - m];
+        for (;;) {
+            double u, v, us, kf, h;
+            philox(call++, row_i, row_j, TAG_PERM2X2, k0, k1, out);
+            u = ((double)out[0] + 0.5) * 2.3283064365386963e-10 - 0.5;
+            v = ((double)out[1] + 0.5) * 2.3283064365386963e-10;
+            us = 0.5 - fabs(u);
+            kf = floor((2.0 * a / us + b) * u + c);
+            if (kf < 0.0 || kf > (double)n) continue;
+            k = (uint32_t)kf;
+            if (us >= 0.07 && v <= vr) break;
+            v = v * alpha / (a / (us * us) + b);
+            h = hm - t->LF[k] - t->LF[n - k] + ((double)k - (double)m) * lr;
+            if (v <= lgo_det_exp(h)) break;
+        }
+    }
+    return flip ? n - k : k;
+}
+
 static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row_i, uint32_t row_j,
                          uint32_t n_shuffles, uint64_t seed, double* ptail_out)
 {
@@ -440,7 +507,6 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
         hg22 h;
         double p;
         uint64_t thr;
-        uint32_t out[4];
         const uint32_t kobs = T[3 * nzr[1] + nzc[1]];
         h.N = N; h.K = R[nzr[1]]; h.n = C[nzc[1]];
         h.kmin = h.K + h.n > N ? h.K + h.n - N : 0;
@@ -454,11 +520,7 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
         if (ptail_out) *ptail_out = p;
         thr = (uint64_t)(p * 4294967296.0);
         if (thr > 4294967296ull) thr = 4294967296ull;
-        for (s = 0; s < n_shuffles; ++s) {
-            if ((s & 3u) == 0) philox(s >> 2, row_i, row_j, TAG_PERM2X2, k0, k1, out);
-            exceed += ((uint64_t)out[s & 3u] < thr);
-        }
-        return exceed;
+        return binom_draw(t, n_shuffles, thr, row_i, row_j, k0, k1);
     }
     {
         const int64_t sobs = stat9(t, T);
@@ -498,6 +560,7 @@ int lgo_perm_rows(uint64_t n_rows, const uint32_t* row_i, const uint32_t* row_j,
         for (k = 0; k < 9; ++k) n += counts[9 * r + k];
         if (n > max_n) max_n = n;
     }
+    if (n_shuffles > max_n) max_n = n_shuffles;        /* binom_draw looks up LF[0 .. n_shuffles] */
     if (tables_init(&t, max_n)) return -1;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -529,6 +592,16 @@ int lgo_hg_draw_many2(uint32_t pop, uint32_t good, uint32_t sample, uint64_t see
         g.c0 = i; g.c1 = 1; g.c2 = 2; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0;
         out[i] = hg_draw(&t, pop, good, sample, &g, use_table ? &ft : NULL);
     }
+    free(t.G); free(t.LF);
+    return 0;
+}
+
+int lgo_binom_draw_many(uint32_t n, uint64_t thr, uint64_t seed, uint32_t count, uint32_t* out)
+{
+    perm_tables t;
+    uint32_t i;
+    if (tables_init(&t, n)) return -1;
+    for (i = 0; i < count; ++i) out[i] = binom_draw(&t, n, thr, i, 7u, (uint32_t)seed, (uint32_t)(seed >> 32));
     free(t.G); free(t.LF);
     return 0;
 }

@@ -379,7 +379,7 @@ def test_bad_arguments_are_rejected(engine):
         st3.site_pos = pos.ctypes.data_as(_lib.i64p)
         assert lib.lgmi_batch_upload(engine.handle, C.byref(st3), C.byref(h)) == _lib.E_ARG
     # reserved bytes / absurd shuffle counts
-    prm = lgmi_params(n_shuffles=2**31)
+    prm = lgmi_params(n_shuffles=2**24 + 1)
     res, info = _lib.Result(), _lib.RunInfo()
     assert lib.lgmi_run(engine.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)) == _lib.E_ARG
     assert lib.lgmi_run(None, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)) == _lib.E_ARG

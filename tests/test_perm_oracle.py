@@ -23,6 +23,8 @@ def lib():
     lib.lgo_hg_draw_many2.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_int]
     lib.lgo_first_table.restype = C.c_int
     lib.lgo_first_table.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    lib.lgo_binom_draw_many.restype = C.c_int
+    lib.lgo_binom_draw_many.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, u32p]
     lib.lgo_perm_ptail.restype = C.c_int
     lib.lgo_perm_ptail.argtypes = [u32p, f64p]
     return lib
@@ -100,6 +102,48 @@ def test_hypergeometric_sampler_matches_scipy(lib, pop, good, sample, use_table)
     assert p > 1e-4, 'chi2 %.1f over %d cells, p=%.2e' % (chi2, len(e), p)
     mean = good * sample / pop
     assert abs(out.mean() - mean) < 5 * np.sqrt(max(stats.hypergeom.var(pop, good, sample), 1e-9) / n) + 1e-9
+
+
+# (n, p): inversion branch (n p < 10), BTRS branch, both sides of the switch, p > 1/2 (mirrored), tiny and huge n
+BINOM_CASES = [(1000, 0.5), (1000, 0.013), (1000, 0.0099), (1000, 0.0101), (1000, 0.3), (1000, 0.97), (1000, 0.9995),
+               (1000, 1e-5), (64, 0.4), (20, 0.5), (50, 0.19), (50, 0.21), (100000, 0.2), (10000000, 0.5), (3, 0.5), (1, 0.3)]
+
+
+@pytest.mark.parametrize('n,p', BINOM_CASES)
+def test_binomial_sampler_matches_scipy(lib, n, p):
+    """the 2 x 2 path draws the exceed count as ONE Binomial(n_shuffles, P_tail) variate"""
+    cnt = 100000
+    thr = int(p * 2 ** 32)
+    out = np.zeros(cnt, np.uint32)
+    assert lib.lgo_binom_draw_many(n, thr, 5, cnt, out.ctypes.data_as(u32p)) == 0
+    pp = thr / 2 ** 32
+    assert out.max() <= n
+    lo, hi = int(out.min()), int(out.max())
+    ks = np.arange(max(0, lo - 10), min(n, hi + 10) + 1)
+    obs = np.bincount(out - ks[0], minlength=len(ks)).astype(float)
+    exp = stats.binom.pmf(ks, n, pp) * cnt
+    order = np.argsort(-exp)
+    keep = exp[order] >= 8
+    o = np.append(obs[order][keep], obs[order][~keep].sum())
+    e = np.append(exp[order][keep], cnt - exp[order][keep].sum())
+    if e[-1] < 1e-6:
+        assert o[-1] == 0
+        o, e = o[:-1], e[:-1]
+    if len(e) > 1:
+        chi2 = ((o - e) ** 2 / e).sum()
+        pv = stats.chi2.sf(chi2, len(e) - 1)
+        assert pv > 1e-4, 'chi2 %.1f over %d cells, p=%.2e' % (chi2, len(e), pv)
+    assert abs(out.mean() - n * pp) < 5 * np.sqrt(n * pp * (1 - pp) / cnt) + 1e-9
+
+
+def test_binomial_sampler_edges(lib):
+    out = np.zeros(100, np.uint32)
+    assert lib.lgo_binom_draw_many(1000, 0, 1, 100, out.ctypes.data_as(u32p)) == 0 and (out == 0).all()
+    assert lib.lgo_binom_draw_many(1000, 2 ** 32, 1, 100, out.ctypes.data_as(u32p)) == 0 and (out == 1000).all()
+    assert lib.lgo_binom_draw_many(0, 2 ** 31, 1, 100, out.ctypes.data_as(u32p)) == 0 and (out == 0).all()
+    # thr = 1: p = 2^-32 -> essentially always 0; thr = 2^32 - 1 -> essentially always n
+    assert lib.lgo_binom_draw_many(1000, 1, 1, 100, out.ctypes.data_as(u32p)) == 0 and (out == 0).all()
+    assert lib.lgo_binom_draw_many(1000, 2 ** 32 - 1, 1, 100, out.ctypes.data_as(u32p)) == 0 and (out == 1000).all()
 
 
 def stat_of(table):
