@@ -25,7 +25,17 @@
 #include "lgmi_internal.h"
 #include "philox.h"
 
+#ifndef LGMI_PABL
+#define LGMI_PABL 0     // timing-only ablations (results wrong by construction), tools/abl_perm.sh
+#endif
+
 namespace lgmi {
+
+#if LGMI_PABL
+__device__ __forceinline__ U4 cheap_rng(uint32_t a, uint32_t b) {
+    U4 o; o.x = a * 2654435761u + b * 40503u; o.y = (o.x ^ (o.x >> 15)) * 2246822519u; o.x ^= o.y >> 13; o.z = o.x; o.w = o.y; return o;
+}
+#endif
 
 static const uint32_t TAG_PERM2X2 = 0x5eed0004u;
 static const uint32_t TAG_PERMGEN = 0x60000000u;
@@ -296,15 +306,25 @@ __global__ __launch_bounds__(256) void k_perm_fast(
             h.c0 += LF[h.n];
             h.c0 += LF[N - h.n];
             h.c0 -= LF[N];
+#if LGMI_PABL & 64
+            tb.klo = T[3 * a2 + b2]; tb.khi = tb.klo + 40; tb.centre = 1;
+#else
             tb = bounds22(G, h, T[3 * a2 + b2]);
+#endif
         } else {
             kind = 3;
+#if !(LGMI_PABL & 16)
             gen_list[atomicAdd(gen_count, 1u)] = (uint32_t)r;
+#endif
         }
     }
     // ---- phase B (the wave works on one row at a time): exact tail mass
     double my_p = 1.0;
+#if LGMI_PABL & 32
+    unsigned long long todo = 0; if (kind == 2) my_p = 0.37;
+#else
     unsigned long long todo = __ballot(kind == 2);
+#endif
     while (todo) {
         const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         todo &= todo - 1ull;
@@ -337,7 +357,11 @@ __global__ __launch_bounds__(256) void k_perm_fast(
     } else {
         unsigned long long thr = (unsigned long long)(my_p * 4294967296.0);
         if (thr > 4294967296ull) thr = 4294967296ull;
+#if LGMI_PABL & 128
+        exceed = (uint32_t)(thr >> 24);
+#else
         exceed = binom_draw(LF, n_shuffles, thr, row_i[r], row_j[r], (uint32_t)seed, (uint32_t)(seed >> 32));
+#endif
     }
     out_exceed[r] = exceed;
     out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
@@ -385,6 +409,7 @@ struct GState {
 //   tab_thr[e]   inverse-CDF thresholds of the first real draw of a shuffle.  Its parameters are the same in every
 //                shuffle of the row, so it is drawn with one 32-bit word and a binary search instead of a
 //                rejection loop (window of at most FIRST_MAX values around the mode, else the HRUA path stays)
+//   tab_guide[b] where the search starts for a word whose top byte is b (256 buckets: 1 - 3 probes instead of 11)
 //   next_s       the next shuffle index nobody has taken: a lane that finishes a shuffle takes the next one, so
 //                the wave drains together whatever the lanes' rejection counts were (the exceed count is a sum
 //                over shuffles and every shuffle has its own Philox stream: who runs which one does not matter)
@@ -397,6 +422,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
     double* __restrict__ out_p, uint32_t* __restrict__ out_exceed)
 {
     __shared__ uint32_t tab_thr[FIRST_MAX];
+    __shared__ uint16_t tab_guide[257];     // tab_guide[b] = the draw for u = b << 24: where the search for u >> 24 == b starts
     __shared__ uint32_t next_s;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -484,6 +510,20 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     const unsigned long long t = (unsigned long long)tab_thr[e] + before;
                     tab_thr[e] = t >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
                 }
+                for (uint32_t b = lane; b < 257u; b += 64u) tab_guide[b] = (uint16_t)(tab_n - 1u);
+                __syncthreads();
+                // entry e is the answer for every u in [thr[e-1], thr[e]): it starts the buckets whose first
+                // value b << 24 falls in that range (thresholds do not decrease, so each bucket is written once)
+                uint32_t prev = e0 > 0u && e0 < tab_n ? tab_thr[e0 - 1u] : 0u;
+                for (uint32_t e = e0; e < e1; ++e) {
+                    const uint32_t cur = tab_thr[e];
+                    if (cur > prev) {
+                        const uint32_t b_hi = (cur - 1u) >> 24;
+                        for (uint32_t b = (uint32_t)(((unsigned long long)prev + 0xFFFFFFull) >> 24); b <= b_hi; ++b)
+                            tab_guide[b] = (uint16_t)e;
+                    }
+                    prev = cur;
+                }
             }
             __syncthreads();
         }
@@ -498,7 +538,30 @@ __global__ __launch_bounds__(64) void k_perm_general(
         bool need_begin = g.s < n_shuffles;   // lane has a shuffle to start
         bool have_z = false;
         uint32_t z = 0;
-        if (need_begin) { g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0; }
+        // the first real draw of a shuffle when the row has a threshold table: one 32-bit word, inverse CDF
+        auto table_draw = [&]() {
+#if LGMI_PABL & 8
+            const U4 o = cheap_rng(g.s + ci, g.call + cj);
+            g.call++;
+            return tab_klo + (tab_n >> 1) + (o.x & 7u);
+#else
+            const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+#endif
+            g.call++;
+            // smallest e with u < thr[e] (the last entry when there is none); the guide table narrows the
+            // search to the entries between the answers for the bucket's first value and the next bucket's
+            uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
+            }
+            return tab_klo + lo;
+        };
+        if (need_begin) {
+            g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
+            g.cc = C0; g.pop = N;
+            if (tab_ok) { z = table_draw(); have_z = true; need_begin = false; }
+        }
 
         for (;;) {
             // ---- (1) one candidate / urn step for the lanes that are inside a draw.  One Philox call
@@ -506,7 +569,11 @@ __global__ __launch_bounds__(64) void k_perm_general(
             const bool in_draw = !need_begin && g.phase != 3;
             double ux = 0.5, uy = 0.5;
             if (in_draw) {
+#if LGMI_PABL & 1
+                const U4 o = philox4x32_r<5>(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+#else
                 const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+#endif
                 g.call++;
                 ux = ((double)o.x + 0.5) * 2.3283064365386963e-10;
                 uy = ((double)o.y + 0.5) * 2.3283064365386963e-10;
@@ -518,7 +585,11 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     const uint32_t zc = (uint32_t)floor(w);
                     const double tt = g.d10 - (LF[zc] + LF[g.mn - zc] + LF[g.m - zc] + LF[g.mx - g.m + zc]);
                     bool acc = (x * (4.0 - x) - 3.0 <= tt);
+                    #if LGMI_PABL & 2
+                    if (!acc && !(x * (x - tt) >= 1.0)) acc = (x * x <= 1.0 + tt);
+#else
                     if (!acc && !(x * (x - tt) >= 1.0)) acc = (x * x <= det_exp(tt));   // 2 ln x <= tt
+#endif
                     if (acc) {
                         z = zc;
                         if (g.good > g.pop - g.good) z = g.m - z;   // z counted the minority kind
@@ -543,8 +614,13 @@ __global__ __launch_bounds__(64) void k_perm_general(
             //          column / the table when it is complete, set up the next real draw.
             //          g.d = 2 * column + row (row 1 only exists when three rows are non-empty)
             if (have_z || need_begin) {
+                bool done = false;                                   // lane has run out of shuffles
                 for (;;) {
-                    if (have_z) {
+                    // (2a) booking.  A lane that finishes a shuffle and has a table draws the next shuffle's
+                    //      first result right here and books it in a second pass, so that every lane reaches
+                    //      the set-up code below once, together (the table draw is never trivially determined:
+                    //      the table only exists when both margins of the draw are inside (0, N))
+                    while (have_z) {
                         have_z = false;
                         bool column_done = false;
                         uint32_t x0 = 0, x1 = 0, x2 = 0;
@@ -557,7 +633,11 @@ __global__ __launch_bounds__(64) void k_perm_general(
                             column_done = true;
                         }
                         if (column_done) {
+#if LGMI_PABL & 1024
+                            g.ss += x0 + x1 + x2;
+#else
                             g.ss += G[x0] + G[x1] + G[x2];
+#endif
                             g.rr0 -= x0; g.rr1 -= x1; rr2 -= x2;
                             g.pop_all -= ((g.d >> 1) == 0 ? C0 : C1);
                             g.d = (g.d | 1) + 1;                     // first row of the next column
@@ -565,13 +645,15 @@ __global__ __launch_bounds__(64) void k_perm_general(
                                 g.ss += G[g.rr0] + G[g.rr1] + G[rr2];
                                 exceed += (g.ss >= sobs);
                                 g.s = atomicAdd(&next_s, 1u);
-                                if (g.s >= n_shuffles) { g.phase = 3; need_begin = false; break; }
+                                if (g.s >= n_shuffles) { g.phase = 3; done = true; break; }
                                 g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
+                                if (tab_ok) { g.cc = C0; g.pop = N; z = table_draw(); have_z = true; }
                             }
                         }
                     }
+                    if (done) break;
                     need_begin = false;
-                    // parameters of draw g.d
+                    // (2b) parameters of draw g.d
                     if ((g.d & 1) == 0) { g.cc = ((g.d >> 1) == 0 ? C0 : C1); g.pop = g.pop_all; g.good = g.rr0; }
                     else { g.good = g.rr1; }
                     g.sample = g.cc;
@@ -579,30 +661,28 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     if (sample == 0u || good == 0u) { z = 0u; have_z = true; continue; }
                     if (bad == 0u) { z = sample; have_z = true; continue; }
                     if (sample == pop) { z = good; have_z = true; continue; }
-                    if (tab_ok && g.d == 0) {
-                        // the first real draw of the shuffle: one 32-bit word, inverse CDF on the row's table
-                        const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
-                        g.call++;
-                        uint32_t lo = 0u, hi = tab_n - 1u;
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
-                        }
-                        z = tab_klo + lo;
-                        have_z = true;
-                        continue;
-                    }
                     g.m = sample < pop - sample ? sample : pop - sample;
                     if (g.m < 10u) {
                         g.rem_total = pop; g.rem_good = good; g.left = g.m;
                         g.phase = 2;
                     } else {
                         HrBase& hb = (g.d & 1) ? base1 : base0;
+#if LGMI_PABL & 2048
+                        if (hb.pop == 0u) hr_base(pop, good, hb);
+#else
                         if (hb.pop != pop || hb.good != good) hr_base(pop, good, hb);
+#endif
                         g.mn = good < bad ? good : bad;
                         g.mx = good < bad ? bad : good;
                         g.d6 = (double)g.m * hb.d4 + 0.5;
+#if LGMI_PABL & 256
+                        g.d8 = 100.0; g.d10 = -1000.0; g.d11 = (double)((g.m < g.mn ? g.m : g.mn) + 1u); g.phase = 1; break;
+#endif
+#if LGMI_PABL & 4
+                        const double d7 = (double)__fsqrt_rn((float)((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5));
+#else
                         const double d7 = det_sqrt((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5);
+#endif
                         const uint32_t d9 = (uint32_t)floor((double)(g.m + 1u) * hb.c9);
                         g.d10 = LF[d9] + LF[g.mn - d9] + LF[g.m - d9] + LF[g.mx - g.m + d9];
                         g.d8 = HRUA_D1 * d7 + HRUA_D2;

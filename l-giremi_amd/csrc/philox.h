@@ -20,9 +20,10 @@ LGMI_HD void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
     lo = (uint32_t)p;
 }
 
-LGMI_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+template <int ROUNDS>
+LGMI_HD U4 philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         uint32_t hi0, lo0, hi1, lo1;
         mulhilo(0xD2511F53u, c0, hi0, lo0);
         mulhilo(0xCD9E8D57u, c2, hi1, lo1);
@@ -33,6 +34,10 @@ LGMI_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     }
     U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
     return o;
+}
+
+LGMI_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    return philox4x32_r<10>(c0, c1, c2, c3, k0, k1);
 }
 
 // stream tags (counter word 2)
