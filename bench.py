@@ -209,7 +209,8 @@ def main():
                                'frac': ops / secs / 1e12 / MFMA_I8_PEAK_TOPS, 'traffic': hbm['traffic'],
                                'algorithmic_ops': ops,
                                'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2); '
-                                       'v_mfma_i32_32x32x32_i8, operands expanded from bit planes in registers'}
+                                       'v_mfma_i32_32x32x32_i8, weighted-bit int8 operands made from the bit planes in registers '
+                                       '(one AND per operand dword)'}
             out['hbm_roofline'] = hbm
         else:
             out['roofline'] = hbm
