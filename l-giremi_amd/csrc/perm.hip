@@ -11,10 +11,12 @@
 // p = (1 + #{S(T_s) >= S(T_obs)}) / (n_shuffles + 1).
 //
 //   k_perm_fast     one lane per row.  Degenerate tables: p = 1.  2 x 2 tables (one
-//                   degree of freedom k): shuffle s lands in the "as or more extreme" set
-//                   iff u_s < P_tail, with P_tail summed exactly from log-factorials —
-//                   pure ALU + Philox, no table is materialised.  Larger tables are
-//                   queued for k_perm_general.
+//                   degree of freedom k): the mass P_tail of the "as or more extreme" set is
+//                   summed exactly from log-factorials (units of 16 values dealt evenly over
+//                   the wave, integer fixed-point sums), and the number of shuffles that land
+//                   in the set is drawn as one Binomial(n_shuffles, P_tail) variate — pure
+//                   ALU + Philox, no table is materialised.  Larger tables are queued for
+//                   k_perm_general.
 //   k_perm_general  one wave per queued row, shuffles spread over the 64 lanes; each
 //                   shuffle draws the table with conditional hypergeometric draws (urn
 //                   scheme for small samples, Stadlober's HRUA otherwise).
@@ -123,7 +125,7 @@ __device__ __forceinline__ double pmf22(const double* __restrict__ LF, const HG2
 // lane-private part of the exact tail: bisection for the far boundary of the "as or more
 // extreme" set {k <= klo} U {k >= khi}, and the choice between summing that set or its
 // complement (whichever lies within ~7 sigma)
-struct Tail22 { long long klo, khi; int centre; };
+struct Tail22 { long long klo, khi; int centre; double var; };
 
 __device__ Tail22 bounds22(const long long* __restrict__ G, const HG22& h, uint32_t kobs) {
     const long long sobs = stat22(G, h, kobs);
@@ -152,58 +154,33 @@ __device__ Tail22 bounds22(const long long* __restrict__ G, const HG22& h, uint3
                        ((double)h.N * (double)h.N * (double)(h.N > 1 ? h.N - 1 : 1));
     const double clen = (double)(t.khi - t.klo - 1);
     t.centre = (clen * clen <= 49.0 * var + 64.0) ? 1 : 0;
+    t.var = var;
     return t;
 }
 
-// wave-cooperative run: term number q goes to lane q % 64; after each 64-term chunk the
-// run stops when its farthest term has fallen below 2^-44 of the run's first term.
-// All control flow is wave-uniform (count, base and the two broadcast terms).
-__device__ __forceinline__ void run_sum_wave(const double* __restrict__ LF, const HG22& h, long long k0, long long kend,
-                                             int dir, int stop_rule, uint32_t lane, double& acc) {
-    const long long count = dir > 0 ? kend - k0 + 1 : k0 - kend + 1;
-    if (count <= 0) return;
-    double first = 0.0;
-    for (long long base = 0; base < count; base += 64) {
-        const long long idx = base + lane;
-        double term = 0.0;
-        if (idx < count) {
-            term = pmf22(LF, h, (uint32_t)(k0 + dir * idx));
-            acc += term;
-        }
-        if (base == 0) first = __shfl(term, 0);
-        if (stop_rule) {
-            const long long rem = count - base - 1;
-            const double last = __shfl(term, (int)(rem < 63 ? rem : 63));
-            if (!(last > first * 5.684341886080802e-14)) break;   // also stops a run of zeros
-        }
-    }
-}
+// Exact mass of UNIT = 16 consecutive values k0 .. k0 + len - 1 in units of 2^-62: first term from the
+// log-factorials, the following ones through the hypergeometric ratio carried division-free
+// (sum = t0 (1 + P / Q) with N <- N num, Q <- Q den, P <- fma(P, den, N)), truncated to the fixed-point grid.
+// The mass of a range is the INTEGER sum of its units: it does not depend on which lane sums which unit or on
+// the order of the additions (CPU specification: unit_mass / range_mass in oracle/lgmi_perm_oracle.c).
+static const uint32_t UNIT = 16;
 
-// the complement (centre) run in 64 contiguous segments: first term of a lane's segment from the
-// log-factorials, the rest by the hypergeometric ratio (one division instead of an exp per term)
-__device__ __forceinline__ void centre_sum_wave(const double* __restrict__ LF, const HG22& h, long long k0,
-                                                long long kend_excl, uint32_t lane, double& acc) {
-    const long long count = kend_excl - k0;
-    if (count <= 0) return;
-    const long long seg = (count + 63) / 64;
-    const long long ks = k0 + (long long)lane * seg;
-    long long ke = ks + seg;
-    if (ke > kend_excl) ke = kend_excl;
-    double term = 0.0;
-    if (ks < kend_excl) {
-        term = pmf22(LF, h, (uint32_t)ks);
-        acc += term;
-    }
-    for (long long step = 1; step < seg; ++step) {      // wave-uniform trip count
-        const long long k = ks + step - 1;              // term k -> term k + 1
-        if (k + 1 < ke) {
-            const uint32_t ku = (uint32_t)k;
-            const double num = (double)(h.K - ku) * (double)(h.n - ku);
-            const double den = (double)(ku + 1u) * (double)(h.N - h.K - h.n + ku + 1u);
-            term = term * num / den;
-            acc += term;
+__device__ __forceinline__ unsigned long long unit_mass(const double* __restrict__ LF, const HG22& h, uint32_t k0, uint32_t len) {
+    const double t0 = pmf22(LF, h, k0);
+    double P = 0.0, Nn = 1.0, Q = 1.0;
+    double a = (double)(h.K - k0), b = (double)(h.n - k0), c = (double)(k0 + 1u), d = (double)(h.N - h.K - h.n + k0 + 1u);
+#pragma unroll 1
+    for (uint32_t j = 1; j < UNIT; ++j) {               // wave-uniform trip count, short units predicated
+        if (j < len) {
+            const double num = a * b, den = c * d;
+            Nn = Nn * num;
+            Q = Q * den;
+            P = fma(P, den, Nn);
+            a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
         }
     }
+    const double sum = t0 + t0 * P / Q;
+    return (unsigned long long)(sum * 4611686018427387904.0);   // 2^62
 }
 
 // The number of "as or more extreme" shuffles of a 2 x 2 table is Binomial(n_shuffles, P_tail): one binomial
@@ -280,7 +257,7 @@ __global__ __launch_bounds__(256) void k_perm_fast(
     // ---- phase A (one lane per row): classify, set up the hypergeometric, find the bounds
     int kind = 0;   // 0 nothing, 1 degenerate, 2 two-by-two, 3 queued for k_perm_general
     HG22 h = {1u, 0u, 0u, 0u, 0u, 0.0};
-    Tail22 tb = {0, 0, 1};
+    Tail22 tb = {0, 0, 1, 0.0};
     if (r < n_rows) {
         uint32_t T[9];
 #pragma unroll
@@ -318,36 +295,85 @@ __global__ __launch_bounds__(256) void k_perm_fast(
 #endif
         }
     }
-    // ---- phase B (the wave works on one row at a time): exact tail mass
-    double my_p = 1.0;
-#if LGMI_PABL & 32
-    unsigned long long todo = 0; if (kind == 2) my_p = 0.37;
-#else
-    unsigned long long todo = __ballot(kind == 2);
-#endif
-    while (todo) {
-        const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        todo &= todo - 1ull;
-        HG22 hb;
-        hb.N = bcast32(h.N, L); hb.K = bcast32(h.K, L); hb.n = bcast32(h.n, L);
-        hb.kmin = bcast32(h.kmin, L); hb.kmax = bcast32(h.kmax, L);
-        hb.c0 = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(h.c0), L));
-        const long long klo = (long long)bcast64((unsigned long long)tb.klo, L);
-        const long long khi = (long long)bcast64((unsigned long long)tb.khi, L);
-        const int centre = (int)bcast32((uint32_t)tb.centre, L);
-        double acc = 0.0;
-        if (centre) {
-            centre_sum_wave(LF, hb, klo + 1, khi, lane, acc);
+    // ---- phase B: exact mass of the "as or more extreme" set, or of its complement when that is the short side.
+    //      Each row lists up to two ranges of k; the ranges are cut into units of 16 values and the units of the
+    //      wave's 64 rows are dealt to the lanes 64 at a time, so every lane has the same amount of work whatever
+    //      the rows' range lengths are.  Unit masses are integers (2^-62) added with LDS atomics: exact, any order.
+    __shared__ uint32_t s_pre[4][65];
+    __shared__ unsigned long long s_acc[4][64];
+    const uint32_t w = threadIdx.x >> 6;
+    uint32_t start1 = 0, len1 = 0, start2 = 0, len2 = 0;
+    if (kind == 2) {
+#if !(LGMI_PABL & 32)
+        if (tb.centre) {
+            start1 = (uint32_t)(tb.klo + 1);
+            len1 = (uint32_t)(tb.khi - tb.klo - 1);
         } else {
-            run_sum_wave(LF, hb, klo, (long long)hb.kmin, -1, 1, lane, acc);
-            run_sum_wave(LF, hb, khi, (long long)hb.kmax, +1, 1, lane, acc);
+            // both tails start >= ~3.5 sigma out.  First (largest) terms below 2^-60: the whole set weighs less
+            // than 2^-33, thr = 0.  Otherwise 8 sigma + 16 values per tail (the rest is below 2^-80 of it).
+            const double f_lo = tb.klo >= (long long)h.kmin ? pmf22(LF, h, (uint32_t)tb.klo) : 0.0;
+            const double f_hi = tb.khi <= (long long)h.kmax ? pmf22(LF, h, (uint32_t)tb.khi) : 0.0;
+            if (!(f_lo < 8.673617379884035e-19 && f_hi < 8.673617379884035e-19)) {
+                const long long D = (long long)(8.0 * det_sqrt(tb.var + 1.0)) + 16;
+                long long lo_start = tb.klo - D + 1, hi_end = tb.khi + D - 1;
+                if (lo_start < (long long)h.kmin) lo_start = (long long)h.kmin;
+                if (hi_end > (long long)h.kmax) hi_end = (long long)h.kmax;
+                if (tb.klo >= lo_start) { start1 = (uint32_t)lo_start; len1 = (uint32_t)(tb.klo - lo_start + 1); }
+                if (hi_end >= tb.khi) { start2 = (uint32_t)tb.khi; len2 = (uint32_t)(hi_end - tb.khi + 1); }
+            }
         }
+#endif
+    }
+    const uint32_t units1 = (len1 + UNIT - 1u) / UNIT;
+    const uint32_t my_units = units1 + (len2 + UNIT - 1u) / UNIT;
+    uint32_t incl = my_units;                               // inclusive scan over the wave
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        double p = centre ? 1.0 - acc : acc;
-        if (p > 1.0) p = 1.0;
-        if (p < 0.0) p = 0.0;
-        if ((int)lane == L) my_p = p;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    s_pre[w][lane] = incl - my_units;
+    if (lane == 63u) s_pre[w][64] = incl;
+    s_acc[w][lane] = 0ull;
+    __syncthreads();
+    const uint32_t total = s_pre[w][64];                    // wave-uniform
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t id = base + lane;
+        const bool active = id < total;
+        // the row of unit id: the largest r with pre[r] <= id (its successor starts beyond id, so it owns units)
+        uint32_t lo = 0u, hi = 63u;
+        if (active) {
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_pre[w][mid] <= id) lo = mid; else hi = mid - 1u;
+            }
+        }
+        const int rr = (int)lo;
+        HG22 hb;
+        hb.N = __shfl(h.N, rr); hb.K = __shfl(h.K, rr); hb.n = __shfl(h.n, rr);
+        hb.kmin = 0u; hb.kmax = 0u;
+        hb.c0 = __shfl(h.c0, rr);
+        const uint32_t r_start1 = __shfl(start1, rr), r_len1 = __shfl(len1, rr);
+        const uint32_t r_start2 = __shfl(start2, rr), r_len2 = __shfl(len2, rr);
+        if (active) {
+            uint32_t u = id - s_pre[w][rr];
+            const uint32_t r_units1 = (r_len1 + UNIT - 1u) / UNIT;
+            uint32_t k0, len;
+            if (u < r_units1) { k0 = r_start1 + UNIT * u; len = r_len1 - UNIT * u; }
+            else { u -= r_units1; k0 = r_start2 + UNIT * u; len = r_len2 - UNIT * u; }
+            if (len > UNIT) len = UNIT;
+            atomicAdd(&s_acc[w][rr], unit_mass(LF, hb, k0, len));
+        }
+    }
+    __syncthreads();
+    unsigned long long thr = 0ull;
+    if (kind == 2) {
+        const unsigned long long sm = s_acc[w][lane];
+        if (tb.centre) thr = sm <= 4611686018427387904ull ? (4611686018427387904ull - sm) >> 30 : 0ull;
+        else { thr = sm >> 30; if (thr > 4294967296ull) thr = 4294967296ull; }
+#if LGMI_PABL & 32
+        thr = 1589137899ull;
+#endif
     }
     // ---- phase C (one lane per row): the shuffles
     if (kind == 0 || kind == 3) return;
@@ -355,8 +381,6 @@ __global__ __launch_bounds__(256) void k_perm_fast(
     if (kind == 1) {
         exceed = n_shuffles;
     } else {
-        unsigned long long thr = (unsigned long long)(my_p * 4294967296.0);
-        if (thr > 4294967296ull) thr = 4294967296ull;
 #if LGMI_PABL & 128
         exceed = (uint32_t)(thr >> 24);
 #else

@@ -318,74 +318,47 @@ static double pmf22(const perm_tables* t, const hg22* h, uint32_t k)
 
 /* 64-way strided summation, the order the GPU wave uses: term number q of a run goes to
  * accumulator q % 64; the 64 accumulators are combined by an xor butterfly. */
-static double butterfly64(double acc[64])
+/* Exact mass of a range of k, as a 64-bit integer in units of 2^-62.  The range [k0, k0 + len) is cut into units
+ * of UNIT = 16 consecutive values; a unit is summed in double precision — its first term from the log-factorials,
+ * the following ones through the hypergeometric ratio  pmf(k+1) = pmf(k) (K-k)(n-k) / ((k+1)(N-K-n+k+1))  carried
+ * division-free as (sum of terms) = t0 (1 + P / Q) with  N <- N num,  Q <- Q den,  P <- fma(P, den, N)  — and
+ * truncated to the fixed-point grid.  The mass of a range is the INTEGER sum of its units, so it does not depend
+ * on how units are dealt to GPU lanes or in which order they are added. */
+#define UNIT 16
+static uint64_t unit_mass(const perm_tables* t, const hg22* h, int64_t k0, int64_t len)
 {
-    int o, l;
-    for (o = 32; o > 0; o >>= 1) {
-        double nxt[64];
-        for (l = 0; l < 64; ++l) nxt[l] = acc[l] + acc[l ^ o];
-        memcpy(acc, nxt, sizeof nxt);
+    const uint32_t ku = (uint32_t)k0;
+    const double t0 = pmf22(t, h, ku);
+    double P = 0.0, Nn = 1.0, Q = 1.0, sum;
+    double a = (double)(h->K - ku), b = (double)(h->n - ku), c = (double)(ku + 1u), d = (double)(h->N - h->K - h->n + ku + 1u);
+    int64_t j;
+    for (j = 1; j < len; ++j) {
+        const double num = a * b, den = c * d;
+        Nn = Nn * num;
+        Q = Q * den;
+        P = fma(P, den, Nn);
+        a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
     }
-    return acc[0];
+    sum = t0 + t0 * P / Q;
+    return (uint64_t)(sum * 4611686018427387904.0);   /* 2^62 */
 }
 
-/* sum pmf over k = k0, k0+dir, ... up to kend (inclusive) in chunks of 64 terms; after a
- * chunk, stop if its farthest term is below 2^-44 of the run's first term (terms only
- * decrease moving away from the mode).  stop_rule = 0 sums the whole range. */
-static void run_sum(const perm_tables* t, const hg22* h, int64_t k0, int64_t kend, int dir, int stop_rule, double acc[64])
+static uint64_t range_mass(const perm_tables* t, const hg22* h, int64_t k0, int64_t len)
 {
-    const int64_t count = dir > 0 ? kend - k0 + 1 : k0 - kend + 1;
-    int64_t base;
-    double first = 0.0;
-    if (count <= 0) return;
-    first = pmf22(t, h, (uint32_t)k0);
-    for (base = 0; base < count; base += 64) {
-        int l;
-        double last = 0.0;
-        for (l = 0; l < 64 && base + l < count; ++l) {
-            const double term = pmf22(t, h, (uint32_t)(k0 + dir * (base + l)));
-            acc[l] += term;
-            last = term;
-        }
-        if (stop_rule && !(last > first * 5.684341886080802e-14)) break;   /* 2^-44; also stops a run of zeros */
-    }
+    uint64_t s = 0;
+    int64_t o;
+    for (o = 0; o < len; o += UNIT) s += unit_mass(t, h, k0 + o, len - o < UNIT ? len - o : UNIT);
+    return s;
 }
 
-/* the complement (centre) run: its `count` terms are cut into 64 contiguous segments of
- * seg = ceil(count / 64); accumulator l sums segment l — first term from the log-factorials,
- * the following ones by the hypergeometric ratio  pmf(k+1) = pmf(k) (K-k)(n-k) / ((k+1)(N-K-n+k+1)) */
-static void centre_sum(const perm_tables* t, const hg22* h, int64_t k0, int64_t kend_excl, double acc[64])
-{
-    const int64_t count = kend_excl - k0;
-    int64_t seg;
-    int l;
-    if (count <= 0) return;
-    seg = (count + 63) / 64;
-    for (l = 0; l < 64; ++l) {
-        const int64_t ks = k0 + (int64_t)l * seg;
-        int64_t ke = ks + seg, k;
-        double term;
-        if (ks >= kend_excl) break;
-        if (ke > kend_excl) ke = kend_excl;
-        term = pmf22(t, h, (uint32_t)ks);
-        acc[l] += term;
-        for (k = ks; k + 1 < ke; ++k) {
-            const double num = (double)(h->K - (uint32_t)k) * (double)(h->n - (uint32_t)k);
-            const double den = (double)((uint32_t)k + 1u) * (double)(h->N - h->K - h->n + (uint32_t)k + 1u);
-            term = term * num / den;
-            acc[l] += term;
-        }
-    }
-}
-
-/* P(S(k) >= S(k_obs)) under the hypergeometric null */
-static double ptail22(const perm_tables* t, const hg22* h, uint32_t kobs)
+/* trunc(2^32 P(S(k) >= S(k_obs))) under the hypergeometric null, in [0, 2^32]; *p_out gets P as a double */
+static uint64_t ptail22(const perm_tables* t, const hg22* h, uint32_t kobs, double* p_out)
 {
     const int64_t sobs = stat22(t, h, kobs);
     uint32_t kc = (uint32_t)(((uint64_t)h->n * (uint64_t)h->K) / (uint64_t)h->N);   /* S decreases up to kc, increases after */
     int64_t klo, khi;   /* tail = [kmin, klo] U [khi, kmax] */
-    double var, clen, p, acc[64];
-    int l;
+    double var, clen;
+    uint64_t s, thr;
     if (kc < h->kmin) kc = h->kmin;
     if (kc > h->kmax) kc = h->kmax;
     if (kobs <= kc) {
@@ -408,19 +381,32 @@ static double ptail22(const perm_tables* t, const hg22* h, uint32_t kobs)
     var = (double)h->n * (double)h->K * (double)(h->N - h->K) * (double)(h->N - h->n)
           / ((double)h->N * (double)h->N * (double)(h->N > 1 ? h->N - 1 : 1));
     clen = (double)(khi - klo - 1);
-    for (l = 0; l < 64; ++l) acc[l] = 0.0;
     if (clen * clen <= 49.0 * var + 64.0) {
         /* few values are less extreme (within ~7 sigma): 1 - their mass */
-        centre_sum(t, h, klo + 1, khi, acc);
-        p = 1.0 - butterfly64(acc);
+        s = range_mass(t, h, klo + 1, khi - klo - 1);
+        thr = s <= 4611686018427387904ull ? (4611686018427387904ull - s) >> 30 : 0;
+        if (p_out) *p_out = 1.0 - (double)s * 2.168404344971009e-19;
     } else {
-        run_sum(t, h, klo, (int64_t)h->kmin, -1, 1, acc);
-        run_sum(t, h, khi, (int64_t)h->kmax, +1, 1, acc);
-        p = butterfly64(acc);
+        /* both tails start >= ~3.5 sigma out.  When their first (largest) terms are below 2^-60 the whole set
+         * weighs less than 2^-33: thr = 0.  Otherwise each tail is summed over 8 sigma + 16 values (what lies
+         * beyond is below 2^-80 of it), clipped to the support. */
+        const double f_lo = klo >= (int64_t)h->kmin ? pmf22(t, h, (uint32_t)klo) : 0.0;
+        const double f_hi = khi <= (int64_t)h->kmax ? pmf22(t, h, (uint32_t)khi) : 0.0;
+        s = 0;
+        if (!(f_lo < 8.673617379884035e-19 && f_hi < 8.673617379884035e-19)) {
+            const int64_t D = (int64_t)(8.0 * lgo_det_sqrt(var + 1.0)) + 16;
+            int64_t lo_start = klo - D + 1, hi_end = khi + D - 1;
+            if (lo_start < (int64_t)h->kmin) lo_start = (int64_t)h->kmin;
+            if (hi_end > (int64_t)h->kmax) hi_end = (int64_t)h->kmax;
+            if (klo >= lo_start) s += range_mass(t, h, lo_start, klo - lo_start + 1);
+            if (hi_end >= khi) s += range_mass(t, h, khi, hi_end - khi + 1);
+        }
+        thr = s >> 30;
+        if (thr > 4294967296ull) thr = 4294967296ull;
+        if (p_out) *p_out = (double)s * 2.168404344971009e-19;
     }
-    if (p > 1.0) p = 1.0;
-    if (p < 0.0) p = 0.0;
-    return p;
+    if (p_out) { if (*p_out > 1.0) *p_out = 1.0; if (*p_out < 0.0) *p_out = 0.0; }
+    return thr;
 }
 
 /* ------------------------------------------------------------------ binomial draw (2 x 2 tables)
@@ -505,7 +491,6 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
     if (nr <= 1 || nc <= 1) { if (ptail_out) *ptail_out = 1.0; return n_shuffles; }
     if (nr == 2 && nc == 2) {
         hg22 h;
-        double p;
         uint64_t thr;
         const uint32_t kobs = T[3 * nzr[1] + nzc[1]];
         h.N = N; h.K = R[nzr[1]]; h.n = C[nzc[1]];
@@ -516,10 +501,7 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
         h.c0 += t->LF[h.n];
         h.c0 += t->LF[N - h.n];
         h.c0 -= t->LF[N];
-        p = ptail22(t, &h, kobs);
-        if (ptail_out) *ptail_out = p;
-        thr = (uint64_t)(p * 4294967296.0);
-        if (thr > 4294967296ull) thr = 4294967296ull;
+        thr = ptail22(t, &h, kobs, ptail_out);
         return binom_draw(t, n_shuffles, thr, row_i, row_j, k0, k1);
     }
     {

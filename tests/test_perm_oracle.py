@@ -182,6 +182,49 @@ def test_exact_tail_probability_2x2(lib, seed):
     assert lo - 1e-9 <= p.value <= hi + 1e-9, (p.value, lo, hi)
 
 
+def brute_band_fast(N, K, n, kobs):
+    """brute_ptail_2x2 vectorised and restricted to mode +- 14 sigma (what lies beyond weighs < 1e-40)"""
+    lo, hi = max(0, K + n - N), min(K, n)
+    sd = np.sqrt(stats.hypergeom.var(N, K, n))
+    ks = np.arange(max(lo, int(n * K / N - 14 * sd) - 2), min(hi, int(n * K / N + 14 * sd) + 2) + 1)
+    ks = np.union1d(ks, [kobs])
+    pmf = stats.hypergeom.pmf(ks, N, K, n)
+
+    def xlogx(t):
+        t = t.astype(float)
+        return np.where(t > 0, t * np.log(np.where(t > 0, t, 1.0)), 0.0)
+    st = xlogx(N - K - n + ks) + xlogx(n - ks) + xlogx(K - ks) + xlogx(ks)
+    sobs = st[np.searchsorted(ks, kobs)]
+    tol = 1e-11 * max(1.0, abs(sobs))
+    return pmf[st > sobs + tol].sum(), pmf[st >= sobs - tol].sum()
+
+
+@pytest.mark.parametrize('N', [500, 20000, 200000, 3000000])
+def test_exact_tail_near_independence_and_moderate_tails(lib, N):
+    """tables drawn around the null (centre form: 1 - mass of the less extreme values, up to ~7 sigma wide) and
+    further out (tail form: two clipped runs), at read counts up to the millions"""
+    rng = np.random.default_rng(N)
+    for _ in range(12):
+        K = int(rng.integers(N // 20, N - N // 20))
+        n = int(rng.integers(N // 20, N - N // 20))
+        sd = np.sqrt(stats.hypergeom.var(N, K, n))
+        lo, hi = max(0, K + n - N), min(K, n)
+        for z in (0.0, 0.3, -1.0, 2.2, -3.4, 3.6, -4.5, 6.0, -9.0):
+            k = int(np.clip(round(n * K / N + z * sd), lo, hi))
+            T = np.zeros((3, 3), np.uint32)
+            T[1, 1], T[1, 2], T[2, 1], T[2, 2] = N - K - n + k, n - k, K - k, k
+            pv = C.c_double()
+            assert lib.lgo_perm_ptail(np.ascontiguousarray(T.ravel()).ctypes.data_as(u32p), C.byref(pv)) == 0
+            blo, bhi = brute_band_fast(N, K, n, k)
+            # a pmf from differences of log-factorials ~ 4e7 is good to ~1e-8 at millions of reads (the table's
+            # libm lgamma; measured against a 60-digit Stirling sum), and the centre form inherits that as an
+            # ABSOLUTE error of its complement
+            tol = 1e-9 if N <= 200000 else 5e-8
+            assert blo - tol <= pv.value <= bhi + tol, (N, K, n, k, pv.value, blo, bhi)
+            if pv.value > 1e-6 and N <= 200000:
+                assert blo * (1 - 1e-6) - 1e-12 <= pv.value <= bhi * (1 + 1e-6) + 1e-12
+
+
 def run_perm(tables, n_shuffles, seed=7):
     lib = c_oracle.load()
     t = np.ascontiguousarray(np.asarray(tables, np.uint32).reshape(-1, 9))
