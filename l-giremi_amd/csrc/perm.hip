@@ -114,6 +114,9 @@ __device__ __forceinline__ long long stat22(const long long* __restrict__ G, con
 }
 
 __device__ __forceinline__ double pmf22(const double* __restrict__ LF, const HG22& h, uint32_t k) {
+#if LGMI_PABL & 4096
+    return det_exp(h.c0 - LF[k & 15u] - LF[(h.K - k) & 15u] - LF[(h.n - k) & 15u] - LF[(h.N - h.K - h.n + k) & 15u] - 3.0e6);
+#endif
     double e = h.c0;
     e -= LF[k];
     e -= LF[h.K - k];
@@ -158,28 +161,36 @@ __device__ Tail22 bounds22(const long long* __restrict__ G, const HG22& h, uint3
     return t;
 }
 
-// Exact mass of UNIT = 16 consecutive values k0 .. k0 + len - 1 in units of 2^-62: first term from the
-// log-factorials, the following ones through the hypergeometric ratio carried division-free
-// (sum = t0 (1 + P / Q) with N <- N num, Q <- Q den, P <- fma(P, den, N)), truncated to the fixed-point grid.
-// The mass of a range is the INTEGER sum of its units: it does not depend on which lane sums which unit or on
-// the order of the additions (CPU specification: unit_mass / range_mass in oracle/lgmi_perm_oracle.c).
-static const uint32_t UNIT = 16;
+// Exact mass of UNIT = 64 consecutive values k0 .. k0 + len - 1 in units of 2^-62: first term from the
+// log-factorials (four table lines per unit — scattered 8-byte look-ups are what the L2 charges for), the
+// following ones through the hypergeometric ratio carried division-free over sub-blocks of SUB = 16 steps
+// (N <- N num, Q <- Q den, P <- fma(P, den, N); then sum += t P / Q, t <- t N / Q), truncated to the fixed-point
+// grid.  The mass of a range is the INTEGER sum of its units: it does not depend on which lane sums which unit
+// or on the order of the additions (CPU specification: unit_mass / range_mass in oracle/lgmi_perm_oracle.c).
+static const uint32_t UNIT = 64, SUB = 16;
 
 __device__ __forceinline__ unsigned long long unit_mass(const double* __restrict__ LF, const HG22& h, uint32_t k0, uint32_t len) {
-    const double t0 = pmf22(LF, h, k0);
-    double P = 0.0, Nn = 1.0, Q = 1.0;
-    double a = (double)(h.K - k0), b = (double)(h.n - k0), c = (double)(k0 + 1u), d = (double)(h.N - h.K - h.n + k0 + 1u);
+    uint32_t k = k0;
+    double term = pmf22(LF, h, k), sum = term;
+    uint32_t rem = len - 1u;
 #pragma unroll 1
-    for (uint32_t j = 1; j < UNIT; ++j) {               // wave-uniform trip count, short units predicated
-        if (j < len) {
+    while (rem > 0u) {                                   // per-lane trip counts: lanes drop out, nothing is re-selected
+        const uint32_t m = rem < SUB ? rem : SUB;
+        double P = 0.0, Nn = 1.0, Q = 1.0;
+        double a = (double)(h.K - k), b = (double)(h.n - k), c = (double)(k + 1u), d = (double)(h.N - h.K - h.n + k + 1u);
+#pragma unroll 1
+        for (uint32_t j = 0; j < m; ++j) {
             const double num = a * b, den = c * d;
             Nn = Nn * num;
             Q = Q * den;
             P = fma(P, den, Nn);
             a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
         }
+        sum += term * P / Q;
+        term = term * Nn / Q;
+        k += m;
+        rem -= m;
     }
-    const double sum = t0 + t0 * P / Q;
     return (unsigned long long)(sum * 4611686018427387904.0);   // 2^62
 }
 
@@ -246,7 +257,7 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int 
     return ((unsigned long long)bcast32((uint32_t)(v >> 32), L) << 32) | bcast32((uint32_t)v, L);
 }
 
-__global__ __launch_bounds__(256) void k_perm_fast(
+__global__ __launch_bounds__(64) void k_perm_fast(
     uint64_t n_rows, const uint32_t* __restrict__ row_i, const uint32_t* __restrict__ row_j,
     const uint32_t* __restrict__ counts, const long long* __restrict__ G, const double* __restrict__ LF,
     uint32_t n_shuffles, uint64_t seed, double* __restrict__ out_p, uint32_t* __restrict__ out_exceed,
@@ -296,12 +307,13 @@ __global__ __launch_bounds__(256) void k_perm_fast(
         }
     }
     // ---- phase B: exact mass of the "as or more extreme" set, or of its complement when that is the short side.
-    //      Each row lists up to two ranges of k; the ranges are cut into units of 16 values and the units of the
+    //      Each row lists up to two ranges of k; the ranges are cut into units of 64 values and the units of the
     //      wave's 64 rows are dealt to the lanes 64 at a time, so every lane has the same amount of work whatever
     //      the rows' range lengths are.  Unit masses are integers (2^-62) added with LDS atomics: exact, any order.
-    __shared__ uint32_t s_pre[4][65];
-    __shared__ unsigned long long s_acc[4][64];
-    const uint32_t w = threadIdx.x >> 6;
+    // (one wave per workgroup: the barriers below cost nothing and no wave waits for another's rows)
+    __shared__ uint32_t s_pre[1][65];
+    __shared__ unsigned long long s_acc[1][64];
+    const uint32_t w = 0u;
     uint32_t start1 = 0, len1 = 0, start2 = 0, len2 = 0;
     if (kind == 2) {
 #if !(LGMI_PABL & 32)
@@ -734,7 +746,7 @@ void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const u
                  double* out_p, uint32_t* out_exceed, uint32_t* gen_list, unsigned int* gen_count)
 {
     if (!n_rows) return;
-    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, n_rows, out_i, out_j,
+    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)((n_rows + 63) / 64)), dim3(64), 0, st, n_rows, out_i, out_j,
                        counts, G, LF, n_shuffles, seed, out_p, out_exceed, gen_list, gen_count);
     // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
     // stride over the queued rows

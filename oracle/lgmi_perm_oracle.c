@@ -319,27 +319,37 @@ static double pmf22(const perm_tables* t, const hg22* h, uint32_t k)
 /* 64-way strided summation, the order the GPU wave uses: term number q of a run goes to
  * accumulator q % 64; the 64 accumulators are combined by an xor butterfly. */
 /* Exact mass of a range of k, as a 64-bit integer in units of 2^-62.  The range [k0, k0 + len) is cut into units
- * of UNIT = 16 consecutive values; a unit is summed in double precision — its first term from the log-factorials,
- * the following ones through the hypergeometric ratio  pmf(k+1) = pmf(k) (K-k)(n-k) / ((k+1)(N-K-n+k+1))  carried
- * division-free as (sum of terms) = t0 (1 + P / Q) with  N <- N num,  Q <- Q den,  P <- fma(P, den, N)  — and
+ * of UNIT = 64 consecutive values; a unit is summed in double precision — its first term from the log-factorials
+ * (one look-up of four table lines per 64 values), the following ones through the hypergeometric ratio
+ *     pmf(k+1) = pmf(k) (K-k)(n-k) / ((k+1)(N-K-n+k+1))
+ * carried division-free over sub-blocks of SUB = 16 steps:  N <- N num,  Q <- Q den,  P <- fma(P, den, N), then
+ * sum += t P / Q and t <- t N / Q (products of 16 factors below 2^52 stay inside the double range) — and
  * truncated to the fixed-point grid.  The mass of a range is the INTEGER sum of its units, so it does not depend
  * on how units are dealt to GPU lanes or in which order they are added. */
-#define UNIT 16
+#define UNIT 64
+#define SUB 16
 static uint64_t unit_mass(const perm_tables* t, const hg22* h, int64_t k0, int64_t len)
 {
-    const uint32_t ku = (uint32_t)k0;
-    const double t0 = pmf22(t, h, ku);
-    double P = 0.0, Nn = 1.0, Q = 1.0, sum;
-    double a = (double)(h->K - ku), b = (double)(h->n - ku), c = (double)(ku + 1u), d = (double)(h->N - h->K - h->n + ku + 1u);
-    int64_t j;
-    for (j = 1; j < len; ++j) {
-        const double num = a * b, den = c * d;
-        Nn = Nn * num;
-        Q = Q * den;
-        P = fma(P, den, Nn);
-        a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
+    uint32_t k = (uint32_t)k0;
+    double term = pmf22(t, h, k), sum = term;
+    int64_t rem = len - 1;
+    while (rem > 0) {
+        const int64_t m = rem < SUB ? rem : SUB;
+        double P = 0.0, Nn = 1.0, Q = 1.0;
+        double a = (double)(h->K - k), b = (double)(h->n - k), c = (double)(k + 1u), d = (double)(h->N - h->K - h->n + k + 1u);
+        int64_t j;
+        for (j = 0; j < m; ++j) {
+            const double num = a * b, den = c * d;
+            Nn = Nn * num;
+            Q = Q * den;
+            P = fma(P, den, Nn);
+            a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
+        }
+        sum += term * P / Q;
+        term = term * Nn / Q;
+        k += (uint32_t)m;
+        rem -= m;
     }
-    sum = t0 + t0 * P / Q;
     return (uint64_t)(sum * 4611686018427387904.0);   /* 2^62 */
 }
 
