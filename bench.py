@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # 3.93e13
 WORD_OP_LANE_OPS = 4                  # one 64-bit AND+POPC = 2 v_and_b32 + 2 v_bcnt_u32_b32
 MFMA_I8_PEAK_TOPS = 5000.0            # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (2.5 PF dense) per clock
+MFMA_FP4_PEAK_TOPS = 10000.0          # MI355X_MICROARCH.md: FP4/FP6 MFMA ~10 PF dense
 
 
 def pmc_traffic(workload, mfma=False):
@@ -202,15 +203,19 @@ def main():
                 'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12, 'unit': 'T word-ops/s (64-bit AND+POPC)',
                 'frac': word_ops / secs / (VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS)}
         if mfma:
-            # k_count_mfma: the four counts of a pair-word are 4 x 64 int8 multiply-accumulates = 512 ops
+            # matrix-core count kernels: the four counts of a pair-word are 4 x 64 multiply-accumulates = 512 ops
             ops = 512.0 * info['word_pairs']
-            out['roofline'] = {'kernel': 'k_count_mfma', 'bound': 'mfma', 'achieved': ops / secs / 1e12,
-                               'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s', 'op_kind': 'int8 multiply-add ops (tera-ops/s), dense MFMA peak',
-                               'frac': ops / secs / 1e12 / MFMA_I8_PEAK_TOPS, 'traffic': hbm['traffic'],
+            fp4 = info.get('mfma_dtype', 1) == 2
+            peak = MFMA_FP4_PEAK_TOPS if fp4 else MFMA_I8_PEAK_TOPS
+            out['roofline'] = {'kernel': 'k_count_mfma_fp4' if fp4 else 'k_count_mfma', 'bound': 'mfma',
+                               'achieved': ops / secs / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                               'op_kind': ('fp4 (e2m1)' if fp4 else 'int8') + ' multiply-add ops (tera-ops/s), dense MFMA peak',
+                               'frac': ops / secs / 1e12 / peak, 'traffic': hbm['traffic'],
                                'algorithmic_ops': ops,
                                'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2); '
-                                       'v_mfma_i32_32x32x32_i8, weighted-bit int8 operands made from the bit planes in registers '
-                                       '(one AND per operand dword)'}
+                                       + ('v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands and unit scales, exact in f32 below 2^24 reads; '
+                                          if fp4 else 'v_mfma_i32_32x32x32_i8; ')
+                                       + 'weighted-bit operands made from the bit planes in registers (AND / shift-AND per operand dword)'}
             out['hbm_roofline'] = hbm
         else:
             out['roofline'] = hbm

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LGMI_ABI_VERSION 1
+#define LGMI_ABI_VERSION 2
 
 /* error codes */
 #define LGMI_OK        0
@@ -142,7 +142,9 @@ typedef struct lgmi_run_info {
     float ms_perm;          /* permutation p-values                                */
     float ms_mean;          /* per-site mean MI                                    */
     uint32_t n_count_launches;
-    uint32_t n_mfma_tiles;  /* 128 x 128 tiles computed on the int8 matrix cores (0: VALU popcount only) */
+    uint32_t n_mfma_tiles;  /* 128 x 128 tiles computed on the matrix cores (0: VALU popcount only)      */
+    uint32_t mfma_dtype;    /* operand type of those tiles: 0 none, 1 int8, 2 fp4 (e2m1)                 */
+    uint32_t reserved;
 } lgmi_run_info;
 
 /* device-side synthetic chromosome generator (SURVEY 8d "dense" regime):

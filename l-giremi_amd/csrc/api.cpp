@@ -427,17 +427,20 @@ struct Plan {
     std::vector<BlockPlan> plans;
     std::vector<uint32_t> xlist, ylist;
     std::vector<SiteMap> smap;
+    bool mfma_fp4 = true;           // every matrix-core block has fewer than 2^24 reads: f32 accumulation is exact
     std::vector<Tile> tiles;        // 64 x 64 tiles for k_count (VALU popcount)
     std::vector<Tile> mtiles;       // 128 x 128 tiles for k_count_mfma (int8 matrix cores)
     uint64_t total_slots = 0, n_examined = 0, bytes_in = 0;
 };
 
 static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
-    int count_kernel_choice = 0;   // 0 auto, 1 VALU popcount only, 2 matrix cores only
+    int count_kernel_choice = 0;   // 0 auto, 1 VALU popcount only, 2 matrix cores only, 3 matrix cores with int8 operands only
     if (const char* e = getenv("LGMI_COUNT_KERNEL")) {
         if (!strcmp(e, "valu")) count_kernel_choice = 1;
         else if (!strcmp(e, "mfma")) count_kernel_choice = 2;
+        else if (!strcmp(e, "mfma_i8")) count_kernel_choice = 3;
     }
+    if (count_kernel_choice == 3) pl.mfma_fp4 = false;
     const uint64_t ns = db->d.n_sites;
     pl.smap.assign(ns, SiteMap{NONE, NONE, NONE, NONE, 0, 0});
     pl.plans.resize(db->d.n_blocks);
@@ -483,8 +486,9 @@ static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
         const uint32_t block_words = (db->block_n_reads[b] + 63u) / 64u;
         bool use_mfma = bp.nx >= 96 && bp.ny >= 96 && block_words >= 32;
         if (count_kernel_choice == 1) use_mfma = false;
-        if (count_kernel_choice == 2) use_mfma = true;
-        if (db->block_n_reads[b] >= (1u << 26)) use_mfma = false;   // its accumulators hold 64 * count in 32 bits
+        if (count_kernel_choice >= 2) use_mfma = true;
+        if (db->block_n_reads[b] >= (1u << 26)) use_mfma = false;   // the int8 kernel's accumulators hold 64 * count in 32 bits
+        if (use_mfma && db->block_n_reads[b] >= (1u << 24)) pl.mfma_fp4 = false;
         const uint32_t edge = use_mfma ? 128u : (uint32_t)TILE;
         std::vector<Tile>& out_tiles = use_mfma ? pl.mtiles : pl.tiles;
         // tiles: union band per `edge`-column group of each list
@@ -623,8 +627,9 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
 
     HIPCHK(hipEventRecord(ctx->ev[1], st));
-    launch_count_mfma(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols,
-                      db->d.d_cplanes, db->d.d_cplanes + db->d.n_pairs16, sN, sR, sC, sA);
+    (pl.mfma_fp4 ? launch_count_mfma_fp4 : launch_count_mfma)(
+        st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
+        db->d.d_cplanes + db->d.n_pairs16, sN, sR, sC, sA);
     launch_count(st, (uint32_t)pl.tiles.size(), d_tiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
                  sN, sR, sC, sA);
     HIPCHK(hipGetLastError());
@@ -686,6 +691,8 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     inf.bytes_out = n_rows * (16ull + (want_p ? 8ull : 0ull) + (want_counts ? 36ull : 0ull));
     inf.n_count_launches = (pl.tiles.empty() ? 0 : 1) + (pl.mtiles.empty() ? 0 : 1);
     inf.n_mfma_tiles = (uint32_t)std::min<size_t>(pl.mtiles.size(), 0xFFFFFFFFu);
+    inf.mfma_dtype = pl.mtiles.empty() ? 0u : (pl.mfma_fp4 ? 2u : 1u);
+    inf.reserved = 0;
     HIPCHK(hipEventElapsedTime(&inf.ms_prep, ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&inf.ms_count, ctx->ev[1], ctx->ev[2]));
     HIPCHK(hipEventElapsedTime(&inf.ms_emit, ctx->ev[2], ctx->ev[3]));

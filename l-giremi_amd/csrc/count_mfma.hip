@@ -28,36 +28,11 @@
 //   C/D:       reg r of lane l is D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
 // Which read a k index stands for is the same on both sides (byte j of dword q of half h, bit i: read
 // 128 h + 32 q + 8 j + i of the 256), which is all the sum over k needs.
-#include "lgmi_internal.h"
+#include "mfma_common.h"
 
 namespace lgmi {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ uint32_t xcd_remap_m(uint32_t b, uint32_t n) {
-    uint32_t q = n / 8, r = n % 8, xcd = b % 8, idx = b / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-struct MStageCol { const ulonglong2* base; uint32_t w0, w1; };
-
-__device__ __forceinline__ MStageCol m_col(uint32_t col, const Col* __restrict__ cols, const ulonglong2* __restrict__ cplanes) {
-    MStageCol sc;
-    if (col != NONE) {
-        const Col ci = cols[col];
-        sc.base = cplanes + ci.off - ci.w0; sc.w0 = ci.w0; sc.w1 = ci.w0 + ci.nw;
-    } else { sc.base = cplanes; sc.w0 = 1u; sc.w1 = 0u; }
-    return sc;
-}
-
-// words outside a column's band read the all-zero entry api.cpp keeps after the last column: the load stays
-// unconditional, so the loop has no branches and the compiler can count the loads in flight (s_waitcnt at
-// first use, not right after the issue)
-__device__ __forceinline__ uint4 m_ld_entry(const MStageCol& c, uint32_t k, const ulonglong2* __restrict__ zero) {
-    const ulonglong2* p = (k >= c.w0 && k < c.w1) ? c.base + k : zero;
-    return *reinterpret_cast<const uint4*>(p);
-}
 
 // bits of each byte reversed (bit i of byte b -> bit 7 - i of byte b)
 __device__ __forceinline__ uint32_t rev_in_bytes(uint32_t w) { return __builtin_bswap32(__brev(w)); }

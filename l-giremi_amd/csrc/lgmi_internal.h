@@ -82,6 +82,10 @@ void launch_count_mfma(hipStream_t st, uint32_t n_tiles, const Tile* tiles, cons
                        const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
                        const ulonglong2* cplanes, const ulonglong2* zero_entry, uint32_t* sN, uint32_t* sR,
                        uint32_t* sC, uint32_t* sA);
+void launch_count_mfma_fp4(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
+                           const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
+                           const ulonglong2* cplanes, const ulonglong2* zero_entry, uint32_t* sN, uint32_t* sR,
+                           uint32_t* sC, uint32_t* sA);
 
 // emit.hip
 struct EmitArgs {

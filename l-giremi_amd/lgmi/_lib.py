@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LGMI_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'liblgmi.so'))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, E_ARG, E_OOM, E_HIP, E_RCCL, E_NODEV, E_STATE, E_DOMAIN = 0, -1, -2, -3, -4, -5, -6, -7
 TYPE_MISMATCH, TYPE_SNP, TYPE_HET_SNP = 0, 1, 2
 UNIQUE_ID_BYTES = 128
@@ -41,7 +41,8 @@ class RunInfo(C.Structure):
                 ('word_pairs', C.c_uint64), ('bytes_in', C.c_uint64), ('bytes_out', C.c_uint64),
                 ('ms_total', C.c_float), ('ms_prep', C.c_float), ('ms_count', C.c_float),
                 ('ms_emit', C.c_float), ('ms_perm', C.c_float), ('ms_mean', C.c_float),
-                ('n_count_launches', C.c_uint32), ('n_mfma_tiles', C.c_uint32)]
+                ('n_count_launches', C.c_uint32), ('n_mfma_tiles', C.c_uint32),
+                ('mfma_dtype', C.c_uint32), ('reserved', C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}

@@ -32,7 +32,7 @@ def test_abi_version_and_struct_sizes():
     assert C.sizeof(_lib.Batch) == 88
     assert C.sizeof(_lib.Params) == 24
     assert C.sizeof(_lib.Result) == 88
-    assert C.sizeof(_lib.RunInfo) == 80
+    assert C.sizeof(_lib.RunInfo) == 88
     assert C.sizeof(_lib.SynthSpec) == 40
 
 

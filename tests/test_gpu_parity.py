@@ -321,8 +321,8 @@ def test_mip_column(engine):
     assert np.isnan(lgmi.mean_mi_to_mip([np.nan, np.nan], np.array(['het_snp', 'snp']), engine=engine)).all()
 
 
-# ---------------------------------------------------------------- the two count kernels (VALU popcount / int8 matrix cores)
-@pytest.mark.parametrize('kernel', ['valu', 'mfma'])
+# ---------------------------------------------------------------- the count kernels (VALU popcount / FP4 and int8 matrix cores)
+@pytest.mark.parametrize('kernel', ['valu', 'mfma', 'mfma_i8'])
 @pytest.mark.parametrize('seed', range(6))
 def test_both_count_kernels_match_oracle(engine, monkeypatch, kernel, seed):
     from oracle import c_oracle
@@ -338,7 +338,8 @@ def test_both_count_kernels_match_oracle(engine, monkeypatch, kernel, seed):
         ora = c_oracle.run(pb, min_common=3, het_only=het_only)
         res = engine.run(pb, min_common=3, het_only=het_only, emit_counts=True)
         assert_same_as_oracle(res, ora)
-        assert (res.info['n_mfma_tiles'] > 0) == (kernel == 'mfma')
+        assert (res.info['n_mfma_tiles'] > 0) == (kernel != 'valu')
+        assert res.info['mfma_dtype'] == {'valu': 0, 'mfma': 2, 'mfma_i8': 1}[kernel]
 
 
 def test_auto_kernel_choice_uses_matrix_cores_on_large_dense_blocks(engine):
@@ -348,7 +349,7 @@ def test_auto_kernel_choice_uses_matrix_cores_on_large_dense_blocks(engine):
     spec.tri_per_1024 = 100
     db = engine.synth_dense(spec)
     dr = engine.run_device(db, min_common=6, het_only=True, emit_counts=True)
-    assert dr.info()['n_mfma_tiles'] > 0
+    assert dr.info()['n_mfma_tiles'] > 0 and dr.info()['mfma_dtype'] == 2      # < 2^24 reads: FP4 operands
     res = dr.fetch()
     ora = c_oracle.run(db.download(), min_common=6, het_only=True)
     assert_same_as_oracle(res, ora)
