@@ -76,7 +76,13 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     LGMI_MFMA4(acc[1][0][2], O.a[2], O.b[1]); LGMI_MFMA4(acc[1][0][3], O.a[3], O.b[1]);                 \
     LGMI_MFMA4(acc[1][1][0], O.a[2], O.b[2]); LGMI_MFMA4(acc[1][1][1], O.a[3], O.b[2]);                 \
     LGMI_MFMA4(acc[1][1][2], O.a[2], O.b[3]); LGMI_MFMA4(acc[1][1][3], O.a[3], O.b[3]);
+#ifndef LGMI_ABL
+#define LGMI_ABL 0      // timing-only ablations (tools/abl_mfma.sh): 1 operands never rebuilt, 2 no loads at all, 4 no loads inside the loop
+#endif
     // operands of bit I (0..3) of every nibble (table in the header)
+#if LGMI_ABL & 1
+#define LGMI_OPS(O, R, I)
+#else
 #define LGMI_OPS(O, R, I)                                                                             \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
         if ((I) == 0) { O.a[q_] = R.x[q_] & 0x11111111; O.b[q_] = (R.y[q_] << 2) & 0x44444444; }         \
@@ -84,13 +90,18 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
         if ((I) == 2) { O.a[q_] = R.x[q_] & 0x44444444; O.b[q_] = (R.y[q_] >> 2) & 0x11111111; }         \
         if ((I) == 3) { O.a[q_] = (R.x[q_] >> 3) & 0x11111111; O.b[q_] = (R.y[q_] >> 1) & 0x44444444; }  \
     }
+#endif
     // the two words of this lane's half of column C at step word KW -> plane quads (C, A)
+#if LGMI_ABL & 2
+#define LGMI_LOAD2(QC, QA, C, KW) { QC = v4i{(int)(KW), 1, 2, 3}; QA = v4i{4, 5, (int)(KW), 7}; }
+#else
 #define LGMI_LOAD2(QC, QA, C, KW)                                                                     \
     {                                                                                                 \
         const uint4 e0_ = m_ld_entry(C, (KW), zero_entry), e1_ = m_ld_entry(C, (KW) + 1u, zero_entry);    \
         QC = v4i{(int)e0_.x, (int)e0_.y, (int)e1_.x, (int)e1_.y};                                       \
         QA = v4i{(int)e0_.z, (int)e0_.w, (int)e1_.z, (int)e1_.w};                                       \
     }
+#endif
     // one slot = the 16 MFMAs of a k-step with V VALU operations of the next k-step's preparation between them;
     // nothing moves across a slot boundary
 #define LGMI_SLOT_END(V)                                                                              \
@@ -102,17 +113,29 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     // One 256-read step of the CUR words (4 k-steps); the words two steps ahead are loaded into FAR during
     // slots 0 and 1, and slot 3 prepares bit 0 of the NXT words (loaded one step ago).
     // On entry P holds the operands of bit 0 of CUR; on exit those of NXT.
+#if LGMI_ABL & 4
+#define LGMI_LOADX(FAR, KW) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) FAR.x[q_] = FAR.x[q_] ^ (int)(KW);
+#define LGMI_LOADY(FAR, KW) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) FAR.y[q_] = FAR.y[q_] ^ (int)(KW);
+#else
+#define LGMI_LOADX(FAR, KW) LGMI_LOAD2(FAR.x[0], FAR.x[1], cx0, (KW)) LGMI_LOAD2(FAR.x[2], FAR.x[3], cx1, (KW))
+#define LGMI_LOADY(FAR, KW) LGMI_LOAD2(FAR.y[0], FAR.y[1], cy0, (KW)) LGMI_LOAD2(FAR.y[2], FAR.y[3], cy1, (KW))
+#endif
 #define LGMI_STEP(CUR, NXT, FAR, KW)                                                                  \
-    LGMI_LOAD2(FAR.x[0], FAR.x[1], cx0, (KW)) LGMI_LOAD2(FAR.x[2], FAR.x[3], cx1, (KW))                 \
+    LGMI_LOADX(FAR, KW)                                                                               \
     LGMI_OPS(Q, CUR, 1) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                                 \
-    LGMI_LOAD2(FAR.y[0], FAR.y[1], cy0, (KW)) LGMI_LOAD2(FAR.y[2], FAR.y[3], cy1, (KW))                 \
+    LGMI_LOADY(FAR, KW)                                                                               \
     LGMI_OPS(P, CUR, 2) LGMI_MFMA16(Q) LGMI_SLOT_END(5)                                                 \
     LGMI_OPS(Q, CUR, 3) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                                 \
     LGMI_OPS(P, NXT, 0) LGMI_MFMA16(Q) LGMI_SLOT_END(3)
 
     const uint32_t n_words = t.k1 - t.k0;
     const uint32_t n_trip = (n_words + 11u) / 12u;        // steps go three at a time; words past k1 are outside every band -> zeros
+    const uint32_t kw0_ = t.k0 + 2u * lh + 8u;
     Raw ra, rb, rc;
+#if LGMI_ABL & 4
+    LGMI_LOAD2(rc.x[0], rc.x[1], cx0, kw0_) LGMI_LOAD2(rc.x[2], rc.x[3], cx1, kw0_)
+    LGMI_LOAD2(rc.y[0], rc.y[1], cy0, kw0_) LGMI_LOAD2(rc.y[2], rc.y[3], cy1, kw0_)
+#endif
     Ops P, Q;
     uint32_t kw = t.k0 + 2u * lh;                         // first of this lane's two words of the step
     LGMI_LOAD2(ra.x[0], ra.x[1], cx0, kw) LGMI_LOAD2(ra.x[2], ra.x[3], cx1, kw)

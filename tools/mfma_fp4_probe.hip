@@ -52,6 +52,42 @@ __global__ __launch_bounds__(256) void rate(float* out, int iters) {
     if (s == 12345.f) out[0] = s;
 }
 
+// how many independent VALU operations fit under one FP4 MFMA: NV v_and/v_lshrrev per MFMA, 8 accumulators
+template <int NV>
+__global__ __launch_bounds__(256) void rate_valu(float* out, int iters, int seedv) {
+    v8i a = {0x22222222, 0x12121212, 0x41414141, 0x22222222, 0, 0, 0, 0};
+    v8i b = {0x11111111, 0x22222222, 0x44444444, 0x21212121, 0, 0, 0, 0};
+    v16f c[8];
+    int x[8];
+    for (int i = 0; i < 8; ++i) { c[i] = v16f{0}; x[i] = seedv + i * (int)threadIdx.x; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c[i], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) x[(i + v) & 7] = (x[(i + v) & 7] >> 1) & (0x11111111 + it);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += c[i][0] + (float)x[i];
+    if (s == 12345.f) out[0] = s;
+}
+
+template <int NV>
+static void run_rate_valu(float* dD, int blocks_per_cu) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000;
+    hipLaunchKernelGGL(rate_valu<NV>, dim3(256 * blocks_per_cu), dim3(256), 0, 0, dD, 10, 3);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(rate_valu<NV>, dim3(256 * blocks_per_cu), dim3(256), 0, 0, dD, iters, 3);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double mfmas = 256.0 * blocks_per_cu * 4 * 8 * iters;
+    printf("  %d waves/SIMD, %d x 2 VALU per MFMA: %.1f ms, cycles per MFMA per SIMD at 2.4 GHz: %.1f\n", blocks_per_cu, NV, ms, 2.4e9 * (ms * 1e-3) / (mfmas / 1024));
+}
+
 int main() {
     uint8_t hA[32 * 64], hB[64 * 32];
     float hD[1024], ref[1024];
@@ -82,5 +118,6 @@ int main() {
     const double mfmas = 256.0 * 4 * 4 * 8 * iters;
     printf("rate: %.1f ms, %.3g MFMA/s, %.2f POP/s (2*32*32*64 per MFMA), cycles per MFMA per SIMD at 2.4 GHz: %.1f\n", ms,
            mfmas / (ms * 1e-3), mfmas * 2 * 32 * 32 * 64 / (ms * 1e-3) / 1e15, 2.4e9 * (ms * 1e-3) / (mfmas / 1024));
+    for (int w = 1; w <= 2; ++w) { run_rate_valu<0>(dD, w); run_rate_valu<1>(dD, w); run_rate_valu<2>(dD, w); run_rate_valu<3>(dD, w); run_rate_valu<4>(dD, w); }
     return bad != 0;
 }
