@@ -564,6 +564,103 @@ __global__ __launch_bounds__(64) void k_perm_general(
             __syncthreads();
         }
 
+        // ---- 3 x 2 and 2 x 3 tables whose two real draws are "threshold table, then HRUA" for every possible
+        //      first result (the usual case: a tri-allelic site against a bi-allelic one at hundreds of reads or
+        //      more): the same draws, streams and arithmetic as the general state machine below, without its
+        //      generality — one begin (table draw + HRUA set-up) and one candidate per trip, the statistic in
+        //      closed form.  Anything else (urn-sized draws, draws that can be trivially determined, 3 x 3)
+        //      takes the general path.
+        bool simple = false;
+        if (tab_ok && nr * nc == 6) {
+            const uint32_t xlo = tab_klo, xhi = tab_klo + tab_n - 1u;
+            if (nr == 3) {
+                const uint32_t pop2 = N - R0;
+                simple = (C0 - xhi >= 10u) && (pop2 - (C0 - xlo) >= 10u) && (C0 - xlo < pop2);
+            } else {
+                const uint32_t pop2 = N - C0, m2 = C1 < pop2 - C1 ? C1 : pop2 - C1;
+                simple = (m2 >= 10u) && (R0 - xhi >= 1u) && (R0 - xlo < pop2);
+            }
+        }
+#if LGMI_PABL & 8192
+        simple = false;
+#endif
+        if (simple) {
+            const uint32_t pop2 = nr == 3 ? N - R0 : N - C0;
+            HrBase hb;                                   // nr == 3: the second draw's (pop, good) are the row's
+            hb.pop = 0u; hb.good = 0u; hb.d4 = 0.0; hb.cvar = 0.0; hb.c9 = 0.0;
+            if (nr == 3) hr_base(pop2, R1, hb);
+            uint32_t s_id = lane, call = 0u, exceed = 0u, x0 = 0u;
+            uint32_t good = 0u, sample = 0u, m = 0u, mn = 0u, mx = 0u;
+            double d6 = 0.0, d8 = 0.0, d10 = 0.0, d11 = 0.0;
+            int phase = s_id < n_shuffles ? 0 : 3;       // 0 begin, 1 HRUA candidates, 3 finished
+            for (;;) {
+                if (phase == 0) {
+                    // first draw: one 32-bit word, inverse CDF on the row's table (Philox call 0 of the shuffle)
+                    const U4 o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN, k0, k1);
+                    call = 1u;
+                    uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
+                    }
+                    x0 = tab_klo + lo;
+                    // second draw: HRUA set-up (the expressions of the general path)
+                    if (nr == 3) { good = R1; sample = C0 - x0; }
+                    else { good = R0 - x0; sample = C1; hr_base(pop2, good, hb); }
+                    const uint32_t bad = pop2 - good;
+                    m = sample < pop2 - sample ? sample : pop2 - sample;
+                    mn = good < bad ? good : bad;
+                    mx = good < bad ? bad : good;
+                    d6 = (double)m * hb.d4 + 0.5;
+                    const double d7 = det_sqrt((double)(pop2 - m) * (double)m * hb.cvar + 0.5);
+                    const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
+                    d10 = LF[d9] + LF[mn - d9] + LF[m - d9] + LF[mx - m + d9];
+                    d8 = HRUA_D1 * d7 + HRUA_D2;
+                    const double cap = (double)((m < mn ? m : mn) + 1u);
+                    const double lim = floor(d6 + 16.0 * d7);
+                    d11 = cap < lim ? cap : lim;
+                    phase = 1;
+                }
+                if (phase == 1) {
+                    const U4 o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN + call, k0, k1);
+                    call++;
+                    const double x = ((double)o.x + 0.5) * 2.3283064365386963e-10;
+                    const double y = ((double)o.y + 0.5) * 2.3283064365386963e-10;
+                    const double w = d6 + d8 * (y - 0.5) / x;
+                    if (!(w < 0.0 || w >= d11)) {
+                        const uint32_t zc = (uint32_t)floor(w);
+                        const double tt = d10 - (LF[zc] + LF[mn - zc] + LF[m - zc] + LF[mx - m + zc]);
+                        bool acc = (x * (4.0 - x) - 3.0 <= tt);
+                        if (!acc && !(x * (x - tt) >= 1.0)) acc = (x * x <= det_exp(tt));   // 2 ln x <= tt
+                        if (acc) {
+                            uint32_t z = zc;
+                            if (good > pop2 - good) z = m - z;       // z counted the minority kind
+                            if (m < sample) z = good - z;            // drew the complement
+                            long long ss;
+                            if (nr == 3) {
+                                const uint32_t x2 = C0 - x0 - z;
+                                ss = G[x0] + G[z] + G[x2] + G[R0 - x0] + G[R1 - z] + G[R2 - x2];
+                            } else {
+                                const uint32_t t02 = R0 - x0 - z;
+                                ss = G[x0] + G[C0 - x0] + G[z] + G[C1 - z] + G[t02] + G[R1 - (C0 - x0) - (C1 - z)];
+                            }
+                            exceed += (ss >= sobs);
+                            s_id = atomicAdd(&next_s, 1u);
+                            phase = s_id < n_shuffles ? 0 : 3;
+                        }
+                    }
+                }
+                if (!__any(phase != 3)) break;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) exceed += __shfl_xor(exceed, o);
+            if (lane == 0) {
+                out_exceed[r] = exceed;
+                out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+            }
+            continue;
+        }
+
         GState g;
         g.s = lane; g.phase = 3; g.call = 0; g.d = 0; g.ss = 0;
         g.rr0 = 0; g.rr1 = 0; g.pop_all = 0; g.cc = 0; g.pop = 0; g.xa = 0;
