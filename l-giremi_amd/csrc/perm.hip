@@ -525,14 +525,24 @@ __global__ __launch_bounds__(64) void k_perm_general(
                 const uint32_t e0 = lane * seg < tab_n ? lane * seg : tab_n;
                 const uint32_t e1 = e0 + seg < tab_n ? e0 + seg : tab_n;
                 unsigned long long loc = 0ull;         // running sum of pmf * 2^52 inside the lane's segment
-                for (uint32_t e = e0; e < e1; ++e) {
-                    const uint32_t k = tab_klo + e;
+                double pm = 0.0;
+                if (e0 < e1) {                         // first entry of the segment: from the log-factorials
+                    const uint32_t k = tab_klo + e0;
                     double x = c0;
                     x -= LF[k];
                     x -= LF[good - k];
                     x -= LF[sample - k];
                     x -= LF[pop - good - sample + k];
-                    loc += (unsigned long long)(det_exp(x) * 4503599627370496.0);
+                    pm = det_exp(x);
+                    loc = (unsigned long long)(pm * 4503599627370496.0);
+                    tab_thr[e0] = (uint32_t)(loc >> 20);
+                }
+                for (uint32_t e = e0 + 1u; e < e1; ++e) {   // the others: by the hypergeometric ratio
+                    const uint32_t k = tab_klo + e;
+                    const double num = (double)(good - k + 1u) * (double)(sample - k + 1u);
+                    const double den = (double)k * (double)(pop - good - sample + k);
+                    pm = pm * num / den;
+                    loc += (unsigned long long)(pm * 4503599627370496.0);
                     tab_thr[e] = (uint32_t)(loc >> 20);
                 }
                 unsigned long long incl = loc;         // inclusive scan of the segment totals over the lanes

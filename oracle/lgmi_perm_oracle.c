@@ -163,7 +163,8 @@ static const double HRUA_D2 = 0.8989161620588988;   /* 3 - 2*sqrt(3/e) */
  * drawn by inverse CDF instead of rejection: one 32-bit Philox word u, result = the smallest k of the window
  * with u < thr[k - klo] (the last k of the window when there is none: the window misses < 1e-10 of the mass).
  * The thresholds are integer prefix sums, so they do not depend on the order of the additions:
- *     q[e]   = trunc(pmf(klo + e) * 2^52)                                 (u64)
+ *     q[e]   = trunc(pmf(klo + e) * 2^52)                                 (u64; pmf from the log-factorials at the
+ *              first entry of a segment, then by the ratio pmf(k) = pmf(k-1) (good-k+1)(sample-k+1)/(k (pop-good-sample+k)))
  *     the window is cut into 64 contiguous segments of seg = ceil(n / 64) entries (one per GPU lane);
  *     thr[e] = min(2^32 - 1, (sum of q over the entries of e's segment up to e) >> 20
  *                            + (sum of q over all earlier segments) >> 20)
@@ -200,15 +201,25 @@ static void first_table_build(const perm_tables* t, uint32_t pop, uint32_t good,
     seg = (ft->n + 63u) / 64u;
     for (l = 0; l < 64; ++l) {
         uint64_t loc = 0;
+        double pm = 0.0;
         for (e = l * seg; e < ft->n && e < (l + 1) * seg; ++e) {
             const uint32_t k = ft->klo + e;
             uint64_t thr;
-            double x = c0;
-            x -= t->LF[k];
-            x -= t->LF[good - k];
-            x -= t->LF[sample - k];
-            x -= t->LF[pop - good - sample + k];
-            loc += (uint64_t)(lgo_det_exp(x) * 4503599627370496.0);
+            if (e == l * seg) {
+                /* first entry of a segment: from the log-factorials */
+                double x = c0;
+                x -= t->LF[k];
+                x -= t->LF[good - k];
+                x -= t->LF[sample - k];
+                x -= t->LF[pop - good - sample + k];
+                pm = lgo_det_exp(x);
+            } else {
+                /* the others: pmf(k) = pmf(k-1) (good-k+1)(sample-k+1) / (k (pop-good-sample+k)) */
+                const double num = (double)(good - k + 1u) * (double)(sample - k + 1u);
+                const double den = (double)k * (double)(pop - good - sample + k);
+                pm = pm * num / den;
+            }
+            loc += (uint64_t)(pm * 4503599627370496.0);
             thr = (uint64_t)(uint32_t)(loc >> 20) + (earlier >> 20);
             ft->thr[e] = thr >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
         }
