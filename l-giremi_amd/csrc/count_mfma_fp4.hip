@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
 
     const uint32_t n_words = t.k1 - t.k0;
     const uint32_t n_trip = (n_words + 11u) / 12u;        // steps go three at a time; words past k1 are outside every band -> zeros
-    const uint32_t kw0_ = t.k0 + 2u * lh + 8u;
     Raw ra, rb, rc;
 #if LGMI_ABL & 4
+    const uint32_t kw0_ = t.k0 + 2u * lh + 8u;
     LGMI_LOAD2(rc.x[0], rc.x[1], cx0, kw0_) LGMI_LOAD2(rc.x[2], rc.x[3], cx1, kw0_)
     LGMI_LOAD2(rc.y[0], rc.y[1], cy0, kw0_) LGMI_LOAD2(rc.y[2], rc.y[3], cy1, kw0_)
 #endif
