@@ -357,6 +357,27 @@ def test_auto_kernel_choice_uses_matrix_cores_on_large_dense_blocks(engine):
     db.free()
 
 
+@pytest.mark.parametrize('n_reads,dtype', [(2 ** 24 - 64, 2), (2 ** 24 + 64, 1)])
+def test_matrix_core_kernels_at_the_exactness_limit(engine, n_reads, dtype):
+    """a block just below 2^24 reads runs on the FP4 matrix cores (f32 sums of {0,1} products, exact below 2^24:
+    the common-read counts here reach ~13.6 million, far above 2^23 where f32 spacing becomes 1); just above,
+    the int8 kernel (exact int32 sums) takes over.  Counts must match the CPU oracle bit for bit either way."""
+    import lgmi
+    from oracle import c_oracle
+    spec = lgmi.default_synth_spec(200, n_reads, seed=11)
+    spec.tri_per_1024 = 60
+    db = engine.synth_dense(spec)
+    dr = engine.run_device(db, min_common=6, het_only=False, emit_counts=True)      # 200 x 200: enough rows for a matrix-core tile
+    info = dr.info()
+    assert info['n_mfma_tiles'] > 0 and info['mfma_dtype'] == dtype
+    res = dr.fetch()
+    assert res.row_counts.reshape(-1, 9).sum(axis=1).max() > 2 ** 23
+    ora = c_oracle.run(db.download(), min_common=6, het_only=False)
+    assert_same_as_oracle(res, ora)
+    dr.free()
+    db.free()
+
+
 # ---------------------------------------------------------------- API robustness
 def test_bad_arguments_are_rejected(engine):
     import ctypes as C
