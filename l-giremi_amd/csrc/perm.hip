@@ -417,14 +417,23 @@ __global__ __launch_bounds__(64) void k_perm_fast(
 #define HRUA_D1 1.7155277699214135
 #define HRUA_D2 0.8989161620588988
 
-struct HrBase { uint32_t pop, good; double d4, cvar, c9; };   // the three quotients of a (pop, good)
+// the three quotients of a (pop, good), as products with the reciprocals of pop, pop - 1, pop + 2: most draws of
+// a row share the population size, so the divisions happen once per row, not once per draw
+struct HrRecip { uint32_t pop; double rp, rp1, rp2; };
+struct HrBase { uint32_t pop, good; double d4, cvar, c9; };
 
-__device__ __forceinline__ void hr_base(uint32_t pop, uint32_t good, HrBase& b) {
-    const uint32_t bad = pop - good, mn = good < bad ? good : bad;
-    b.pop = pop; b.good = good;
-    b.d4 = (double)mn / (double)pop;
-    b.cvar = b.d4 * (1.0 - b.d4) / (double)(pop - 1u);
-    b.c9 = (double)(mn + 1u) / ((double)pop + 2.0);
+__device__ __forceinline__ void hr_recip(uint32_t pop, HrRecip& r) {
+    r.pop = pop;
+    r.rp = 1.0 / (double)pop;
+    r.rp1 = 1.0 / (double)(pop - 1u);
+    r.rp2 = 1.0 / ((double)pop + 2.0);
+}
+__device__ __forceinline__ void hr_base(const HrRecip& r, uint32_t good, HrBase& b) {      // r holds the reciprocals of b's pop
+    const uint32_t bad = r.pop - good, mn = good < bad ? good : bad;
+    b.pop = r.pop; b.good = good;
+    b.d4 = (double)mn * r.rp;
+    b.cvar = b.d4 * (1.0 - b.d4) * r.rp1;
+    b.c9 = (double)(mn + 1u) * r.rp2;
 }
 
 struct GState {
@@ -490,6 +499,8 @@ __global__ __launch_bounds__(64) void k_perm_general(
         HrBase base0, base1;   // quotient caches for row-0 and row-1 draws (hits in the first column)
         base0.pop = 0u; base0.good = 0u; base0.d4 = 0.0; base0.cvar = 0.0; base0.c9 = 0.0;
         base1 = base0;
+        HrRecip rcp;           // reciprocals of the population size last seen by either
+        rcp.pop = 0u; rcp.rp = 0.0; rcp.rp1 = 0.0; rcp.rp2 = 0.0;
 
         // ---- per-row threshold table of the first draw (wave-uniform control flow; integer prefix sums, so the
         //      result does not depend on the order of the additions — see the CPU specification)
@@ -596,9 +607,11 @@ __global__ __launch_bounds__(64) void k_perm_general(
 #endif
         if (simple) {
             const uint32_t pop2 = nr == 3 ? N - R0 : N - C0;
-            HrBase hb;                                   // nr == 3: the second draw's (pop, good) are the row's
-            hb.pop = 0u; hb.good = 0u; hb.d4 = 0.0; hb.cvar = 0.0; hb.c9 = 0.0;
-            if (nr == 3) hr_base(pop2, R1, hb);
+            HrRecip rc2;                                 // the second draw's population is the row's; nr == 3: its good too
+            hr_recip(pop2, rc2);
+            HrBase hb;
+            hb.pop = pop2; hb.good = 0u; hb.d4 = 0.0; hb.cvar = 0.0; hb.c9 = 0.0;
+            if (nr == 3) hr_base(rc2, R1, hb);
             uint32_t s_id = lane, call = 0u, exceed = 0u, x0 = 0u;
             uint32_t good = 0u, sample = 0u, m = 0u, mn = 0u, mx = 0u;
             double d6 = 0.0, d8 = 0.0, d10 = 0.0, d11 = 0.0;
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     x0 = tab_klo + lo;
                     // second draw: HRUA set-up (the expressions of the general path)
                     if (nr == 3) { good = R1; sample = C0 - x0; }
-                    else { good = R0 - x0; sample = C1; hr_base(pop2, good, hb); }
+                    else { good = R0 - x0; sample = C1; hr_base(rc2, good, hb); }
                     const uint32_t bad = pop2 - good;
                     m = sample < pop2 - sample ? sample : pop2 - sample;
                     mn = good < bad ? good : bad;
@@ -811,9 +824,12 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     } else {
                         HrBase& hb = (g.d & 1) ? base1 : base0;
 #if LGMI_PABL & 2048
-                        if (hb.pop == 0u) hr_base(pop, good, hb);
+                        if (hb.pop == 0u) { hr_recip(pop, rcp); hr_base(rcp, good, hb); }
 #else
-                        if (hb.pop != pop || hb.good != good) hr_base(pop, good, hb);
+                        if (hb.pop != pop || hb.good != good) {
+                            if (rcp.pop != pop) hr_recip(pop, rcp);
+                            hr_base(rcp, good, hb);
+                        }
 #endif
                         g.mn = good < bad ? good : bad;
                         g.mx = good < bad ? bad : good;

@@ -266,9 +266,12 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
     } else {
         const uint32_t mn = good < bad ? good : bad, mx = good < bad ? bad : good;
         /* the three quotients depend on (pop, good) only: the kernel keeps them across shuffles */
-        const double d4 = (double)mn / (double)pop;
-        const double cvar = d4 * (1.0 - d4) / (double)(pop - 1);
-        const double c9 = (double)(mn + 1) / ((double)pop + 2.0);
+        /* quotients by pop, pop - 1, pop + 2 as products with their reciprocals: within a row most draws share
+         * the population size, so the GPU keeps the three reciprocals and never divides per draw */
+        const double rp = 1.0 / (double)pop, rp1 = 1.0 / (double)(pop - 1), rp2 = 1.0 / ((double)pop + 2.0);
+        const double d4 = (double)mn * rp;
+        const double cvar = d4 * (1.0 - d4) * rp1;
+        const double c9 = (double)(mn + 1) * rp2;
         const double d6 = (double)m * d4 + 0.5;
         const double d7 = lgo_det_sqrt((double)(pop - m) * (double)m * cvar + 0.5);
         const double d8 = HRUA_D1 * d7 + HRUA_D2;
