@@ -177,14 +177,16 @@ __device__ __forceinline__ unsigned long long unit_mass(const double* __restrict
     while (rem > 0u) {                                   // per-lane trip counts: lanes drop out, nothing is re-selected
         const uint32_t m = rem < SUB ? rem : SUB;
         double P = 0.0, Nn = 1.0, Q = 1.0;
-        double a = (double)(h.K - k), b = (double)(h.n - k), c = (double)(k + 1u), d = (double)(h.N - h.K - h.n + k + 1u);
+        // num = (K-k)(n-k) and den = (k+1)(N-K-n+k+1) step by second differences: integers below 2^53, so the
+        // sums are the same doubles as the products the specification writes
+        const double a = (double)(h.K - k), b = (double)(h.n - k), c = (double)(k + 1u), d = (double)(h.N - h.K - h.n + k + 1u);
+        double num = a * b, den = c * d, sn = a + b - 1.0, sd = c + d + 1.0;
 #pragma unroll 1
         for (uint32_t j = 0; j < m; ++j) {
-            const double num = a * b, den = c * d;
             Nn = Nn * num;
             Q = Q * den;
             P = fma(P, den, Nn);
-            a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
+            num -= sn; den += sd; sn -= 2.0; sd += 2.0;
         }
         sum += term * P / Q;
         term = term * Nn / Q;
