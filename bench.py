@@ -186,7 +186,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'u64 bit-planes / u32 counts / f64 MI', 'data': 'synthetic',
+            'dtype': {2: 'u64 bit planes -> fp4 (e2m1) MFMA operands, f32 counts (exact < 2^24), f64 MI',
+                      1: 'u64 bit planes -> int8 MFMA operands, i32 counts, f64 MI'}.get(
+                          info.get('mfma_dtype', 0), 'u64 bit planes (AND + popcount), u32 counts, f64 MI'),
+            'data': 'synthetic',
             'config': {'workload': args.workload, 'n_sites': wl['n_sites'], 'n_reads': wl['n_reads'],
                        'regime': wl.get('regime', 'dense'), 'het_every': 5, 'min_common': args.min_common,
                        'n_shuffles': args.shuffles, 'examined_pairs_per_gpu': examined,
@@ -194,6 +197,10 @@ def main():
             'stage_ms': {k: sum(i[k] for i in infos) / len(infos)
                          for k in ('ms_total', 'ms_prep', 'ms_count', 'ms_emit', 'ms_perm', 'ms_mean')},
         }
+        # emitted pairs/s and pair-shuffles/s beside the examined-pair rate (whole job)
+        rows_all = sum(info.get('world_rows', [info['n_rows']]))
+        out['rates'] = {'emitted_pairs_per_s': rows_all * args.steps / elapsed,
+                        'pair_shuffles_per_s': rows_all * args.shuffles * args.steps / elapsed}
         hbm = {'kernel': 'count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes, 'achieved': alg_bytes / secs / 1e9,
                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
                'traffic': pmc_traffic(args.workload, mfma),
