@@ -429,7 +429,8 @@ struct Plan {
     std::vector<SiteMap> smap;
     bool mfma_fp4 = true;           // every matrix-core block has fewer than 2^24 reads: f32 accumulation is exact
     std::vector<Tile> tiles;        // 64 x 64 tiles for k_count (VALU popcount)
-    std::vector<Tile> mtiles;       // 128 x 128 tiles for k_count_mfma (int8 matrix cores)
+    std::vector<Tile> mtiles;       // 128 x 128 tiles for the matrix-core count kernels
+    std::vector<uint2> items;       // emit work items: (site, segment of EMIT_SEG partners), in row order
     uint64_t total_slots = 0, n_examined = 0, bytes_in = 0;
 };
 
@@ -477,8 +478,11 @@ static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
         pl.total_slots += (uint64_t)bp.nx * bp.ny_pad;
         pl.plans[b] = bp;
         // examined pairs: pairs a wave of the emit kernel will look at
-        for (uint32_t s = sb; s < se; ++s)
-            pl.n_examined += (pl.smap[s].xrow != NONE) ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
+        for (uint32_t s = sb; s < se; ++s) {
+            const uint32_t ncand = (pl.smap[s].xrow != NONE) ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
+            pl.n_examined += ncand;
+            for (uint32_t g = 0; g * EMIT_SEG < ncand; ++g) pl.items.push_back(make_uint2(s, g));
+        }
         if (bp.nx == 0) continue;
         // which count kernel: the matrix-core kernel pays off on blocks with many columns and many reads
         // (its 128 x 128 tile has a 256-store epilogue per lane); small or shallow blocks keep the
@@ -575,7 +579,8 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     Plan pl;
     build_plan(db, prm->het_only != 0, pl);
-    if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull) return fail(LGMI_E_ARG, "too many tiles");
+    if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull || pl.items.size() >= 0x7FFFFFFFull)
+        return fail(LGMI_E_ARG, "too many tiles");
 
     lgmi_dresult* res = new lgmi_dresult();
     res->ctx = ctx;
@@ -590,11 +595,12 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     } guard{pool, scratch, res};
     auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
 
-    BlockPlan* d_plans; uint32_t* d_xlist; uint32_t* d_ylist; SiteMap* d_smap; Tile* d_tiles; Tile* d_mtiles;
+    BlockPlan* d_plans; uint32_t* d_xlist; uint32_t* d_ylist; SiteMap* d_smap; Tile* d_tiles; Tile* d_mtiles; uint2* d_items;
     uint32_t *sN, *sR, *sC, *sA, *d_rowcnt; uint64_t* d_rowstart; unsigned long long* d_sum; uint32_t* d_cnt;
     int* d_err; unsigned long long* d_wordpairs;
     if ((rc = salloc((void**)&d_plans, pl.plans.size() * sizeof(BlockPlan)))) return rc;
     if ((rc = salloc((void**)&d_xlist, pl.xlist.size() * 4))) return rc;
+    if ((rc = salloc((void**)&d_items, std::max<size_t>(pl.items.size(), 1) * sizeof(uint2)))) return rc;
     if ((rc = salloc((void**)&d_ylist, pl.ylist.size() * 4))) return rc;
     if ((rc = salloc((void**)&d_smap, pl.smap.size() * sizeof(SiteMap)))) return rc;
     if ((rc = salloc((void**)&d_tiles, pl.tiles.size() * sizeof(Tile)))) return rc;
@@ -603,8 +609,9 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if ((rc = salloc((void**)&sR, pl.total_slots * 4))) return rc;
     if ((rc = salloc((void**)&sC, pl.total_slots * 4))) return rc;
     if ((rc = salloc((void**)&sA, pl.total_slots * 4))) return rc;
-    if ((rc = salloc((void**)&d_rowcnt, (size_t)ns * 4))) return rc;
-    if ((rc = salloc((void**)&d_rowstart, ((size_t)ns + 1) * 8))) return rc;
+    const size_t n_items = pl.items.size();
+    if ((rc = salloc((void**)&d_rowcnt, std::max<size_t>(n_items, 1) * 4))) return rc;
+    if ((rc = salloc((void**)&d_rowstart, (n_items + 1) * 8))) return rc;
     if ((rc = salloc((void**)&d_sum, (size_t)ns * 8))) return rc;
     if ((rc = salloc((void**)&d_cnt, (size_t)ns * 4 + 16))) return rc;
     d_err = (int*)(d_cnt + ns);
@@ -618,6 +625,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     };
     HIPCHK(h2d(d_plans, pl.plans.data(), pl.plans.size() * sizeof(BlockPlan)));
     HIPCHK(h2d(d_xlist, pl.xlist.data(), pl.xlist.size() * 4));
+    HIPCHK(h2d(d_items, pl.items.data(), pl.items.size() * sizeof(uint2)));
     HIPCHK(h2d(d_ylist, pl.ylist.data(), pl.ylist.size() * 4));
     HIPCHK(h2d(d_smap, pl.smap.data(), pl.smap.size() * sizeof(SiteMap)));
     HIPCHK(h2d(d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)));
@@ -640,13 +648,14 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     ea.plans = d_plans; ea.smap = d_smap; ea.xlist = d_xlist; ea.cols = db->d.d_cols;
     ea.type = db->d.d_type; ea.tri = db->d.d_tri;
     ea.sN = sN; ea.sR = sR; ea.sC = sC; ea.sA = sA;
+    ea.n_items = (uint32_t)n_items; ea.items = d_items;
     ea.row_cnt = d_rowcnt; ea.row_start = d_rowstart;
     ea.site_sum = d_sum; ea.site_cnt = d_cnt; ea.err_flag = d_err; ea.word_pairs = d_wordpairs;
     launch_emit_count(st, ea);
-    launch_scan(st, d_rowcnt, d_rowstart, ns);
+    launch_scan(st, d_rowcnt, d_rowstart, (uint32_t)n_items);
     HIPCHK(hipGetLastError());
     uint64_t n_rows = 0;
-    HIPCHK(hipMemcpyAsync(&n_rows, d_rowstart + ns, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&n_rows, d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     res->n_rows = n_rows;
     const size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);

@@ -47,9 +47,11 @@ __device__ __forceinline__ double mi_from_table(const uint32_t t[9]) {
 template <int PASS>
 __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (i >= a.n_sites) return;
+    __shared__ uint32_t cstage[4][64 * 9];          // pass 2: one wave's 3 x 3 tables, row-major, before the coalesced store
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * 4u + wv;
+    if (item >= a.n_items) return;
+    const uint32_t i = a.items[item].x, seg = a.items[item].y;
     const SiteMap mi_ = a.smap[i];
     const BlockPlan bp = a.plans[mi_.block];
     const bool i_in_x = (mi_.xrow != NONE);
@@ -68,15 +70,16 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
     unsigned long long wsum = 0ull;
     uint64_t base_row = 0;
     unsigned long long my_sum = 0ull;
-    if (PASS == 2) base_row = a.row_start[i];
+    if (PASS == 2) base_row = a.row_start[item];
+    const uint32_t q_end = min(ncand, (seg + 1u) * EMIT_SEG);
 
-    for (uint32_t qb = 0; qb < ncand; qb += 64u) {
+    for (uint32_t qb = seg * EMIT_SEG; qb < q_end; qb += 64u) {
         const uint32_t q = qb + lane;
         bool valid = false;
         uint32_t j = 0, n_common = 0;
         uint64_t slot = 0;
         SiteMap mj;
-        if (q < ncand) {
+        if (q < q_end) {
             j = i_in_x ? (i + 1u + q) : a.xlist[bp.xl_off + q0 + q];
             const Col cj = a.cols[j];
             const uint32_t lo = max(i_w0, cj.w0), hi = min(i_w1, cj.w0 + cj.nw);
@@ -148,14 +151,24 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
                 a.out_i[r] = i;
                 a.out_j[r] = j;
                 a.out_mi[r] = mi;
-                if (a.out_counts) {
+                if (a.out_counts) {     // staged through LDS below: 9 dwords per row at a 36-byte stride are partial-line stores
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) a.out_counts[9 * r + k] = T[k];
+                    for (int k = 0; k < 9; ++k) cstage[wv][9u * prefix + k] = T[k];
                 }
                 const unsigned long long fx = (unsigned long long)__double2ll_rn(mi * MEAN_SCALE);
                 my_sum += fx;
                 atomicAdd(&a.site_sum[j], fx);
                 atomicAdd(&a.site_cnt[j], 1u);
+            }
+            if (a.out_counts) {
+                // the valid lanes' tables are consecutive rows: write them as one contiguous run, 64 dwords per store
+                const uint32_t n_dw = 9u * (uint32_t)__popcll(ball);
+                uint32_t* dst = a.out_counts + 9ull * (base_row + running);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const uint32_t idx = 64u * k + lane;
+                    if (idx < n_dw) dst[idx] = cstage[wv][idx];
+                }
             }
             running += (uint32_t)__popcll(ball);
         }
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
         if (lane == 0) {
-            a.row_cnt[i] = running;
+            a.row_cnt[item] = running;
             if (wsum) atomicAdd(a.word_pairs, wsum);
         }
     } else {
@@ -179,12 +192,12 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
 }
 
 void launch_emit_count(hipStream_t st, const EmitArgs& a) {
-    if (!a.n_sites) return;
-    hipLaunchKernelGGL(k_emit<1>, dim3((a.n_sites + 3) / 4), dim3(256), 0, st, a);
+    if (!a.n_items) return;
+    hipLaunchKernelGGL(k_emit<1>, dim3((a.n_items + 3) / 4), dim3(256), 0, st, a);
 }
 void launch_emit_write(hipStream_t st, const EmitArgs& a) {
-    if (!a.n_sites) return;
-    hipLaunchKernelGGL(k_emit<2>, dim3((a.n_sites + 3) / 4), dim3(256), 0, st, a);
+    if (!a.n_items) return;
+    hipLaunchKernelGGL(k_emit<2>, dim3((a.n_items + 3) / 4), dim3(256), 0, st, a);
 }
 
 // exclusive scan of n u32 counts into n+1 u64 offsets; one workgroup, each thread

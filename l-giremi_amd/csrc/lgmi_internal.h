@@ -99,13 +99,18 @@ struct EmitArgs {
     const uint8_t* type;
     const uint8_t* tri;
     const uint32_t* sN; const uint32_t* sR; const uint32_t* sC; const uint32_t* sA;
-    uint32_t* row_cnt;        // [n_sites]   pass 1 out
-    const uint64_t* row_start;// [n_sites+1] pass 2 in
+    // work items of the two emit passes: a site row is cut into segments of EMIT_SEG partners so that the long
+    // rows of x sites (up to the whole block) spread over many waves; items are in (site, segment) order
+    uint32_t n_items;
+    const uint2* items;       // [n_items] (site, segment)
+    uint32_t* row_cnt;        // [n_items]   pass 1 out
+    const uint64_t* row_start;// [n_items+1] pass 2 in
     uint32_t* out_i; uint32_t* out_j; double* out_mi; uint32_t* out_counts; // pass 2 out
     unsigned long long* site_sum; uint32_t* site_cnt;  // [n_sites] fixed-point sums
     int* err_flag;            // set to 1 when a pair with N == 0 reaches the MI
     unsigned long long* word_pairs;  // pass 1: sum over examined pairs of overlapping words
 };
+static const uint32_t EMIT_SEG = 8192;   // multiple of 64
 void launch_emit_count(hipStream_t st, const EmitArgs& a);
 void launch_scan(hipStream_t st, const uint32_t* cnt, uint64_t* start, uint32_t n);
 void launch_emit_write(hipStream_t st, const EmitArgs& a);
