@@ -342,6 +342,25 @@ def test_both_count_kernels_match_oracle(engine, monkeypatch, kernel, seed):
         assert res.info['mfma_dtype'] == {'valu': 0, 'mfma': 2, 'mfma_i8': 1}[kernel]
 
 
+def test_mixed_batch_uses_both_kinds_of_count_kernel(engine):
+    """one run whose blocks go to different count kernels (a large dense block on the matrix cores, small and
+    banded blocks on the VALU popcount kernel): rows, counts and means must match the oracle across the seams"""
+    from oracle import c_oracle
+    from util_synth import pack_class_matrix, random_block
+    rng = np.random.Generator(np.random.PCG64(4242))
+    blocks = [random_block(rng, 30, 150, tri_frac=0.2, het_frac=0.4),
+              random_block(rng, 260, 4200, tri_frac=0.1, het_frac=0.5),
+              random_block(rng, 120, 900, banded=True, tri_frac=0.1, het_frac=0.3),
+              random_block(rng, 3, 40, het_frac=1.0)]
+    pb = pack_class_matrix(blocks)
+    for het_only in (True, False):
+        ora = c_oracle.run(pb, min_common=4, het_only=het_only, n_shuffles=40, seed=17)
+        res = engine.run(pb, min_common=4, het_only=het_only, emit_counts=True, n_shuffles=40, seed=17)
+        assert_same_as_oracle(res, ora)
+        assert_perm_same(res, ora, 40)
+        assert res.info['n_mfma_tiles'] > 0 and res.info['n_count_launches'] == 2
+
+
 def test_auto_kernel_choice_uses_matrix_cores_on_large_dense_blocks(engine):
     import lgmi
     from oracle import c_oracle
