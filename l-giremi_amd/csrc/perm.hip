@@ -443,6 +443,8 @@ struct GState {
     uint32_t call;
     // table being drawn
     uint32_t s, rr0, rr1, pop_all, cc, pop, xa;
+    uint32_t sp1, sp2;     // words 1, 2 of the threshold-table draw's call: the next pair of uniforms (spare != 0)
+    int spare;
     int d;                 // draw index: column d>>1, row d&1
     long long ss;
     // draw in flight
@@ -498,10 +500,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
             if (Rr[a]) { if (nr == 0) R0 = Rr[a]; else if (nr == 1) R1 = Rr[a]; else R2 = Rr[a]; nr++; }
             if (Cq[a]) { if (nc == 0) C0 = Cq[a]; else if (nc == 1) C1 = Cq[a]; nc++; }
         }
-        HrBase base0, base1;   // quotient caches for row-0 and row-1 draws (hits in the first column)
-        base0.pop = 0u; base0.good = 0u; base0.d4 = 0.0; base0.cvar = 0.0; base0.c9 = 0.0;
-        base1 = base0;
-        HrRecip rcp;           // reciprocals of the population size last seen by either
+        HrRecip rcp;           // reciprocals of the population size last seen
         rcp.pop = 0u; rcp.rp = 0.0; rcp.rp1 = 0.0; rcp.rp2 = 0.0;
 
         // ---- per-row threshold table of the first draw (wave-uniform control flow; integer prefix sums, so the
@@ -619,16 +618,20 @@ __global__ __launch_bounds__(64) void k_perm_general(
             double d6 = 0.0, d8 = 0.0, d10 = 0.0, d11 = 0.0;
             int phase = s_id < n_shuffles ? 0 : 3;       // 0 begin, 1 HRUA candidates, 3 finished
             for (;;) {
+                // one Philox call per trip and lane.  A lane that starts a shuffle (call 0) draws its first result
+                // from word 0 through the row's table and takes words 1, 2 for the first candidate of the second
+                // draw; a lane that is retrying takes words 0, 1 of its next call.
+                U4 o = {0u, 0u, 0u, 0u};
+                if (phase != 3) { o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN + call, k0, k1); call++; }
+                uint32_t wx_ = o.x, wy_ = o.y;
                 if (phase == 0) {
-                    // first draw: one 32-bit word, inverse CDF on the row's table (Philox call 0 of the shuffle)
-                    const U4 o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN, k0, k1);
-                    call = 1u;
                     uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
                     while (lo < hi) {
                         const uint32_t mid = (lo + hi) >> 1;
                         if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
                     }
                     x0 = tab_klo + lo;
+                    wx_ = o.y; wy_ = o.z;
                     // second draw: HRUA set-up (the expressions of the general path)
                     if (nr == 3) { good = R1; sample = C0 - x0; }
                     else { good = R0 - x0; sample = C1; hr_base(rc2, good, hb); }
@@ -647,10 +650,8 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     phase = 1;
                 }
                 if (phase == 1) {
-                    const U4 o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN + call, k0, k1);
-                    call++;
-                    const double x = ((double)o.x + 0.5) * 2.3283064365386963e-10;
-                    const double y = ((double)o.y + 0.5) * 2.3283064365386963e-10;
+                    const double x = ((double)wx_ + 0.5) * 2.3283064365386963e-10;
+                    const double y = ((double)wy_ + 0.5) * 2.3283064365386963e-10;
                     const double w = d6 + d8 * (y - 0.5) / x;
                     if (!(w < 0.0 || w >= d11)) {
                         const uint32_t zc = (uint32_t)floor(w);
@@ -671,6 +672,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
                             }
                             exceed += (ss >= sobs);
                             s_id = atomicAdd(&next_s, 1u);
+                            call = 0u;
                             phase = s_id < n_shuffles ? 0 : 3;
                         }
                     }
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
 
         GState g;
         g.s = lane; g.phase = 3; g.call = 0; g.d = 0; g.ss = 0;
-        g.rr0 = 0; g.rr1 = 0; g.pop_all = 0; g.cc = 0; g.pop = 0; g.xa = 0;
+        g.rr0 = 0; g.rr1 = 0; g.pop_all = 0; g.cc = 0; g.pop = 0; g.xa = 0; g.sp1 = 0; g.sp2 = 0; g.spare = 0;
         g.good = 0; g.sample = 0; g.m = 0; g.mn = 0; g.mx = 0; g.d6 = 0; g.d8 = 0; g.d10 = 0; g.d11 = 0;
         g.rem_total = 0; g.rem_good = 0; g.left = 0;
         uint32_t rr2 = 0;
@@ -706,6 +708,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
             const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
 #endif
             g.call++;
+            g.sp1 = o.y; g.sp2 = o.z; g.spare = 1;     // the next pair of uniforms comes from this call
             // smallest e with u < thr[e] (the last entry when there is none); the guide table narrows the
             // search to the entries between the answers for the bucket's first value and the next bucket's
             uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
@@ -727,14 +730,20 @@ __global__ __launch_bounds__(64) void k_perm_general(
             const bool in_draw = !need_begin && g.phase != 3;
             double ux = 0.5, uy = 0.5;
             if (in_draw) {
+                uint32_t wx_, wy_;
+                if (g.spare) {                          // right after a threshold-table draw
+                    g.spare = 0; wx_ = g.sp1; wy_ = g.sp2;
+                } else {
 #if LGMI_PABL & 1
-                const U4 o = philox4x32_r<5>(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+                    const U4 o = philox4x32_r<5>(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
 #else
-                const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+                    const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
 #endif
-                g.call++;
-                ux = ((double)o.x + 0.5) * 2.3283064365386963e-10;
-                uy = ((double)o.y + 0.5) * 2.3283064365386963e-10;
+                    g.call++;
+                    wx_ = o.x; wy_ = o.y;
+                }
+                ux = ((double)wx_ + 0.5) * 2.3283064365386963e-10;
+                uy = ((double)wy_ + 0.5) * 2.3283064365386963e-10;
             }
             if (in_draw && g.phase == 1) {
                 const double x = ux, y = uy;
@@ -824,15 +833,10 @@ __global__ __launch_bounds__(64) void k_perm_general(
                         g.rem_total = pop; g.rem_good = good; g.left = g.m;
                         g.phase = 2;
                     } else {
-                        HrBase& hb = (g.d & 1) ? base1 : base0;
-#if LGMI_PABL & 2048
-                        if (hb.pop == 0u) { hr_recip(pop, rcp); hr_base(rcp, good, hb); }
-#else
-                        if (hb.pop != pop || hb.good != good) {
-                            if (rcp.pop != pop) hr_recip(pop, rcp);
-                            hr_base(rcp, good, hb);
-                        }
-#endif
+                        // (with the reciprocals at hand the three quotients are five flops: no cache per draw position)
+                        if (rcp.pop != pop) hr_recip(pop, rcp);
+                        HrBase hb;
+                        hr_base(rcp, good, hb);
                         g.mn = good < bad ? good : bad;
                         g.mx = good < bad ? bad : good;
                         g.d6 = (double)g.m * hb.d4 + 0.5;

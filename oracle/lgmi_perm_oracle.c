@@ -145,9 +145,18 @@ static int tables_init(perm_tables* t, uint32_t max_n)
 typedef struct { uint32_t c0, c1, c2, k0, k1, call; uint32_t buf[4]; int have; } gen_stream;
 
 /* one Philox call per candidate / urn step: u[0], u[1] = ((word + 0.5) * 2^-32) of the first two
- * words (exact in double, never 0 or 1); the other two words are not used */
+ * words (exact in double, never 0 or 1); the other two words are not used.  Exception: the pair that follows a
+ * threshold-table draw comes from words 1 and 2 of the table draw's own call (word 0 drew the table), so that a
+ * shuffle's first two draws cost one call. */
 static void next_pair(gen_stream* g, double* u0, double* u1)
 {
+    if (g->have) {
+        /* right after a threshold-table draw: words 1 and 2 of the call that drew it */
+        g->have = 0;
+        *u0 = ((double)g->buf[1] + 0.5) * 2.3283064365386963e-10;
+        *u1 = ((double)g->buf[2] + 0.5) * 2.3283064365386963e-10;
+        return;
+    }
     philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
     g->call++;
     *u0 = ((double)g->buf[0] + 0.5) * 2.3283064365386963e-10;
@@ -244,6 +253,7 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
         uint32_t lo = 0, hi = ft->n - 1, u;
         philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
         g->call++;
+        g->have = 1;                 /* words 1, 2 serve the next pair of uniforms */
         u = g->buf[0];
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
