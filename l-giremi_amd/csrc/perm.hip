@@ -28,7 +28,12 @@
 #include "philox.h"
 
 #ifndef LGMI_PABL
-#define LGMI_PABL 0     // timing-only ablations (results wrong by construction), tools/abl_perm.sh
+#define LGMI_PABL 0     // timing-only ablations (results wrong by construction), tools/abl_perm.sh.  Bits:
+//    1 candidate Philox with 5 rounds      2 exp in the HRUA test replaced by 1 + t      4 set-up sqrt in f32
+//    8 threshold-table draw replaced by a cheap hash      16 general rows not queued (k_perm_fast alone)
+//   32 exact-tail sums skipped      64 bisection skipped      128 binomial draw skipped
+//  256 HRUA set-up skipped (generic path; needs 1024+2048 not to hang)      1024 statistic look-ups skipped
+// 2048 HRUA quotients never recomputed      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
 #endif
 
 namespace lgmi {
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     const uint32_t zc = (uint32_t)floor(w);
                     const double tt = g.d10 - (LF[zc] + LF[g.mn - zc] + LF[g.m - zc] + LF[g.mx - g.m + zc]);
                     bool acc = (x * (4.0 - x) - 3.0 <= tt);
-                    #if LGMI_PABL & 2
+#if LGMI_PABL & 2
                     if (!acc && !(x * (x - tt) >= 1.0)) acc = (x * x <= 1.0 + tt);
 #else
                     if (!acc && !(x * (x - tt) >= 1.0)) acc = (x * x <= det_exp(tt));   // 2 ln x <= tt
