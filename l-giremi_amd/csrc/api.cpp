@@ -511,7 +511,8 @@ static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
         // tile order: groups of XG x-tile rows sweep the y tiles together, so that the XG tiles that
         // run side by side on an XCD (xcd_remap in the kernels) share one y tile in L2 and every y column is
         // fetched from HBM once per group instead of once per x-tile row
-        const uint32_t XG = use_mfma ? 4 : 8;
+        uint32_t XG = use_mfma ? 4 : 8;
+        if (const char* e = getenv("LGMI_XG")) XG = (uint32_t)std::max(1, atoi(e));
         for (uint32_t tg = 0; tg < ntx; tg += XG) {
             for (uint32_t ty = 0; ty < nty; ++ty) {
                 if (ymin[ty] >= ymax[ty]) continue;
