@@ -469,6 +469,12 @@ struct GState {
 //                over shuffles and every shuffle has its own Philox stream: who runs which one does not matter)
 static const uint32_t FIRST_MAX = 2032;
 
+// rint(p * 2^52) for 0 <= p < 1 without a 64-bit conversion: adding 2^52 leaves the rounded value in the mantissa
+__device__ __forceinline__ unsigned long long to_fixed52(double p) {
+    const double t = p * 4503599627370496.0 + 4503599627370496.0;
+    return (unsigned long long)__double_as_longlong(t) & 0x000FFFFFFFFFFFFFull;
+}
+
 __global__ __launch_bounds__(64) void k_perm_general(
     const uint32_t* __restrict__ gen_list, const unsigned int* __restrict__ gen_count,
     const uint32_t* __restrict__ row_i, const uint32_t* __restrict__ row_j, const uint32_t* __restrict__ counts,
@@ -521,8 +527,14 @@ __global__ __launch_bounds__(64) void k_perm_general(
                 const double var = (double)sample * pg * (1.0 - pg) * (double)(pop - sample) / (double)(pop - 1u);
                 const double sd = det_sqrt(var + 1.0);
                 const uint32_t w = (uint32_t)floor(6.5 * sd) + 4u;
-                uint32_t mode = (uint32_t)(((unsigned long long)(sample + 1u) * (unsigned long long)(good + 1u)) /
-                                           ((unsigned long long)pop + 2ull));
+                // floor((sample+1)(good+1) / (pop+2)): the product is below 2^53, so one f64 division lands within one
+                // of the integer quotient and an integer remainder settles it (a 64-bit integer division costs 90 instructions)
+                const unsigned long long prod = (unsigned long long)(sample + 1u) * (unsigned long long)(good + 1u);
+                uint32_t mode = (uint32_t)((double)prod / ((double)pop + 2.0));
+                {
+                    const long long rem = (long long)prod - (long long)mode * (long long)(pop + 2u);
+                    if (rem < 0) mode--; else if (rem >= (long long)(pop + 2u)) mode++;
+                }
                 if (mode < kmin) mode = kmin;
                 if (mode > kmax) mode = kmax;
                 tab_klo = mode - kmin > w ? mode - w : kmin;
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     x -= LF[sample - k];
                     x -= LF[pop - good - sample + k];
                     pm = det_exp(x);
-                    loc = (unsigned long long)(pm * 4503599627370496.0);
+                    loc = to_fixed52(pm);
                     tab_thr[e0] = (uint32_t)(loc >> 20);
                 }
                 for (uint32_t e = e0 + 1u; e < e1; ++e) {   // the others: by the hypergeometric ratio
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     const double num = (double)(good - k + 1u) * (double)(sample - k + 1u);
                     const double den = (double)k * (double)(pop - good - sample + k);
                     pm = pm * num / den;
-                    loc += (unsigned long long)(pm * 4503599627370496.0);
+                    loc += to_fixed52(pm);
                     tab_thr[e] = (uint32_t)(loc >> 20);
                 }
                 unsigned long long incl = loc;         // inclusive scan of the segment totals over the lanes

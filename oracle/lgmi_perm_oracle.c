@@ -172,7 +172,7 @@ static const double HRUA_D2 = 0.8989161620588988;   /* 3 - 2*sqrt(3/e) */
  * drawn by inverse CDF instead of rejection: one 32-bit Philox word u, result = the smallest k of the window
  * with u < thr[k - klo] (the last k of the window when there is none: the window misses < 1e-10 of the mass).
  * The thresholds are integer prefix sums, so they do not depend on the order of the additions:
- *     q[e]   = trunc(pmf(klo + e) * 2^52)                                 (u64; pmf from the log-factorials at the
+ *     q[e]   = rint(pmf(klo + e) * 2^52)                                 (u64; pmf from the log-factorials at the
  *              first entry of a segment, then by the ratio pmf(k) = pmf(k-1) (good-k+1)(sample-k+1)/(k (pop-good-sample+k)))
  *     the window is cut into 64 contiguous segments of seg = ceil(n / 64) entries (one per GPU lane);
  *     thr[e] = min(2^32 - 1, (sum of q over the entries of e's segment up to e) >> 20
@@ -228,7 +228,7 @@ static void first_table_build(const perm_tables* t, uint32_t pop, uint32_t good,
                 const double den = (double)k * (double)(pop - good - sample + k);
                 pm = pm * num / den;
             }
-            loc += (uint64_t)(pm * 4503599627370496.0);
+            loc += (uint64_t)rint(pm * 4503599627370496.0);
             thr = (uint64_t)(uint32_t)(loc >> 20) + (earlier >> 20);
             ft->thr[e] = thr >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
         }
