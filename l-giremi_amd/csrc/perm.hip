@@ -603,6 +603,35 @@ __global__ __launch_bounds__(64) void k_perm_general(
             __syncthreads();
         }
 
+        // ---- 3 x 2 / 2 x 3 rows: one HRUA hat width for the draw that follows the table draw, the largest over the
+        //      first draw's window (any width >= Stadlober's keeps HRUA exact; CPU specification: hrua_width_bound)
+        double d7max = 0.0;
+        uint32_t key_pop2 = 0u, key2 = 0u;
+        if (tab_ok && nr * nc == 6 && N - R0 > 1u && N - C0 > 1u) {
+            const uint32_t xlo = tab_klo, xhi = tab_klo + tab_n - 1u;
+            double varmax;
+            if (nr == 3) {
+                const uint32_t pop2 = N - R0, good = R1, bad = pop2 - good, mn = good < bad ? good : bad, half = pop2 / 2u;
+                const uint32_t s_lo = C0 - xhi, s_hi = C0 - xlo;
+                const uint32_t m_lo = s_lo < pop2 - s_lo ? s_lo : pop2 - s_lo, m_hi = s_hi < pop2 - s_hi ? s_hi : pop2 - s_hi;
+                const uint32_t m_max = (s_lo <= half && half <= s_hi) ? half : (m_lo > m_hi ? m_lo : m_hi);
+                const double rp = 1.0 / (double)pop2, rp1 = 1.0 / (double)(pop2 - 1u);
+                const double d4 = (double)mn * rp, cvar = d4 * (1.0 - d4) * rp1;
+                varmax = (double)(pop2 - m_max) * (double)m_max * cvar;
+                key_pop2 = pop2; key2 = good;
+            } else {
+                const uint32_t pop2 = N - C0, m = C1 < pop2 - C1 ? C1 : pop2 - C1, half = pop2 / 2u;
+                const uint32_t g_lo = R0 - xhi, g_hi = R0 - xlo;
+                const uint32_t n_lo = g_lo < pop2 - g_lo ? g_lo : pop2 - g_lo, n_hi = g_hi < pop2 - g_hi ? g_hi : pop2 - g_hi;
+                const uint32_t mn_max = (g_lo <= half && half <= g_hi) ? half : (n_lo > n_hi ? n_lo : n_hi);
+                const double rp = 1.0 / (double)pop2, rp1 = 1.0 / (double)(pop2 - 1u);
+                const double d4 = (double)mn_max * rp, cvar = d4 * (1.0 - d4) * rp1;
+                varmax = (double)(pop2 - m) * (double)m * cvar;
+                key_pop2 = pop2; key2 = C1;
+            }
+            d7max = det_sqrt(varmax + 0.5) * (1.0 + 9.094947017729282e-13);   // 1 + 2^-40 against rounding
+        }
+
         // ---- 3 x 2 and 2 x 3 tables whose two real draws are "threshold table, then HRUA" for every possible
         //      first result (the usual case: a tri-allelic site against a bi-allelic one at hundreds of reads or
         //      more): the same draws, streams and arithmetic as the general state machine below, without its
@@ -657,7 +686,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
                     mn = good < bad ? good : bad;
                     mx = good < bad ? bad : good;
                     d6 = (double)m * hb.d4 + 0.5;
-                    const double d7 = det_sqrt((double)(pop2 - m) * (double)m * hb.cvar + 0.5);
+                    const double d7 = d7max;                     // the row's hat width (no square root per shuffle)
                     const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
                     d10 = LF[d9] + LF[mn - d9] + LF[m - d9] + LF[mx - m + d9];
                     d8 = HRUA_D1 * d7 + HRUA_D2;
@@ -863,7 +892,9 @@ __global__ __launch_bounds__(64) void k_perm_general(
 #if LGMI_PABL & 4
                         const double d7 = (double)__fsqrt_rn((float)((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5));
 #else
-                        const double d7 = det_sqrt((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5);
+                        // the draw right after the table draw of a 3 x 2 / 2 x 3 row takes the row's hat width
+                        const bool bounded = d7max > 0.0 && g.spare && pop == key_pop2 && (nr == 3 ? good == key2 : sample == key2);
+                        const double d7 = bounded ? d7max : det_sqrt((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5);
 #endif
                         const uint32_t d9 = (uint32_t)floor((double)(g.m + 1u) * hb.c9);
                         g.d10 = LF[d9] + LF[g.mn - d9] + LF[g.m - d9] + LF[g.mx - g.m + d9];

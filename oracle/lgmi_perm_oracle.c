@@ -180,7 +180,16 @@ static const double HRUA_D2 = 0.8989161620588988;   /* 3 - 2*sqrt(3/e) */
  * i.e. floor(2^32 * CDF) to within 2 units (the two shifts are taken separately so that a lane only has to
  * keep 32 bits per entry). */
 #define FIRST_MAX 2032
-typedef struct { int valid; uint32_t pop, good, sample, klo, n; uint32_t thr[FIRST_MAX]; } first_table;
+typedef struct {
+    int valid;
+    uint32_t pop, good, sample, klo, n;
+    /* 3 x 2 / 2 x 3 rows: the HRUA draw that follows the table draw — population pop2 and, with nr3, good == key2,
+     * else sample == key2 — takes d7_next (> 0) instead of its own sqrt(var + 0.5): see hrua_width_bound() */
+    uint32_t pop2, key2;
+    int nr3;
+    double d7_next;
+    uint32_t thr[FIRST_MAX];
+} first_table;
 
 static void first_table_build(const perm_tables* t, uint32_t pop, uint32_t good, uint32_t sample, first_table* ft)
 {
@@ -190,6 +199,7 @@ static void first_table_build(const perm_tables* t, uint32_t pop, uint32_t good,
     uint32_t mode, w, khi, seg, e, l;
     uint64_t earlier = 0;
     ft->valid = 0;
+    ft->d7_next = 0.0; ft->pop2 = 0; ft->key2 = 0; ft->nr3 = 0;
     if (sample == 0 || good == 0 || good == pop || sample == pop || m < 10) return;
     p = (double)good / (double)pop;
     var = (double)sample * p * (1.0 - p) * (double)(pop - sample) / (double)(pop - 1);
@@ -283,7 +293,9 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
         const double cvar = d4 * (1.0 - d4) * rp1;
         const double c9 = (double)(mn + 1) * rp2;
         const double d6 = (double)m * d4 + 0.5;
-        const double d7 = lgo_det_sqrt((double)(pop - m) * (double)m * cvar + 0.5);
+        const int bounded = ft && ft->valid && ft->d7_next > 0.0 && g->have && pop == ft->pop2 &&
+                            (ft->nr3 ? good == ft->key2 : sample == ft->key2);
+        const double d7 = bounded ? ft->d7_next : lgo_det_sqrt((double)(pop - m) * (double)m * cvar + 0.5);
         const double d8 = HRUA_D1 * d7 + HRUA_D2;
         const uint32_t d9 = (uint32_t)floor((double)(m + 1) * c9);   /* mode (may be off by one: harmless) */
         const double d10 = t->LF[d9] + t->LF[mn - d9] + t->LF[m - d9] + t->LF[mx - m + d9];
@@ -510,6 +522,37 @@ static uint32_t binom_draw(const perm_tables* t, uint32_t n, uint64_t thr, uint3
     return flip ? n - k : k;
 }
 
+/* HRUA stays exact with any hat width at least as large as Stadlober's D1 sqrt(var + 1/2) + D2 (the acceptance
+ * region only has to lie inside the rectangle the candidates are uniform on).  In a 3 x 2 / 2 x 3 row the draw
+ * after the table draw has var = (pop2 - m) m cvar with, over the first draw's window [xlo, xhi], either m or the
+ * minority count behind cvar moving monotonically: the largest value over the window serves every shuffle and the
+ * square root is taken once per row (times 1 + 2^-40 against rounding). */
+static void hrua_width_bound(first_table* ft, uint32_t N, int nr, uint32_t R0, uint32_t R1, uint32_t C0, uint32_t C1)
+{
+    const uint32_t xlo = ft->klo, xhi = ft->klo + ft->n - 1;
+    double varmax;
+    if (nr == 3) {
+        const uint32_t pop2 = N - R0, good = R1, bad = pop2 - good, mn = good < bad ? good : bad, half = pop2 / 2;
+        const uint32_t s_lo = C0 - xhi, s_hi = C0 - xlo;
+        const uint32_t m_lo = s_lo < pop2 - s_lo ? s_lo : pop2 - s_lo, m_hi = s_hi < pop2 - s_hi ? s_hi : pop2 - s_hi;
+        const uint32_t m_max = (s_lo <= half && half <= s_hi) ? half : (m_lo > m_hi ? m_lo : m_hi);
+        const double rp = 1.0 / (double)pop2, rp1 = 1.0 / (double)(pop2 - 1);
+        const double d4 = (double)mn * rp, cvar = d4 * (1.0 - d4) * rp1;
+        varmax = (double)(pop2 - m_max) * (double)m_max * cvar;
+        ft->pop2 = pop2; ft->key2 = good; ft->nr3 = 1;
+    } else {
+        const uint32_t pop2 = N - C0, m = C1 < pop2 - C1 ? C1 : pop2 - C1, half = pop2 / 2;
+        const uint32_t g_lo = R0 - xhi, g_hi = R0 - xlo;
+        const uint32_t n_lo = g_lo < pop2 - g_lo ? g_lo : pop2 - g_lo, n_hi = g_hi < pop2 - g_hi ? g_hi : pop2 - g_hi;
+        const uint32_t mn_max = (g_lo <= half && half <= g_hi) ? half : (n_lo > n_hi ? n_lo : n_hi);
+        const double rp = 1.0 / (double)pop2, rp1 = 1.0 / (double)(pop2 - 1);
+        const double d4 = (double)mn_max * rp, cvar = d4 * (1.0 - d4) * rp1;
+        varmax = (double)(pop2 - m) * (double)m * cvar;
+        ft->pop2 = pop2; ft->key2 = C1; ft->nr3 = 0;
+    }
+    ft->d7_next = lgo_det_sqrt(varmax + 0.5) * (1.0 + 9.094947017729282e-13);   /* 1 + 2^-40 */
+}
+
 static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row_i, uint32_t row_j,
                          uint32_t n_shuffles, uint64_t seed, double* ptail_out)
 {
@@ -542,6 +585,8 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
         const int64_t sobs = stat9(t, T);
         first_table ft;
         first_table_build(t, N, R[nzr[0]], C[nzc[0]], &ft);   /* the first non-empty row and column */
+        if (ft.valid && nr * nc == 6 && N - R[nzr[0]] > 1 && N - C[nzc[0]] > 1)
+            hrua_width_bound(&ft, N, (int)nr, R[nzr[0]], R[nzr[1]], C[nzc[0]], C[nzc[1]]);
         for (s = 0; s < n_shuffles; ++s) {
             gen_stream g;
             uint32_t rr[3] = {R[0], R[1], R[2]}, Ts[9], pop_all = N;
@@ -609,6 +654,31 @@ int lgo_hg_draw_many2(uint32_t pop, uint32_t good, uint32_t sample, uint64_t see
         out[i] = hg_draw(&t, pop, good, sample, &g, use_table ? &ft : NULL);
     }
     free(t.G); free(t.LF);
+    return 0;
+}
+
+/* HRUA draws with the hat width inflated by `factor` (the row-constant bound of hrua_width_bound is such an inflation) */
+int lgo_hg_draw_wide(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed, uint32_t n, uint32_t* out, double factor)
+{
+    perm_tables t;
+    first_table* ft = (first_table*)calloc(1, sizeof(first_table));
+    uint32_t i;
+    const uint32_t bad = pop - good, mn = good < bad ? good : bad, m = sample < pop - sample ? sample : pop - sample;
+    if (!ft || tables_init(&t, pop)) { free(ft); return -1; }
+    {
+        const double rp = 1.0 / (double)pop, rp1 = 1.0 / (double)(pop - 1);
+        const double d4 = (double)mn * rp, cvar = d4 * (1.0 - d4) * rp1;
+        ft->valid = 1; ft->pop2 = pop; ft->key2 = good; ft->nr3 = 1;
+        ft->d7_next = lgo_det_sqrt((double)(pop - m) * (double)m * cvar + 0.5) * factor;
+    }
+    for (i = 0; i < n; ++i) {
+        gen_stream g;
+        g.c0 = i; g.c1 = 5; g.c2 = 6; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 1;
+        philox(i, 5, 6, TAG_PERMGEN, g.k0, g.k1, g.buf);     /* as if a table draw had just used word 0 of call 0 */
+        g.have = 1;
+        out[i] = hg_draw(&t, pop, good, sample, &g, ft);
+    }
+    free(t.G); free(t.LF); free(ft);
     return 0;
 }
 

@@ -23,6 +23,8 @@ def lib():
     lib.lgo_hg_draw_many2.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_int]
     lib.lgo_first_table.restype = C.c_int
     lib.lgo_first_table.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    lib.lgo_hg_draw_wide.restype = C.c_int
+    lib.lgo_hg_draw_wide.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_double]
     lib.lgo_binom_draw_many.restype = C.c_int
     lib.lgo_binom_draw_many.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, u32p]
     lib.lgo_perm_ptail.restype = C.c_int
@@ -144,6 +146,27 @@ def test_binomial_sampler_edges(lib):
     # thr = 1: p = 2^-32 -> essentially always 0; thr = 2^32 - 1 -> essentially always n
     assert lib.lgo_binom_draw_many(1000, 1, 1, 100, out.ctypes.data_as(u32p)) == 0 and (out == 0).all()
     assert lib.lgo_binom_draw_many(1000, 2 ** 32 - 1, 1, 100, out.ctypes.data_as(u32p)) == 0 and (out == 1000).all()
+
+
+@pytest.mark.parametrize('factor', [1.0, 1.02, 1.5])
+@pytest.mark.parametrize('pop,good,sample', [(300, 40, 150), (5000, 2500, 2500), (160000, 80000, 48000), (160000, 8000, 150000)])
+def test_hrua_with_a_wider_hat_is_still_exact(lib, pop, good, sample, factor):
+    """the draw that follows a table draw in a 3 x 2 row uses one hat width per row, the largest over the first
+    draw's window: any width >= Stadlober's keeps the sampler exact (only the acceptance rate drops)"""
+    n = 40000
+    out = np.zeros(n, np.uint32)
+    assert lib.lgo_hg_draw_wide(pop, good, sample, 91, n, out.ctypes.data_as(u32p), factor) == 0
+    lo, hi = max(0, sample + good - pop), min(good, sample)
+    assert out.min() >= lo and out.max() <= hi
+    ks = np.arange(lo, hi + 1)
+    obs = np.bincount(out - lo, minlength=len(ks)).astype(float)
+    exp = stats.hypergeom.pmf(ks, pop, good, sample) * n
+    order = np.argsort(-exp)
+    keep = exp[order] >= 8
+    o = np.append(obs[order][keep], obs[order][~keep].sum())
+    e = np.append(exp[order][keep], n - exp[order][keep].sum())
+    chi2 = ((o - e) ** 2 / e).sum()
+    assert stats.chi2.sf(chi2, len(e) - 1) > 1e-4
 
 
 def stat_of(table):
