@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LGMI_ABI_VERSION 2
+#define LGMI_ABI_VERSION 3
 
 /* error codes */
 #define LGMI_OK        0
@@ -102,15 +102,29 @@ typedef struct lgmi_params {
     uint8_t  het_only;     /* 1: only pairs with >=1 het_snp side (mismatch.py:392-396);
                               0: all P(P-1)/2 pairs (mutual_information.py:12)   */
     uint8_t  emit_counts;  /* 1: fill row_counts (3x3 table per row)              */
-    uint8_t  reserved[6];  /* must be 0 */
+    uint8_t  exact_2x2;    /* 1: rows whose table has at most 2 non-empty classes per site get the EXACT
+                              permutation p (the hypergeometric mass of the tables with MI >= observed,
+                              summed from log-factorials) instead of a Monte-Carlo estimate; their
+                              row_exceed is LGMI_EXCEED_EXACT.  Larger tables keep the n_shuffles
+                              estimate (row_p NaN, row_exceed LGMI_EXCEED_EXACT when n_shuffles == 0) */
+    uint8_t  reserved0;    /* must be 0 */
+    /* tile-level sharding of ONE batch over several GPUs (the reference's analogue is the chunked
+     * Pool.map of script/giremi.py:367-394): the result rows, in reference order, are cut into shard_world
+     * contiguous, cost-balanced ranges; this call computes range shard_rank only (count tiles that feed it,
+     * its rows, their p-values, its share of the per-site sums).  Concatenating the shards' rows in rank
+     * order gives exactly the unsharded rows.  0/0 or x/1 = unsharded. */
+    uint16_t shard_rank;
+    uint16_t shard_world;
 } lgmi_params;
+#define LGMI_EXCEED_EXACT 0xFFFFFFFFu
 
 /*
  * lgmi_result — rows in reference order: block, then combinations() order of
  * the sorted positions (i < j). Site indices are GLOBAL (into the batch's site
  * arrays). row_counts[9*r + 3*a + b] = #common reads with class a at site i
  * and class b at site j (a, b in 0,1,2). site_mean_mi[s] is NaN and
- * site_n_pairs[s] 0 for a site that appears in no row.
+ * site_n_pairs[s] 0 for a site that appears in no row.  In a sharded run (shard_world > 1) the per-site
+ * figures cover the shard's own rows only; lgmi_comm_gather() adds the shards' integer sums up.
  */
 typedef struct lgmi_result {
     uint64_t n_rows;
@@ -145,6 +159,13 @@ typedef struct lgmi_run_info {
     uint32_t n_mfma_tiles;  /* 128 x 128 tiles computed on the matrix cores (0: VALU popcount only)      */
     uint32_t mfma_dtype;    /* operand type of those tiles: 0 none, 1 int8, 2 fp4 (e2m1)                 */
     uint32_t reserved;
+    uint64_t n_examined_total; /* examined pairs of the whole batch (== n_examined when unsharded)         */
+    uint64_t n_general_rows;   /* rows whose table is larger than 2 x 2: these get n_shuffles real table
+                                  draws each; 2 x 2 rows get ONE binomial variate            */
+    float ms_plan_host;        /* host wall time of the per-run planning (tile list, work items), ms       */
+    float ms_perm_fast;        /* k_perm_fast: classification + exact 2 x 2 tails + binomial draws         */
+    float ms_perm_general;     /* k_perm_general: Monte-Carlo table draws of the larger tables             */
+    uint32_t reserved2;
 } lgmi_run_info;
 
 /* device-side synthetic chromosome generator (SURVEY 8d "dense" regime):
@@ -212,14 +233,70 @@ int  lgmi_site_mean(lgmi_ctx* ctx, uint64_t n_rows, const uint32_t* row_i,
 int  lgmi_ecdf(lgmi_ctx* ctx, uint64_t n_ref, const double* ref, uint64_t n_query,
                const double* query, double* out);
 
+/* ---- sharding plan, host only (no GPU touched): what lgmi_run_device() would do for (shard_rank, shard_world).
+ * Lets a launcher balance / inspect shards and lets CPU-only tests check that every row of a shard is fed by
+ * one of the shard's count tiles.  A work item is (site i, segment g): the partners number
+ * [g * LGMI_EMIT_SEG, (g+1) * LGMI_EMIT_SEG) of site i's row, rows being in reference order. */
+#define LGMI_EMIT_SEG 8192u
+typedef struct lgmi_shard_plan {
+    uint64_t n_items_total;      /* work items of the whole batch                                  */
+    uint64_t item_begin;         /* this shard's items are [item_begin, item_end)                  */
+    uint64_t item_end;
+    uint64_t n_examined_total;
+    uint64_t n_examined;         /* examined pairs inside this shard's items                       */
+    uint64_t n_tiles_total;      /* count tiles of the unsharded plan                              */
+    uint64_t n_tiles;            /* count tiles this shard computes                                */
+    const uint32_t* item_site;   /* [n_items_total]                                                */
+    const uint32_t* item_seg;    /* [n_items_total]                                                */
+    const uint32_t* tile_block;  /* [n_tiles] block of the tile                                    */
+    const uint32_t* tile_x0;     /* [n_tiles] first slot-matrix row                                */
+    const uint32_t* tile_y0;     /* [n_tiles] first slot-matrix column                             */
+    const uint32_t* tile_edge;   /* [n_tiles] 64 (VALU popcount kernel) or 128 (matrix cores)      */
+    const uint32_t* site_xrow;   /* [n_sites] slot-matrix row of the site in its block, or 0xFFFFFFFF */
+    const uint32_t* site_ycol;   /* [n_sites] slot-matrix column                                   */
+    const uint32_t* site_prow;   /* [n_sites] pseudo row (third-class plane) or 0xFFFFFFFF         */
+    const uint32_t* site_pcol;   /* [n_sites] pseudo column or 0xFFFFFFFF                          */
+    const uint32_t* site_xnext;  /* [n_sites] number of x sites of the block at or before the site */
+    void* owner_;
+} lgmi_shard_plan;
+int  lgmi_plan_shard(const lgmi_batch* batch, int het_only, uint32_t shard_rank, uint32_t shard_world,
+                     lgmi_shard_plan* out);
+void lgmi_shard_plan_free(lgmi_shard_plan* plan);
+
+/* wait for everything queued on the context's stream (the bench's device sync) */
+int  lgmi_ctx_synchronize(lgmi_ctx* ctx);
+
 /* ---- multi-GPU: one process per GPU, RCCL used only for the final gather ---- */
 #define LGMI_UNIQUE_ID_BYTES 128
 int  lgmi_comm_unique_id(void* out128);                 /* rank 0 creates, host broadcasts */
 int  lgmi_comm_init(lgmi_ctx* ctx, const void* id128, int rank, int world);
 /* all-gather of one u64 per rank (row counts) over RCCL */
 int  lgmi_comm_allgather_u64(lgmi_ctx* ctx, uint64_t mine, uint64_t* out_world);
-/* gather every rank's rows (row_i,row_j,row_mi[,row_p]) to rank `root` in rank
- * order; on root `out` is a host-resident concatenation, elsewhere n_rows = 0 */
+/* all-gather of n u64 per rank: out_world[r * n + k] = rank r's mine[k] */
+int  lgmi_comm_allgather_u64v(lgmi_ctx* ctx, const uint64_t* mine, uint32_t n, uint64_t* out_world);
+/*
+ * The final gather, HBM to HBM over xGMI: every rank's rows (row_i, row_j, row_mi [, row_p, row_exceed]
+ * [, row_counts]) land on rank `root` in rank order as a new resident result (*out; NULL elsewhere) that
+ * lgmi_dresult_fetch() brings to the host.  Rows stay attributable:
+ *   - site_base is added to the rank's row_i / row_j, so that ranks that ran DIFFERENT batches (blocks dealt to
+ *     ranks) report indices into one global site numbering; the gathered per-site arrays have
+ *     max(site_base + n_sites) entries, each rank's per-site means stored at its base;
+ *   - rank_row_begin (NULL or [world + 1], filled on every rank) tells which rows came from which rank;
+ *   - same_batch = 1 (every rank ran a shard of the SAME batch, lgmi_params.shard_*): site_base must be 0
+ *     everywhere, and the shards' per-site integer sums are added (ncclReduce) before the mean is taken —
+ *     integer sums, so the result equals the unsharded run's bit for bit.
+ * Every rank must call it; an error on one rank (allocation, mismatched flags) is agreed on before any
+ * send / receive is posted, so no rank is left blocked.
+ */
+typedef struct lgmi_gather_opts {
+    uint32_t site_base;
+    uint8_t  same_batch;
+    uint8_t  reserved[3];     /* must be 0 */
+} lgmi_gather_opts;
+int  lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int root, const lgmi_gather_opts* opts_or_null,
+                      lgmi_dresult** out, uint64_t* rank_row_begin_or_null);
+/* lgmi_comm_gather() with default options followed by a fetch on the root: `out` is a host-resident
+ * concatenation there, n_rows = 0 elsewhere */
 int  lgmi_comm_gather_rows(lgmi_ctx* ctx, const lgmi_dresult* mine, int root,
                            lgmi_result* out);
 void lgmi_comm_destroy(lgmi_ctx* ctx);

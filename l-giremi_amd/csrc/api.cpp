@@ -14,8 +14,11 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+
 #include "lgmi_internal.h"
 #include "philox.h"
+#include "plan.h"
 
 using namespace lgmi;
 
@@ -95,6 +98,7 @@ struct lgmi_ctx {
     uint32_t tables_len = 0;
     void* comm = nullptr;       // ncclComm_t (comm.cpp)
     int rank = 0, world = 1;
+    size_t mem_total = 0;       // device memory, for the "allocate rows by their upper bound" decision
 };
 
 struct lgmi_dbatch {
@@ -122,7 +126,9 @@ struct lgmi_dresult {
     double* d_mi = nullptr; double* d_p = nullptr;
     uint32_t* d_exceed = nullptr; uint32_t* d_counts = nullptr;
     double* d_mean = nullptr; uint32_t* d_npairs = nullptr;
+    unsigned long long* d_sum = nullptr;   // per-site sum of MI in 2^-40 fixed point (what d_mean was made from)
     bool has_p = false, has_counts = false;
+    bool sharded = false;                  // per-site figures cover this shard's rows only
 };
 
 struct HostResult : ResultOwner {  // owner_ of a host lgmi_result
@@ -161,6 +167,8 @@ extern "C" int lgmi_ctx_create(int device_id, lgmi_ctx** out) {
     c->device = device_id;
     HIPCHK(hipStreamCreate(&c->stream));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
+    size_t free_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &c->mem_total));
     *out = c;
     return LGMI_OK;
 }
@@ -188,11 +196,38 @@ void** ctx_comm_slot(lgmi_ctx* c) { return &c->comm; }
 int* ctx_rank_slot(lgmi_ctx* c) { return &c->rank; }
 int* ctx_world_slot(lgmi_ctx* c) { return &c->world; }
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
-void dresult_rows(const lgmi_dresult* r, uint64_t* n, const uint32_t** i, const uint32_t** j, const double** mi,
-                  const double** p) {
-    *n = r->n_rows; *i = r->d_i; *j = r->d_j; *mi = r->d_mi; *p = r->has_p ? r->d_p : nullptr;
+Pool& ctx_pool(lgmi_ctx* c) { return c->pool; }
+void dresult_view(const lgmi_dresult* r, DResultView* v) {
+    v->n_rows = r->n_rows; v->n_sites = r->n_sites;
+    v->i = r->d_i; v->j = r->d_j; v->mi = r->d_mi;
+    v->p = r->has_p ? r->d_p : nullptr; v->exceed = r->has_p ? r->d_exceed : nullptr;
+    v->counts = r->has_counts ? r->d_counts : nullptr;
+    v->mean = r->d_mean; v->npairs = r->d_npairs; v->sum = r->d_sum;
+    v->info = r->info;
 }
+// a resident result made by the gather (comm.cpp): arrays come from the context's pool
+lgmi_dresult* dresult_new_gathered(lgmi_ctx* c, const DResultView& v) {
+    lgmi_dresult* r = new lgmi_dresult();
+    r->ctx = c; r->n_rows = v.n_rows; r->n_sites = v.n_sites;
+    r->d_i = const_cast<uint32_t*>(v.i); r->d_j = const_cast<uint32_t*>(v.j); r->d_mi = const_cast<double*>(v.mi);
+    r->d_p = const_cast<double*>(v.p); r->d_exceed = const_cast<uint32_t*>(v.exceed);
+    r->d_counts = const_cast<uint32_t*>(v.counts);
+    r->d_mean = const_cast<double*>(v.mean); r->d_npairs = const_cast<uint32_t*>(v.npairs);
+    r->d_sum = const_cast<unsigned long long*>(v.sum);
+    r->has_p = v.p != nullptr; r->has_counts = v.counts != nullptr;
+    r->info = v.info;
+    return r;
+}
+int pool_alloc(lgmi_ctx* c, void** out, size_t bytes) { return c->pool.alloc(out, bytes); }
+void pool_release(lgmi_ctx* c, void* p) { c->pool.release(p); }
 }  // namespace lgmi
+
+extern "C" int lgmi_ctx_synchronize(lgmi_ctx* ctx) {
+    if (!ctx) return fail(LGMI_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LGMI_OK;
+}
 
 // ---------------------------------------------------------------- upload
 static void free_dbatch_device(lgmi_dbatch* db) {
@@ -422,114 +457,100 @@ extern "C" int lgmi_dbatch_download(lgmi_dbatch* db, lgmi_batch* out) {
     return LGMI_OK;
 }
 
-// ---------------------------------------------------------------- planning (host, every run)
-struct Plan {
-    std::vector<BlockPlan> plans;
-    std::vector<uint32_t> xlist, ylist;
-    std::vector<SiteMap> smap;
-    bool mfma_fp4 = true;           // every matrix-core block has fewer than 2^24 reads: f32 accumulation is exact
-    std::vector<Tile> tiles;        // 64 x 64 tiles for k_count (VALU popcount)
-    std::vector<Tile> mtiles;       // 128 x 128 tiles for the matrix-core count kernels
-    std::vector<uint2> items;       // emit work items: (site, segment of EMIT_SEG partners), in row order
-    uint64_t total_slots = 0, n_examined = 0, bytes_in = 0;
-};
-
-static void build_plan(const lgmi_dbatch* db, bool het_only, Plan& pl) {
-    int count_kernel_choice = 0;   // 0 auto, 1 VALU popcount only, 2 matrix cores only, 3 matrix cores with int8 operands only
+// ---------------------------------------------------------------- planning (host, every run): plan.cpp
+static void plan_env(int* count_kernel, uint32_t* xg) {
+    *count_kernel = 0; *xg = 0;   // LGMI_COUNT_KERNEL=valu|mfma|mfma_i8 forces a count kernel (tests, A/B runs)
     if (const char* e = getenv("LGMI_COUNT_KERNEL")) {
-        if (!strcmp(e, "valu")) count_kernel_choice = 1;
-        else if (!strcmp(e, "mfma")) count_kernel_choice = 2;
-        else if (!strcmp(e, "mfma_i8")) count_kernel_choice = 3;
+        if (!strcmp(e, "valu")) *count_kernel = 1;
+        else if (!strcmp(e, "mfma")) *count_kernel = 2;
+        else if (!strcmp(e, "mfma_i8")) *count_kernel = 3;
     }
-    if (count_kernel_choice == 3) pl.mfma_fp4 = false;
-    const uint64_t ns = db->d.n_sites;
-    pl.smap.assign(ns, SiteMap{NONE, NONE, NONE, NONE, 0, 0});
-    pl.plans.resize(db->d.n_blocks);
-    std::vector<uint32_t> xmin, xmax, ymin, ymax;
-    for (uint64_t b = 0; b < db->d.n_blocks; ++b) {
-        const uint32_t sb = (uint32_t)db->block_site_begin[b], se = (uint32_t)db->block_site_begin[b + 1];
-        const uint32_t P = se - sb;
-        BlockPlan bp{};
-        bp.slot_base = pl.total_slots;
-        bp.xl_off = (uint32_t)pl.xlist.size();
-        bp.yl_off = (uint32_t)pl.ylist.size();
-        bp.site_begin = sb;
-        bp.site_end = se;
-        // x list: x sites in position order, then pseudo rows of the tri x sites
-        uint32_t nxs = 0;
-        for (uint32_t s = sb; s < se; ++s) {
-            const bool in_x = !het_only || db->type[s] == LGMI_TYPE_HET_SNP;
-            if (in_x) { pl.smap[s].xrow = nxs++; pl.xlist.push_back(s); }
-            pl.smap[s].xnext = nxs;
-            pl.smap[s].block = (uint32_t)b;
-        }
-        uint32_t nx = nxs;
-        for (uint32_t s = sb; s < se; ++s)
-            if (pl.smap[s].xrow != NONE && db->tri[s]) { pl.smap[s].prow = nx++; pl.xlist.push_back(db->pseudo_of_site[s]); }
-        // y list: non-x sites, x sites (same order as the x list), pseudo cols of every tri site
-        uint32_t ny = 0;
-        for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow == NONE) { pl.smap[s].ycol = ny++; pl.ylist.push_back(s); }
-        const uint32_t y_xpart = ny;
-        for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow != NONE) { pl.smap[s].ycol = ny++; pl.ylist.push_back(s); }
-        for (uint32_t s = sb; s < se; ++s) if (db->tri[s]) { pl.smap[s].pcol = ny++; pl.ylist.push_back(db->pseudo_of_site[s]); }
-        bp.nx = nx; bp.ny = ny; bp.nxs = nxs;
-        bp.ny_pad = (ny + 3u) & ~3u;
-        if (nxs == 0 || P < 2) { bp.nx = 0; }
-        pl.total_slots += (uint64_t)bp.nx * bp.ny_pad;
-        pl.plans[b] = bp;
-        // examined pairs: pairs a wave of the emit kernel will look at
-        for (uint32_t s = sb; s < se; ++s) {
-            const uint32_t ncand = (pl.smap[s].xrow != NONE) ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
-            pl.n_examined += ncand;
-            for (uint32_t g = 0; g * EMIT_SEG < ncand; ++g) pl.items.push_back(make_uint2(s, g));
-        }
-        if (bp.nx == 0) continue;
-        // which count kernel: the matrix-core kernel pays off on blocks with many columns and many reads
-        // (its 128 x 128 tile has a 256-store epilogue per lane); small or shallow blocks keep the
-        // VALU popcount kernel.  LGMI_COUNT_KERNEL=valu|mfma forces one of them (tests, A/B runs).
-        const uint32_t block_words = (db->block_n_reads[b] + 63u) / 64u;
-        bool use_mfma = bp.nx >= 96 && bp.ny >= 96 && block_words >= 32;
-        if (count_kernel_choice == 1) use_mfma = false;
-        if (count_kernel_choice >= 2) use_mfma = true;
-        if (db->block_n_reads[b] >= (1u << 26)) use_mfma = false;   // the int8 kernel's accumulators hold 64 * count in 32 bits
-        if (use_mfma && db->block_n_reads[b] >= (1u << 24)) pl.mfma_fp4 = false;
-        const uint32_t edge = use_mfma ? 128u : (uint32_t)TILE;
-        std::vector<Tile>& out_tiles = use_mfma ? pl.mtiles : pl.tiles;
-        // tiles: union band per `edge`-column group of each list
-        const uint32_t ntx = (bp.nx + edge - 1) / edge, nty = (bp.ny + edge - 1) / edge;
-        xmin.assign(ntx, 0xFFFFFFFFu); xmax.assign(ntx, 0); ymin.assign(nty, 0xFFFFFFFFu); ymax.assign(nty, 0);
-        for (uint32_t r = 0; r < bp.nx; ++r) {
-            const Col& c = db->cols[pl.xlist[bp.xl_off + r]];
-            if (!c.nw) continue;
-            xmin[r / edge] = std::min(xmin[r / edge], c.w0); xmax[r / edge] = std::max(xmax[r / edge], c.w0 + c.nw);
-        }
-        for (uint32_t q = 0; q < bp.ny; ++q) {
-            const Col& c = db->cols[pl.ylist[bp.yl_off + q]];
-            if (!c.nw) continue;
-            ymin[q / edge] = std::min(ymin[q / edge], c.w0); ymax[q / edge] = std::max(ymax[q / edge], c.w0 + c.nw);
-        }
-        // tile order: groups of XG x-tile rows sweep the y tiles together, so that the XG tiles that
-        // run side by side on an XCD (xcd_remap in the kernels) share one y tile in L2 and every y column is
-        // fetched from HBM once per group instead of once per x-tile row
-        uint32_t XG = use_mfma ? 4 : 8;
-        if (const char* e = getenv("LGMI_XG")) XG = (uint32_t)std::max(1, atoi(e));
-        for (uint32_t tg = 0; tg < ntx; tg += XG) {
-            for (uint32_t ty = 0; ty < nty; ++ty) {
-                if (ymin[ty] >= ymax[ty]) continue;
-                const uint32_t y0 = ty * edge, y1 = std::min(y0 + edge, bp.ny);
-                for (uint32_t tx = tg; tx < std::min(tg + XG, ntx); ++tx) {
-                    if (xmin[tx] >= xmax[tx]) continue;
-                    const uint32_t x0 = tx * edge, x1 = std::min(x0 + edge, bp.nx);
-                    // x site rows against x site cols: only row rank < col rank is ever read
-                    if (x1 <= nxs && y0 >= y_xpart && y1 <= y_xpart + nxs && x0 >= (y1 - 1 - y_xpart)) continue;
-                    const uint32_t k0 = std::max(xmin[tx], ymin[ty]), k1 = std::min(xmax[tx], ymax[ty]);
-                    if (k0 >= k1) continue;
-                    out_tiles.push_back(Tile{(uint32_t)b, x0, y0, k0, k1});
-                }
-            }
-        }
+    if (const char* e = getenv("LGMI_XG")) *xg = (uint32_t)std::max(1, atoi(e));
+}
+
+static PlanInput plan_input(const lgmi_dbatch* db) {
+    PlanInput in;
+    in.n_blocks = db->d.n_blocks; in.n_sites = db->d.n_sites;
+    in.block_site_begin = db->block_site_begin.data(); in.block_n_reads = db->block_n_reads.data();
+    in.type = db->type.data(); in.tri = db->tri.data(); in.cols = db->cols.data();
+    in.pseudo_of_site = db->pseudo_of_site.data();
+    return in;
+}
+
+// the same plan without a GPU (include/lgmi.h: lgmi_plan_shard)
+namespace {
+struct ShardPlanOwner {
+    std::vector<uint32_t> item_site, item_seg, tile_block, tile_x0, tile_y0, tile_edge, xrow, ycol, prow, pcol, xnext;
+};
+}
+
+extern "C" void lgmi_shard_plan_free(lgmi_shard_plan* p) {
+    if (!p) return;
+    delete static_cast<ShardPlanOwner*>(p->owner_);
+    memset(p, 0, sizeof *p);
+}
+
+extern "C" int lgmi_plan_shard(const lgmi_batch* b, int het_only, uint32_t shard_rank, uint32_t shard_world,
+                               lgmi_shard_plan* out) {
+    if (!out) return fail(LGMI_E_ARG, "out is NULL");
+    memset(out, 0, sizeof *out);
+    int rc = validate_batch(b);
+    if (rc) return rc;
+    if (shard_world == 0 || shard_rank >= shard_world) return fail(LGMI_E_ARG, "shard %u of %u", shard_rank, shard_world);
+    const uint64_t ns = b->n_sites;
+    // host restatement of what lgmi_batch_upload() derives on the device: tri flags and the column table
+    std::vector<uint8_t> tri(ns, 0);
+    std::vector<Col> cols(ns);
+    std::vector<uint32_t> pseudo_of_site(ns, NONE);
+    uint64_t off = 0;
+    for (uint64_t s = 0; s < ns; ++s) {
+        const uint64_t* lo = b->planes + b->site_plane_off[s];
+        const uint64_t* hi = lo + b->site_n_words[s];
+        uint64_t any0 = 0;
+        for (uint32_t k = 0; k < b->site_n_words[s]; ++k) any0 |= lo[k] & hi[k];
+        tri[s] = any0 ? 1 : 0;
+        cols[s] = Col{off, b->site_word_off[s], b->site_n_words[s]};
+        off += b->site_n_words[s];
     }
-    for (uint64_t s = 0; s < ns; ++s) pl.bytes_in += 16ull * db->cols[s].nw + 17ull;
+    for (uint64_t s = 0; s < ns; ++s)
+        if (tri[s]) {
+            pseudo_of_site[s] = (uint32_t)cols.size();
+            cols.push_back(Col{off, b->site_word_off[s], b->site_n_words[s]});
+            off += b->site_n_words[s];
+        }
+    std::vector<uint64_t> bsb(b->block_site_begin, b->block_site_begin + b->n_blocks + (b->block_site_begin ? 1 : 0));
+    if (bsb.empty()) bsb.push_back(0);
+    PlanInput in;
+    in.n_blocks = b->n_blocks; in.n_sites = ns; in.block_site_begin = bsb.data(); in.block_n_reads = b->block_n_reads;
+    in.type = b->site_type; in.tri = tri.data(); in.cols = cols.data(); in.pseudo_of_site = pseudo_of_site.data();
+    int ck; uint32_t xg;
+    plan_env(&ck, &xg);
+    Plan whole, mine;
+    build_plan(in, het_only != 0, 0, 1, ck, xg, whole);
+    build_plan(in, het_only != 0, shard_rank, shard_world, ck, xg, mine);
+    ShardPlanOwner* o = new ShardPlanOwner();
+    for (const uint2& it : mine.items) { o->item_site.push_back(it.x); o->item_seg.push_back(it.y); }
+    for (int kind = 0; kind < 2; ++kind)
+        for (const Tile& t : (kind ? mine.mtiles : mine.tiles)) {
+            o->tile_block.push_back(t.block); o->tile_x0.push_back(t.x0); o->tile_y0.push_back(t.y0);
+            o->tile_edge.push_back(kind ? 128u : (uint32_t)TILE);
+        }
+    for (const SiteMap& m : mine.smap) {
+        o->xrow.push_back(m.xrow); o->ycol.push_back(m.ycol); o->prow.push_back(m.prow); o->pcol.push_back(m.pcol);
+        o->xnext.push_back(m.xnext);
+    }
+    out->n_items_total = mine.items.size();
+    out->item_begin = mine.item_begin; out->item_end = mine.item_end;
+    out->n_examined_total = mine.n_examined_total; out->n_examined = mine.n_examined;
+    out->n_tiles_total = whole.tiles.size() + whole.mtiles.size();
+    out->n_tiles = o->tile_block.size();
+    out->item_site = o->item_site.data(); out->item_seg = o->item_seg.data();
+    out->tile_block = o->tile_block.data(); out->tile_x0 = o->tile_x0.data(); out->tile_y0 = o->tile_y0.data();
+    out->tile_edge = o->tile_edge.data();
+    out->site_xrow = o->xrow.data(); out->site_ycol = o->ycol.data(); out->site_prow = o->prow.data();
+    out->site_pcol = o->pcol.data(); out->site_xnext = o->xnext.data();
+    out->owner_ = o;
+    return LGMI_OK;
 }
 
 // ---------------------------------------------------------------- the run
@@ -558,6 +579,7 @@ extern "C" void lgmi_dresult_free(lgmi_dresult* r) {
     Pool& p = r->ctx->pool;
     p.release(r->d_i); p.release(r->d_j); p.release(r->d_mi); p.release(r->d_p);
     p.release(r->d_exceed); p.release(r->d_counts); p.release(r->d_mean); p.release(r->d_npairs);
+    p.release(r->d_sum);
     delete r;
 }
 
@@ -565,29 +587,45 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if (!ctx || !db || !prm || !out) return fail(LGMI_E_ARG, "NULL argument");
     *out = nullptr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
-    for (uint8_t r : prm->reserved) if (r) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
+    if (prm->reserved0) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
+    if (prm->exact_2x2 > 1) return fail(LGMI_E_ARG, "exact_2x2 must be 0 or 1");
     if (prm->n_shuffles > (1u << 24)) return fail(LGMI_E_ARG, "n_shuffles must be <= 2^24");
+    uint32_t sh_world = prm->shard_world, sh_rank = prm->shard_rank;
+    if (sh_world == 0) { if (sh_rank) return fail(LGMI_E_ARG, "shard_rank %u with shard_world 0", sh_rank); sh_world = 1; }
+    if (sh_rank >= sh_world) return fail(LGMI_E_ARG, "shard_rank %u >= shard_world %u", sh_rank, sh_world);
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     Pool& pool = ctx->pool;
     const uint32_t ns = (uint32_t)db->d.n_sites;
-    const bool want_p = prm->n_shuffles > 0;
+    const bool want_p = prm->n_shuffles > 0 || prm->exact_2x2;
     const bool want_counts = prm->emit_counts != 0;
     int rc;
 
     // the log-factorial table also serves the binomial draw of the 2 x 2 path: LF[0 .. n_shuffles]
     if (want_p && (rc = ensure_perm_tables(ctx, std::max(db->max_reads, prm->n_shuffles)))) return rc;   // first use only
     HIPCHK(hipEventRecord(ctx->ev[0], st));
+    const auto t_plan0 = std::chrono::steady_clock::now();
     Plan pl;
-    build_plan(db, prm->het_only != 0, pl);
-    if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull || pl.items.size() >= 0x7FFFFFFFull)
+    {
+        int ck; uint32_t xg;
+        plan_env(&ck, &xg);
+        build_plan(plan_input(db), prm->het_only != 0, sh_rank, sh_world, ck, xg, pl);
+    }
+    const float ms_plan_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
+    const size_t n_items = (size_t)(pl.item_end - pl.item_begin);
+    if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull || n_items >= 0x7FFFFFFFull)
         return fail(LGMI_E_ARG, "too many tiles");
+    // the permutation kernels carry row numbers in 32 bits (gen_list)
+    if (want_p && pl.n_examined >= 0xFFFFFFFFull)
+        return fail(LGMI_E_ARG, "%llu candidate rows: permutation p-values need fewer than 2^32 rows per run (shard the batch)",
+                    (unsigned long long)pl.n_examined);
 
     lgmi_dresult* res = new lgmi_dresult();
     res->ctx = ctx;
     res->n_sites = ns;
     res->has_p = want_p;
     res->has_counts = want_counts;
+    res->sharded = sh_world > 1;
     // scratch (returned to the pool at the end of the call) and the result
     std::vector<void*> scratch;
     struct Guard {
@@ -597,11 +635,11 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
 
     BlockPlan* d_plans; uint32_t* d_xlist; uint32_t* d_ylist; SiteMap* d_smap; Tile* d_tiles; Tile* d_mtiles; uint2* d_items;
-    uint32_t *sN, *sR, *sC, *sA, *d_rowcnt; uint64_t* d_rowstart; unsigned long long* d_sum; uint32_t* d_cnt;
+    uint32_t *sN, *sR, *sC, *sA, *d_rowcnt; uint64_t* d_rowstart; uint32_t* d_cnt;
     int* d_err; unsigned long long* d_wordpairs;
     if ((rc = salloc((void**)&d_plans, pl.plans.size() * sizeof(BlockPlan)))) return rc;
     if ((rc = salloc((void**)&d_xlist, pl.xlist.size() * 4))) return rc;
-    if ((rc = salloc((void**)&d_items, std::max<size_t>(pl.items.size(), 1) * sizeof(uint2)))) return rc;
+    if ((rc = salloc((void**)&d_items, std::max<size_t>(n_items, 1) * sizeof(uint2)))) return rc;
     if ((rc = salloc((void**)&d_ylist, pl.ylist.size() * 4))) return rc;
     if ((rc = salloc((void**)&d_smap, pl.smap.size() * sizeof(SiteMap)))) return rc;
     if ((rc = salloc((void**)&d_tiles, pl.tiles.size() * sizeof(Tile)))) return rc;
@@ -610,28 +648,29 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if ((rc = salloc((void**)&sR, pl.total_slots * 4))) return rc;
     if ((rc = salloc((void**)&sC, pl.total_slots * 4))) return rc;
     if ((rc = salloc((void**)&sA, pl.total_slots * 4))) return rc;
-    const size_t n_items = pl.items.size();
     if ((rc = salloc((void**)&d_rowcnt, std::max<size_t>(n_items, 1) * 4))) return rc;
     if ((rc = salloc((void**)&d_rowstart, (n_items + 1) * 8))) return rc;
-    if ((rc = salloc((void**)&d_sum, (size_t)ns * 8))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
     if ((rc = salloc((void**)&d_cnt, (size_t)ns * 4 + 16))) return rc;
     d_err = (int*)(d_cnt + ns);
+    unsigned int* d_gencount = (unsigned int*)(d_cnt + ns) + 1;
     d_wordpairs = nullptr;
     if ((rc = salloc((void**)&d_wordpairs, 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_mean, (size_t)ns * 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_npairs, (size_t)ns * 4))) return rc;
+    unsigned long long* d_sum = res->d_sum;
 
     auto h2d = [&](void* d, const void* h, size_t n) -> hipError_t {
         return n ? hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st) : hipSuccess;
     };
     HIPCHK(h2d(d_plans, pl.plans.data(), pl.plans.size() * sizeof(BlockPlan)));
     HIPCHK(h2d(d_xlist, pl.xlist.data(), pl.xlist.size() * 4));
-    HIPCHK(h2d(d_items, pl.items.data(), pl.items.size() * sizeof(uint2)));
+    HIPCHK(h2d(d_items, pl.items.data() + pl.item_begin, n_items * sizeof(uint2)));
     HIPCHK(h2d(d_ylist, pl.ylist.data(), pl.ylist.size() * 4));
     HIPCHK(h2d(d_smap, pl.smap.data(), pl.smap.size() * sizeof(SiteMap)));
     HIPCHK(h2d(d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)));
     HIPCHK(h2d(d_mtiles, pl.mtiles.data(), pl.mtiles.size() * sizeof(Tile)));
-    HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
+    if (ns) HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 16, st));
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
 
@@ -655,11 +694,19 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     launch_emit_count(st, ea);
     launch_scan(st, d_rowcnt, d_rowstart, (uint32_t)n_items);
     HIPCHK(hipGetLastError());
+    // Row arrays: the number of rows is only known on the device here.  When the upper bound (every examined pair
+    // is emitted — what a dense block does) fits a third of the device memory the arrays are sized by it and the
+    // stream runs on without the host; otherwise one 8-byte read-back sizes them exactly.
+    const size_t row_bytes = 16 + ((want_counts || want_p) ? 36 : 0) + (want_p ? 16 : 0);
+    uint64_t cap_rows = pl.n_examined;
+    const bool by_bound = (double)cap_rows * (double)row_bytes <= (double)ctx->mem_total / 3.0 && !getenv("LGMI_EXACT_ROW_ALLOC");
     uint64_t n_rows = 0;
-    HIPCHK(hipMemcpyAsync(&n_rows, d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    res->n_rows = n_rows;
-    const size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
+    if (!by_bound) {
+        HIPCHK(hipMemcpyAsync(&n_rows, d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        cap_rows = n_rows;
+    }
+    const size_t nr = (size_t)std::max<uint64_t>(cap_rows, 1);
     if ((rc = pool.alloc((void**)&res->d_i, nr * 4))) return rc;
     if ((rc = pool.alloc((void**)&res->d_j, nr * 4))) return rc;
     if ((rc = pool.alloc((void**)&res->d_mi, nr * 8))) return rc;
@@ -672,13 +719,19 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     launch_emit_write(st, ea);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
-    if (want_p && n_rows) {
-        uint32_t* d_genlist; unsigned int* d_gencount;
-        if ((rc = salloc((void**)&d_genlist, (size_t)n_rows * 4))) return rc;
-        if ((rc = salloc((void**)&d_gencount, 4))) return rc;
-        HIPCHK(hipMemsetAsync(d_gencount, 0, 4, st));
-        launch_perm(st, n_rows, res->d_i, res->d_j, res->d_counts, ctx->d_G, ctx->d_LF, prm->n_shuffles,
-                    prm->seed, res->d_p, res->d_exceed, d_genlist, d_gencount);
+    HIPCHK(hipEventRecord(ctx->ev[6], st));
+    if (want_p && cap_rows) {
+        uint32_t* d_genlist;
+        if ((rc = salloc((void**)&d_genlist, (size_t)cap_rows * 4))) return rc;
+        PermArgs pa{};
+        pa.n_rows_dev = d_rowstart + n_items; pa.max_rows = cap_rows;
+        pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
+        pa.n_shuffles = prm->n_shuffles; pa.seed = prm->seed; pa.exact_2x2 = prm->exact_2x2;
+        pa.out_p = res->d_p; pa.out_exceed = res->d_exceed; pa.gen_list = d_genlist; pa.gen_count = d_gencount;
+        launch_perm_fast(st, pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev[6], st));
+        launch_perm_general(st, pa);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
@@ -686,27 +739,37 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if (ns) HIPCHK(hipMemcpyAsync(res->d_npairs, d_cnt, (size_t)ns * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[5], st));
-    int err = 0; unsigned long long wp = 0;
+    int err = 0; unsigned long long wp = 0; unsigned int n_general = 0;
     HIPCHK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&n_general, d_gencount, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&wp, d_wordpairs, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&n_rows, d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (err) return fail(LGMI_E_DOMAIN, "math domain error: a pair with 0 common reads reached the MI (min_common == 0)");
+    if (n_rows > cap_rows) return fail(LGMI_E_STATE, "internal: %llu rows exceed the planned bound %llu",
+                                       (unsigned long long)n_rows, (unsigned long long)cap_rows);
+    res->n_rows = n_rows;
 
     lgmi_run_info& inf = res->info;
     inf.n_rows = n_rows;
     inf.n_examined = pl.n_examined;
+    inf.n_examined_total = pl.n_examined_total;
+    inf.n_general_rows = n_general;
     inf.n_tile_pairs = (uint64_t)pl.tiles.size() * TILE * TILE + (uint64_t)pl.mtiles.size() * 128 * 128;
     inf.word_pairs = wp;
     inf.bytes_in = pl.bytes_in;
-    inf.bytes_out = n_rows * (16ull + (want_p ? 8ull : 0ull) + (want_counts ? 36ull : 0ull));
+    inf.bytes_out = n_rows * (16ull + (want_p ? 12ull : 0ull) + (want_counts ? 36ull : 0ull));
     inf.n_count_launches = (pl.tiles.empty() ? 0 : 1) + (pl.mtiles.empty() ? 0 : 1);
     inf.n_mfma_tiles = (uint32_t)std::min<size_t>(pl.mtiles.size(), 0xFFFFFFFFu);
     inf.mfma_dtype = pl.mtiles.empty() ? 0u : (pl.mfma_fp4 ? 2u : 1u);
-    inf.reserved = 0;
+    inf.reserved = 0; inf.reserved2 = 0;
+    inf.ms_plan_host = ms_plan_host;
     HIPCHK(hipEventElapsedTime(&inf.ms_prep, ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&inf.ms_count, ctx->ev[1], ctx->ev[2]));
     HIPCHK(hipEventElapsedTime(&inf.ms_emit, ctx->ev[2], ctx->ev[3]));
     HIPCHK(hipEventElapsedTime(&inf.ms_perm, ctx->ev[3], ctx->ev[4]));
+    HIPCHK(hipEventElapsedTime(&inf.ms_perm_fast, ctx->ev[3], ctx->ev[6]));
+    HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&inf.ms_mean, ctx->ev[4], ctx->ev[5]));
     HIPCHK(hipEventElapsedTime(&inf.ms_total, ctx->ev[0], ctx->ev[5]));
     if (!want_counts && res->d_counts) { pool.release(res->d_counts); res->d_counts = nullptr; }

@@ -161,7 +161,12 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
                 atomicAdd(&a.site_cnt[j], 1u);
             }
             if (a.out_counts) {
-                // the valid lanes' tables are consecutive rows: write them as one contiguous run, 64 dwords per store
+                // the valid lanes' tables are consecutive rows: write them as one contiguous run, 64 dwords per store.
+                // The stores above sit in divergent code and other lanes read them here: order them explicitly
+                // (LDS operations of one wave execute in order, but the compiler must not move them across)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t n_dw = 9u * (uint32_t)__popcll(ball);
                 uint32_t* dst = a.out_counts + 9ull * (base_row + running);
 #pragma unroll
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
                     const uint32_t idx = 64u * k + lane;
                     if (idx < n_dw) dst[idx] = cstage[wv][idx];
                 }
+                __builtin_amdgcn_wave_barrier();     // the next trip's stores stay behind these loads
             }
             running += (uint32_t)__popcll(ball);
         }

@@ -58,6 +58,15 @@ static const uint32_t NONE = 0xFFFFFFFFu;
 // what lgmi_result.owner_ points to (api.cpp, comm.cpp); released by lgmi_result_free()
 struct ResultOwner { virtual ~ResultOwner() {} };
 
+// device arrays of a resident result, as comm.cpp sees them (lgmi_dresult stays private to api.cpp)
+struct DResultView {
+    uint64_t n_rows = 0, n_sites = 0;
+    const uint32_t* i = nullptr; const uint32_t* j = nullptr; const double* mi = nullptr;
+    const double* p = nullptr; const uint32_t* exceed = nullptr; const uint32_t* counts = nullptr;
+    const double* mean = nullptr; const uint32_t* npairs = nullptr; const unsigned long long* sum = nullptr;
+    lgmi_run_info info = {};
+};
+
 static const int TILE = 64;      // tile edge in columns
 static const int KC = 8;         // 64-bit words staged per LDS stage
 static const double MEAN_SCALE = 1099511627776.0;  // 2^40 fixed point for mean MI
@@ -110,7 +119,7 @@ struct EmitArgs {
     int* err_flag;            // set to 1 when a pair with N == 0 reaches the MI
     unsigned long long* word_pairs;  // pass 1: sum over examined pairs of overlapping words
 };
-static const uint32_t EMIT_SEG = 8192;   // multiple of 64
+static const uint32_t EMIT_SEG = LGMI_EMIT_SEG;   // multiple of 64
 void launch_emit_count(hipStream_t st, const EmitArgs& a);
 void launch_scan(hipStream_t st, const uint32_t* cnt, uint64_t* start, uint32_t n);
 void launch_emit_write(hipStream_t st, const EmitArgs& a);
@@ -120,9 +129,18 @@ void launch_rows_mean(hipStream_t st, uint64_t n_rows, const uint32_t* ri, const
                       const double* mi, unsigned long long* sum, uint32_t* cnt);
 
 // perm.hip
-void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const uint32_t* out_j,
-                 const uint32_t* counts, const long long* G, const double* LF, uint32_t n_shuffles, uint64_t seed,
-                 double* out_p, uint32_t* out_exceed, uint32_t* gen_list, unsigned int* gen_count);
+struct PermArgs {
+    const uint64_t* n_rows_dev;   // number of rows, on the device (the host may not know it yet)
+    uint64_t max_rows;            // upper bound the grids are sized by
+    const uint32_t* row_i; const uint32_t* row_j; const uint32_t* counts;
+    const long long* G; const double* LF;
+    uint32_t n_shuffles; uint64_t seed;
+    int exact_2x2;                // rows with at most 2 x 2 non-empty classes get the exact p, not a binomial draw
+    double* out_p; uint32_t* out_exceed;
+    uint32_t* gen_list; unsigned int* gen_count;
+};
+void launch_perm_fast(hipStream_t st, const PermArgs& a);
+void launch_perm_general(hipStream_t st, const PermArgs& a);
 
 // ecdf.hip
 size_t ecdf_sort_temp_bytes(uint32_t n);

@@ -12,7 +12,7 @@
 //
 //   k_perm_fast     one lane per row.  Degenerate tables: p = 1.  2 x 2 tables (one
 //                   degree of freedom k): the mass P_tail of the "as or more extreme" set is
-//                   summed exactly from log-factorials (units of 16 values dealt evenly over
+//                   summed exactly from log-factorials (units of 64 values dealt evenly over
 //                   the wave, integer fixed-point sums), and the number of shuffles that land
 //                   in the set is drawn as one Binomial(n_shuffles, P_tail) variate — pure
 //                   ALU + Philox, no table is materialised.  Larger tables are queued for
@@ -32,8 +32,15 @@
 //    1 candidate Philox with 5 rounds      2 exp in the HRUA test replaced by 1 + t      4 set-up sqrt in f32
 //    8 threshold-table draw replaced by a cheap hash      16 general rows not queued (k_perm_fast alone)
 //   32 exact-tail sums skipped      64 bisection skipped      128 binomial draw skipped
-//  256 HRUA set-up skipped (generic path; needs 1024+2048 not to hang)      1024 statistic look-ups skipped
-// 2048 HRUA quotients never recomputed      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
+// 1024 statistic look-ups skipped      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
+// Every surviving bit keeps all table indices inside the range the normal path uses and keeps every rejection
+// loop's acceptance probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the
+// acceptance test unsatisfiable, so k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536,
+// one of which indexed LF[] with set-up values it had skipped (GPU memory fault).  They are gone for good.
+#endif
+#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192)
+#if LGMI_PABL & ~LGMI_PABL_KNOWN
+#error "LGMI_PABL: unknown ablation bit (see the list above; 256, 2048, 16384, 32768, 65536 were removed: they hang or fault)"
 #endif
 
 namespace lgmi {
@@ -131,7 +138,8 @@ __device__ __forceinline__ long long stat22(const long long* __restrict__ G, con
 
 __device__ __forceinline__ double pmf22(const double* __restrict__ LF, const HG22& h, uint32_t k) {
 #if LGMI_PABL & 4096
-    return det_exp(h.c0 - LF[k & 15u] - LF[(h.K - k) & 15u] - LF[(h.n - k) & 15u] - LF[(h.N - h.K - h.n + k) & 15u] - 3.0e6);
+    { const uint32_t md = h.N + 1u;   // LF[] has at least N + 1 entries
+      return det_exp(h.c0 - LF[(k & 15u) % md] - LF[((h.K - k) & 15u) % md] - LF[((h.n - k) & 15u) % md] - LF[((h.N - h.K - h.n + k) & 15u) % md] - 3.0e6); }
 #endif
     double e = h.c0;
     e -= LF[k];
@@ -275,13 +283,17 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int 
     return ((unsigned long long)bcast32((uint32_t)(v >> 32), L) << 32) | bcast32((uint32_t)v, L);
 }
 
-__global__ __launch_bounds__(64) void k_perm_fast(
-    uint64_t n_rows, const uint32_t* __restrict__ row_i, const uint32_t* __restrict__ row_j,
-    const uint32_t* __restrict__ counts, const long long* __restrict__ G, const double* __restrict__ LF,
-    uint32_t n_shuffles, uint64_t seed, double* __restrict__ out_p, uint32_t* __restrict__ out_exceed,
-    uint32_t* __restrict__ gen_list, unsigned int* __restrict__ gen_count)
+__global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 {
+    const uint64_t n_rows = *pa.n_rows_dev;
+    const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
+    const uint32_t* __restrict__ counts = pa.counts;
+    const long long* __restrict__ G = pa.G; const double* __restrict__ LF = pa.LF;
+    const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
+    double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
+    uint32_t* __restrict__ gen_list = pa.gen_list; unsigned int* __restrict__ gen_count = pa.gen_count;
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((uint64_t)blockIdx.x * blockDim.x >= n_rows) return;      // wave-uniform: the grid is sized by an upper bound
     const uint32_t lane = threadIdx.x & 63u;
     // ---- phase A (one lane per row): classify, set up the hypergeometric, find the bounds
     int kind = 0;   // 0 nothing, 1 degenerate, 2 two-by-two, 3 queued for k_perm_general
@@ -313,14 +325,15 @@ __global__ __launch_bounds__(64) void k_perm_fast(
             h.c0 += LF[N - h.n];
             h.c0 -= LF[N];
 #if LGMI_PABL & 64
-            tb.klo = T[3 * a2 + b2]; tb.khi = tb.klo + 40; tb.centre = 1;
+            tb.klo = T[3 * a2 + b2]; tb.khi = tb.klo + 40 <= (long long)h.kmax + 1 ? tb.klo + 40 : (long long)h.kmax + 1; tb.centre = 1;   // stays inside the support
 #else
             tb = bounds22(G, h, T[3 * a2 + b2]);
 #endif
         } else {
             kind = 3;
 #if !(LGMI_PABL & 16)
-            gen_list[atomicAdd(gen_count, 1u)] = (uint32_t)r;
+            if (n_shuffles) gen_list[atomicAdd(gen_count, 1u)] = (uint32_t)r;
+            else { out_exceed[r] = LGMI_EXCEED_EXACT; out_p[r] = __longlong_as_double(0x7ff8000000000000ll); }   // exact_2x2 only: no estimate
 #endif
         }
     }
@@ -397,6 +410,19 @@ __global__ __launch_bounds__(64) void k_perm_fast(
     }
     __syncthreads();
     unsigned long long thr = 0ull;
+    if (pa.exact_2x2 && (kind == 1 || kind == 2)) {
+        // the exact p: the mass itself (oracle/lgmi_perm_oracle.c: ptail22's p_out), no Monte-Carlo draw
+        double p = 1.0;
+        if (kind == 2) {
+            const unsigned long long sm = s_acc[w][lane];
+            p = tb.centre ? 1.0 - (double)sm * 2.168404344971009e-19 : (double)sm * 2.168404344971009e-19;
+            if (p > 1.0) p = 1.0;
+            if (p < 0.0) p = 0.0;
+        }
+        out_exceed[r] = LGMI_EXCEED_EXACT;
+        out_p[r] = p;
+        return;
+    }
     if (kind == 2) {
         const unsigned long long sm = s_acc[w][lane];
         if (tb.centre) thr = sm <= 4611686018427387904ull ? (4611686018427387904ull - sm) >> 30 : 0ull;
@@ -486,12 +512,14 @@ __device__ __forceinline__ unsigned long long to_fixed52(double p) {
     return (unsigned long long)__double_as_longlong(t) & 0x000FFFFFFFFFFFFFull;
 }
 
-__global__ __launch_bounds__(64) void k_perm_general(
-    const uint32_t* __restrict__ gen_list, const unsigned int* __restrict__ gen_count,
-    const uint32_t* __restrict__ row_i, const uint32_t* __restrict__ row_j, const uint32_t* __restrict__ counts,
-    const long long* __restrict__ G, const double* __restrict__ LF, uint32_t n_shuffles, uint64_t seed,
-    double* __restrict__ out_p, uint32_t* __restrict__ out_exceed)
+__global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
 {
+    const uint32_t* __restrict__ gen_list = pa.gen_list; const unsigned int* __restrict__ gen_count = pa.gen_count;
+    const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
+    const uint32_t* __restrict__ counts = pa.counts;
+    const long long* __restrict__ G = pa.G; const double* __restrict__ LF = pa.LF;
+    const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
+    double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
     __shared__ uint32_t tab_thr[FIRST_MAX];
     __shared__ uint16_t tab_guide[257];     // tab_guide[b] = the draw for u = b << 24: where the search for u >> 24 == b starts
     __shared__ uint32_t next_s;
@@ -760,7 +788,7 @@ __global__ __launch_bounds__(64) void k_perm_general(
 #if LGMI_PABL & 8
             const U4 o = cheap_rng(g.s + ci, g.call + cj);
             g.call++;
-            return tab_klo + (tab_n >> 1) + (o.x & 7u);
+            { const uint32_t e_ = (tab_n >> 1) + (o.x & 7u); return tab_klo + (e_ < tab_n ? e_ : tab_n - 1u); }   // stays inside the window
 #else
             const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
 #endif
@@ -897,9 +925,6 @@ __global__ __launch_bounds__(64) void k_perm_general(
                         g.mn = good < bad ? good : bad;
                         g.mx = good < bad ? bad : good;
                         g.d6 = (double)g.m * hb.d4 + 0.5;
-#if LGMI_PABL & 256
-                        g.d8 = 100.0; g.d10 = -1000.0; g.d11 = (double)((g.m < g.mn ? g.m : g.mn) + 1u); g.phase = 1; break;
-#endif
 #if LGMI_PABL & 4
                         const double d7 = (double)__fsqrt_rn((float)((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5));
 #else
@@ -929,17 +954,18 @@ __global__ __launch_bounds__(64) void k_perm_general(
     }
 }
 
-void launch_perm(hipStream_t st, uint64_t n_rows, const uint32_t* out_i, const uint32_t* out_j,
-                 const uint32_t* counts, const long long* G, const double* LF, uint32_t n_shuffles, uint64_t seed,
-                 double* out_p, uint32_t* out_exceed, uint32_t* gen_list, unsigned int* gen_count)
+void launch_perm_fast(hipStream_t st, const PermArgs& a)
 {
-    if (!n_rows) return;
-    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)((n_rows + 63) / 64)), dim3(64), 0, st, n_rows, out_i, out_j,
-                       counts, G, LF, n_shuffles, seed, out_p, out_exceed, gen_list, gen_count);
+    if (!a.max_rows) return;
+    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)((a.max_rows + 63) / 64)), dim3(64), 0, st, a);
+}
+
+void launch_perm_general(hipStream_t st, const PermArgs& a)
+{
+    if (!a.max_rows || !a.n_shuffles) return;
     // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
     // stride over the queued rows
-    hipLaunchKernelGGL(k_perm_general, dim3(256 * 16), dim3(64), 0, st, gen_list, gen_count, out_i, out_j, counts, G, LF,
-                       n_shuffles, seed, out_p, out_exceed);
+    hipLaunchKernelGGL(k_perm_general, dim3(256 * 16), dim3(64), 0, st, a);
 }
 
 }  // namespace lgmi

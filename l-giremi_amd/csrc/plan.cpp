@@ -1,0 +1,208 @@
+// plan.cpp — host-side planner (see plan.h).  No HIP runtime call in this file.
+//
+// Layout of a block's slot matrix (unchanged since round 1): rows = x sites in position order (all sites, or the
+// het_snp ones when het_only — src/giremi/mismatch.py:392-396), then one pseudo row per tri x site; columns = non-x
+// sites, x sites, one pseudo column per tri site.  Rows of the RESULT are in the reference's order
+// (itertools.combinations of the sorted positions, src/giremi/mutual_information.py:10-12): site i's row lists its
+// partners j > i (x site: every later site; other site: the later x sites).  A work item is EMIT_SEG consecutive
+// partners of one site.  A shard is a contiguous range of work items, so its rows are a contiguous range of the
+// unsharded result, and it needs exactly the count tiles its items read slots from.
+#include "plan.h"
+
+#include <algorithm>
+
+namespace lgmi {
+
+namespace {
+
+struct NeedMap {                       // which (x tile, y tile) of a block this shard reads slots from
+    uint32_t ntx = 0, nty = 0, edge = 1;
+    std::vector<uint8_t> bits;
+    void reset(uint32_t ntx_, uint32_t nty_, uint32_t edge_) { ntx = ntx_; nty = nty_; edge = edge_; bits.assign((size_t)ntx * nty, 0); }
+    void mark(uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1) {      // half-open slot ranges
+        if (r0 >= r1 || c0 >= c1) return;
+        const uint32_t tx0 = r0 / edge, tx1 = (r1 - 1) / edge, ty0 = c0 / edge, ty1 = (c1 - 1) / edge;
+        for (uint32_t tx = tx0; tx <= tx1; ++tx)
+            for (uint32_t ty = ty0; ty <= ty1; ++ty) bits[(size_t)tx * nty + ty] = 1;
+    }
+    bool get(uint32_t tx, uint32_t ty) const { return bits[(size_t)tx * nty + ty] != 0; }
+};
+
+}  // namespace
+
+void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_t shard_world, int count_kernel,
+                uint32_t xg_override, Plan& pl)
+{
+    if (shard_world == 0) { shard_world = 1; shard_rank = 0; }
+    const bool sharded = shard_world > 1;
+    if (count_kernel == 3) pl.mfma_fp4 = false;
+    const uint64_t ns = in.n_sites;
+    pl.smap.assign(ns, SiteMap{NONE, NONE, NONE, NONE, 0, 0});
+    pl.plans.resize(in.n_blocks);
+
+    // ---- pass 1: slot-matrix layout of every block, the work items of the whole batch and their costs
+    std::vector<uint64_t> item_cost;                     // partners x words of the block
+    std::vector<uint32_t> item_block, item_ncand;
+    for (uint64_t b = 0; b < in.n_blocks; ++b) {
+        const uint32_t sb = (uint32_t)in.block_site_begin[b], se = (uint32_t)in.block_site_begin[b + 1];
+        const uint32_t P = se - sb;
+        BlockPlan bp{};
+        bp.slot_base = pl.total_slots;
+        bp.xl_off = (uint32_t)pl.xlist.size();
+        bp.yl_off = (uint32_t)pl.ylist.size();
+        bp.site_begin = sb;
+        bp.site_end = se;
+        // x list: x sites in position order, then pseudo rows of the tri x sites
+        uint32_t nxs = 0;
+        for (uint32_t s = sb; s < se; ++s) {
+            const bool in_x = !het_only || in.type[s] == LGMI_TYPE_HET_SNP;
+            if (in_x) { pl.smap[s].xrow = nxs++; pl.xlist.push_back(s); }
+            pl.smap[s].xnext = nxs;
+            pl.smap[s].block = (uint32_t)b;
+        }
+        uint32_t nx = nxs;
+        for (uint32_t s = sb; s < se; ++s)
+            if (pl.smap[s].xrow != NONE && in.tri[s]) { pl.smap[s].prow = nx++; pl.xlist.push_back(in.pseudo_of_site[s]); }
+        // y list: non-x sites, x sites (same order as the x list), pseudo cols of every tri site
+        uint32_t ny = 0;
+        for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow == NONE) { pl.smap[s].ycol = ny++; pl.ylist.push_back(s); }
+        for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow != NONE) { pl.smap[s].ycol = ny++; pl.ylist.push_back(s); }
+        for (uint32_t s = sb; s < se; ++s) if (in.tri[s]) { pl.smap[s].pcol = ny++; pl.ylist.push_back(in.pseudo_of_site[s]); }
+        bp.nx = nx; bp.ny = ny; bp.nxs = nxs;
+        bp.ny_pad = (ny + 3u) & ~3u;
+        if (nxs == 0 || P < 2) { bp.nx = 0; }
+        pl.total_slots += (uint64_t)bp.nx * bp.ny_pad;
+        pl.plans[b] = bp;
+        // examined pairs: pairs a wave of the emit kernel will look at
+        const uint64_t W = std::max<uint64_t>(1, ((uint64_t)in.block_n_reads[b] + 63u) / 64u);
+        for (uint32_t s = sb; s < se; ++s) {
+            const uint32_t ncand = (pl.smap[s].xrow != NONE) ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
+            pl.n_examined_total += ncand;
+            for (uint32_t g = 0; g * EMIT_SEG < ncand; ++g) {
+                pl.items.push_back(make_uint2(s, g));
+                const uint32_t n_in_seg = std::min<uint32_t>(EMIT_SEG, ncand - g * EMIT_SEG);
+                item_ncand.push_back(n_in_seg);
+                item_cost.push_back((uint64_t)n_in_seg * W);
+                item_block.push_back((uint32_t)b);
+            }
+        }
+    }
+
+    // ---- the shard: a contiguous, cost-balanced range of the work items
+    const uint64_t n_items = pl.items.size();
+    pl.item_begin = 0;
+    pl.item_end = n_items;
+    if (sharded) {
+        unsigned __int128 total = 0;
+        for (uint64_t c : item_cost) total += c;
+        const unsigned __int128 lo = total * shard_rank / shard_world, hi = total * (shard_rank + 1u) / shard_world;
+        unsigned __int128 run = 0;
+        uint64_t k = 0;
+        while (k < n_items && run < lo) run += item_cost[k++];     // first item whose start cost is >= lo
+        pl.item_begin = k;
+        while (k < n_items && run < hi) run += item_cost[k++];
+        pl.item_end = (shard_rank + 1u == shard_world) ? n_items : k;
+    }
+    for (uint64_t k = pl.item_begin; k < pl.item_end; ++k) pl.n_examined += item_ncand[k];
+
+    // ---- pass 2: count tiles, block by block; a sharded run keeps the tiles its items read from
+    std::vector<uint32_t> xmin, xmax, ymin, ymax, xbefore, tribefore, trix_before;
+    NeedMap need;
+    uint64_t item_cursor = 0;          // items are in block order: walk them once
+    for (uint64_t b = 0; b < in.n_blocks; ++b) {
+        const BlockPlan& bp = pl.plans[b];
+        const uint32_t sb = bp.site_begin, se = bp.site_end, P = se - sb, nxs = bp.nxs;
+        uint64_t blk_item_begin = item_cursor;
+        while (item_cursor < n_items && item_block[item_cursor] == b) ++item_cursor;
+        const uint64_t blk_item_end = item_cursor;
+        if (bp.nx == 0) continue;
+        const uint32_t y_xpart = P - nxs;
+        // which count kernel: the matrix-core kernel pays off on blocks with many columns and many reads
+        // (its 128 x 128 tile has a 256-store epilogue per lane); small or shallow blocks keep the
+        // VALU popcount kernel.  LGMI_COUNT_KERNEL=valu|mfma forces one of them (tests, A/B runs).
+        const uint32_t block_words = (in.block_n_reads[b] + 63u) / 64u;
+        bool use_mfma = bp.nx >= 96 && bp.ny >= 96 && block_words >= 32;
+        if (count_kernel == 1) use_mfma = false;
+        if (count_kernel >= 2) use_mfma = true;
+        if (in.block_n_reads[b] >= (1u << 26)) use_mfma = false;   // the int8 kernel's accumulators hold 64 * count in 32 bits
+        if (use_mfma && in.block_n_reads[b] >= (1u << 24)) pl.mfma_fp4 = false;
+        const uint32_t edge = use_mfma ? 128u : (uint32_t)TILE;
+        std::vector<Tile>& out_tiles = use_mfma ? pl.mtiles : pl.tiles;
+        const uint32_t ntx = (bp.nx + edge - 1) / edge, nty = (bp.ny + edge - 1) / edge;
+
+        if (sharded) {
+            need.reset(ntx, nty, edge);
+            const uint64_t a = std::max(blk_item_begin, pl.item_begin), e = std::min(blk_item_end, pl.item_end);
+            if (a >= e) continue;                        // none of this block's rows belong to the shard
+            xbefore.assign(P + 1, 0); tribefore.assign(P + 1, 0); trix_before.assign(nxs + 1, 0);
+            for (uint32_t k = 0; k < P; ++k) {
+                const bool is_x = pl.smap[sb + k].xrow != NONE;
+                xbefore[k + 1] = xbefore[k] + (is_x ? 1u : 0u);
+                tribefore[k + 1] = tribefore[k] + (in.tri[sb + k] ? 1u : 0u);
+                if (is_x) trix_before[xbefore[k + 1]] = trix_before[xbefore[k]] + (in.tri[sb + k] ? 1u : 0u);
+            }
+            for (uint64_t it = a; it < e; ++it) {
+                const uint32_t i = pl.items[it].x, g = pl.items[it].y;
+                const SiteMap& mi = pl.smap[i];
+                if (mi.xrow != NONE) {
+                    const uint32_t ncand = se - 1u - i;
+                    const uint32_t qa = g * EMIT_SEG, qb = std::min(ncand, (g + 1u) * EMIT_SEG);
+                    const uint32_t ka = i + 1u + qa - sb, kb = i + 1u + qb - sb;       // partner sites, block-local
+                    const uint32_t c0[3] = {ka - xbefore[ka], y_xpart + xbefore[ka], P + tribefore[ka]};
+                    const uint32_t c1[3] = {kb - xbefore[kb], y_xpart + xbefore[kb], P + tribefore[kb]};
+                    for (int part = 0; part < 3; ++part) {
+                        need.mark(mi.xrow, mi.xrow + 1u, c0[part], c1[part]);
+                        if (mi.prow != NONE) need.mark(mi.prow, mi.prow + 1u, c0[part], c1[part]);
+                    }
+                } else {
+                    const uint32_t ncand = nxs - mi.xnext;
+                    const uint32_t xa = mi.xnext + g * EMIT_SEG, xb = mi.xnext + std::min(ncand, (g + 1u) * EMIT_SEG);
+                    const uint32_t pa = nxs + trix_before[xa], pb = nxs + trix_before[xb];
+                    need.mark(xa, xb, mi.ycol, mi.ycol + 1u);
+                    need.mark(pa, pb, mi.ycol, mi.ycol + 1u);
+                    if (mi.pcol != NONE) {
+                        need.mark(xa, xb, mi.pcol, mi.pcol + 1u);
+                        need.mark(pa, pb, mi.pcol, mi.pcol + 1u);
+                    }
+                }
+            }
+        }
+
+        // tiles: union band per `edge`-column group of each list
+        xmin.assign(ntx, 0xFFFFFFFFu); xmax.assign(ntx, 0); ymin.assign(nty, 0xFFFFFFFFu); ymax.assign(nty, 0);
+        for (uint32_t r = 0; r < bp.nx; ++r) {
+            const Col& c = in.cols[pl.xlist[bp.xl_off + r]];
+            if (!c.nw) continue;
+            xmin[r / edge] = std::min(xmin[r / edge], c.w0); xmax[r / edge] = std::max(xmax[r / edge], c.w0 + c.nw);
+        }
+        for (uint32_t q = 0; q < bp.ny; ++q) {
+            const Col& c = in.cols[pl.ylist[bp.yl_off + q]];
+            if (!c.nw) continue;
+            ymin[q / edge] = std::min(ymin[q / edge], c.w0); ymax[q / edge] = std::max(ymax[q / edge], c.w0 + c.nw);
+        }
+        // tile order: groups of XG x-tile rows sweep the y tiles together, so that the XG tiles that
+        // run side by side on an XCD (xcd_remap in the kernels) share one y tile in L2 and every y column is
+        // fetched from HBM once per group instead of once per x-tile row
+        uint32_t XG = use_mfma ? 4 : 8;
+        if (xg_override) XG = xg_override;
+        for (uint32_t tg = 0; tg < ntx; tg += XG) {
+            for (uint32_t ty = 0; ty < nty; ++ty) {
+                if (ymin[ty] >= ymax[ty]) continue;
+                const uint32_t y0 = ty * edge, y1 = std::min(y0 + edge, bp.ny);
+                for (uint32_t tx = tg; tx < std::min(tg + XG, ntx); ++tx) {
+                    if (xmin[tx] >= xmax[tx]) continue;
+                    const uint32_t x0 = tx * edge, x1 = std::min(x0 + edge, bp.nx);
+                    // x site rows against x site cols: only row rank < col rank is ever read
+                    if (x1 <= nxs && y0 >= y_xpart && y1 <= y_xpart + nxs && x0 >= (y1 - 1 - y_xpart)) continue;
+                    const uint32_t k0 = std::max(xmin[tx], ymin[ty]), k1 = std::min(xmax[tx], ymax[ty]);
+                    if (k0 >= k1) continue;
+                    if (sharded && !need.get(tx, ty)) continue;
+                    out_tiles.push_back(Tile{(uint32_t)b, x0, y0, k0, k1});
+                }
+            }
+        }
+    }
+    for (uint64_t s = 0; s < ns; ++s) pl.bytes_in += 16ull * in.cols[s].nw + 17ull;
+}
+
+}  // namespace lgmi

@@ -9,10 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LGMI_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'liblgmi.so'))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, E_ARG, E_OOM, E_HIP, E_RCCL, E_NODEV, E_STATE, E_DOMAIN = 0, -1, -2, -3, -4, -5, -6, -7
 TYPE_MISMATCH, TYPE_SNP, TYPE_HET_SNP = 0, 1, 2
 UNIQUE_ID_BYTES = 128
+EMIT_SEG = 8192
+EXCEED_EXACT = 0xFFFFFFFF
+NONE = 0xFFFFFFFF
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
 i64p, f64p = C.POINTER(C.c_int64), C.POINTER(C.c_double)
@@ -27,7 +30,8 @@ class Batch(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [('min_common', C.c_uint32), ('n_shuffles', C.c_uint32), ('seed', C.c_uint64),
-                ('het_only', C.c_uint8), ('emit_counts', C.c_uint8), ('reserved', C.c_uint8 * 6)]
+                ('het_only', C.c_uint8), ('emit_counts', C.c_uint8), ('exact_2x2', C.c_uint8),
+                ('reserved0', C.c_uint8), ('shard_rank', C.c_uint16), ('shard_world', C.c_uint16)]
 
 
 class Result(C.Structure):
@@ -42,10 +46,27 @@ class RunInfo(C.Structure):
                 ('ms_total', C.c_float), ('ms_prep', C.c_float), ('ms_count', C.c_float),
                 ('ms_emit', C.c_float), ('ms_perm', C.c_float), ('ms_mean', C.c_float),
                 ('n_count_launches', C.c_uint32), ('n_mfma_tiles', C.c_uint32),
-                ('mfma_dtype', C.c_uint32), ('reserved', C.c_uint32)]
+                ('mfma_dtype', C.c_uint32), ('reserved', C.c_uint32),
+                ('n_examined_total', C.c_uint64), ('n_general_rows', C.c_uint64),
+                ('ms_plan_host', C.c_float), ('ms_perm_fast', C.c_float), ('ms_perm_general', C.c_float),
+                ('reserved2', C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}
+
+
+class ShardPlan(C.Structure):
+    _fields_ = [('n_items_total', C.c_uint64), ('item_begin', C.c_uint64), ('item_end', C.c_uint64),
+                ('n_examined_total', C.c_uint64), ('n_examined', C.c_uint64),
+                ('n_tiles_total', C.c_uint64), ('n_tiles', C.c_uint64),
+                ('item_site', u32p), ('item_seg', u32p),
+                ('tile_block', u32p), ('tile_x0', u32p), ('tile_y0', u32p), ('tile_edge', u32p),
+                ('site_xrow', u32p), ('site_ycol', u32p), ('site_prow', u32p), ('site_pcol', u32p),
+                ('site_xnext', u32p), ('owner_', C.c_void_p)]
+
+
+class GatherOpts(C.Structure):
+    _fields_ = [('site_base', C.c_uint32), ('same_batch', C.c_uint8), ('reserved', C.c_uint8 * 3)]
 
 
 class SynthSpec(C.Structure):
@@ -81,9 +102,14 @@ SYMBOLS = {
     'lgmi_result_free': (None, [C.POINTER(Result)]),
     'lgmi_site_mean': (C.c_int, [VP, C.c_uint64, u32p, u32p, f64p, C.c_uint64, f64p, u32p]),
     'lgmi_ecdf': (C.c_int, [VP, C.c_uint64, f64p, C.c_uint64, f64p, f64p]),
+    'lgmi_plan_shard': (C.c_int, [C.POINTER(Batch), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(ShardPlan)]),
+    'lgmi_shard_plan_free': (None, [C.POINTER(ShardPlan)]),
+    'lgmi_ctx_synchronize': (C.c_int, [VP]),
     'lgmi_comm_unique_id': (C.c_int, [VP]),
     'lgmi_comm_init': (C.c_int, [VP, VP, C.c_int, C.c_int]),
     'lgmi_comm_allgather_u64': (C.c_int, [VP, C.c_uint64, u64p]),
+    'lgmi_comm_allgather_u64v': (C.c_int, [VP, u64p, C.c_uint32, u64p]),
+    'lgmi_comm_gather': (C.c_int, [VP, VP, C.c_int, C.POINTER(GatherOpts), C.POINTER(VP), u64p]),
     'lgmi_comm_gather_rows': (C.c_int, [VP, VP, C.c_int, C.POINTER(Result)]),
     'lgmi_comm_destroy': (None, [VP]),
 }

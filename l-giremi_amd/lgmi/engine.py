@@ -50,11 +50,36 @@ def _copy_result(res: _lib.Result, info: dict) -> MIResult:
                     a(res.site_mean_mi, ns, np.float64), a(res.site_n_pairs, ns, np.uint32), info)
 
 
-def make_params(min_common=5, n_shuffles=0, seed=0, het_only=True, emit_counts=False) -> _lib.Params:
+def make_params(min_common=5, n_shuffles=0, seed=0, het_only=True, emit_counts=False, exact_2x2=False,
+                shard=None) -> _lib.Params:
+    """shard = (rank, world): compute only that contiguous, cost-balanced slice of the result rows"""
     if min_common < 0:
         min_common = 0
+    rank, world = (0, 0) if shard is None else (int(shard[0]), int(shard[1]))
     return _lib.Params(int(min_common), int(n_shuffles), int(seed) & (2**64 - 1),
-                       1 if het_only else 0, 1 if emit_counts else 0, (C.c_uint8 * 6)())
+                       1 if het_only else 0, 1 if emit_counts else 0, 1 if exact_2x2 else 0, 0, rank, world)
+
+
+def plan_shard(batch: PackedBatch, het_only=True, shard=(0, 1)) -> dict:
+    """The planner's view of one shard, computed on the host (no GPU): item range, examined pairs, count tiles
+    and the slot-matrix coordinates of every site (include/lgmi.h: lgmi_plan_shard)."""
+    lib = _lib.load()
+    st, sp = batch.as_struct(), _lib.ShardPlan()
+    _lib.check(lib.lgmi_plan_shard(C.byref(st), 1 if het_only else 0, int(shard[0]), int(shard[1]), C.byref(sp)))
+    try:
+        def a(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n and ptr else np.zeros(0, np.uint32)
+        ni, nt, ns = int(sp.n_items_total), int(sp.n_tiles), len(batch.site_pos)
+        return {'n_items_total': ni, 'item_begin': int(sp.item_begin), 'item_end': int(sp.item_end),
+                'n_examined_total': int(sp.n_examined_total), 'n_examined': int(sp.n_examined),
+                'n_tiles_total': int(sp.n_tiles_total), 'n_tiles': nt,
+                'item_site': a(sp.item_site, ni), 'item_seg': a(sp.item_seg, ni),
+                'tile_block': a(sp.tile_block, nt), 'tile_x0': a(sp.tile_x0, nt), 'tile_y0': a(sp.tile_y0, nt),
+                'tile_edge': a(sp.tile_edge, nt),
+                'site_xrow': a(sp.site_xrow, ns), 'site_ycol': a(sp.site_ycol, ns), 'site_prow': a(sp.site_prow, ns),
+                'site_pcol': a(sp.site_pcol, ns), 'site_xnext': a(sp.site_xnext, ns)}
+    finally:
+        lib.lgmi_shard_plan_free(C.byref(sp))
 
 
 def default_synth_spec(n_sites, n_reads, seed=20250808) -> _lib.SynthSpec:
@@ -150,15 +175,19 @@ class Engine:
             pass
 
     # ---- one-shot path (upload + kernels + fetch)
-    def run(self, batch: PackedBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-            emit_counts=False) -> MIResult:
+    def synchronize(self):
         self._alive()
-        st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts)
+        _lib.check(self.lib.lgmi_ctx_synchronize(self.handle))
+
+    def run(self, batch: PackedBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
+            emit_counts=False, exact_2x2=False, shard=None) -> MIResult:
+        self._alive()
+        st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard)
         res, info = _lib.Result(), _lib.RunInfo()
         _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
         try:
             d = info.as_dict()
-            d['has_p'], d['has_counts'] = n_shuffles > 0, bool(emit_counts)
+            d['has_p'], d['has_counts'] = n_shuffles > 0 or bool(exact_2x2), bool(emit_counts)
             return _copy_result(res, d)
         finally:
             self.lib.lgmi_result_free(C.byref(res))
@@ -177,9 +206,9 @@ class Engine:
         return DeviceBatch(self, h)
 
     def run_device(self, dbatch: DeviceBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-                   emit_counts=False) -> DeviceResult:
+                   emit_counts=False, exact_2x2=False, shard=None) -> DeviceResult:
         self._alive()
-        prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts), C.c_void_p()
+        prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard), C.c_void_p()
         _lib.check(self.lib.lgmi_run_device(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
         return DeviceResult(self, h)
 
@@ -236,6 +265,25 @@ class Engine:
         out = (C.c_uint64 * self.world)()
         _lib.check(self.lib.lgmi_comm_allgather_u64(self.handle, int(value), out))
         return [int(v) for v in out]
+
+    def comm_allgather_u64v(self, values):
+        self._alive()
+        n = len(values)
+        mine = (C.c_uint64 * n)(*[int(v) for v in values])
+        out = (C.c_uint64 * (n * self.world))()
+        _lib.check(self.lib.lgmi_comm_allgather_u64v(self.handle, mine, n, out))
+        return [[int(out[r * n + k]) for k in range(n)] for r in range(self.world)]
+
+    def comm_gather(self, dresult: 'DeviceResult', root=0, site_base=0, same_batch=False):
+        """HBM-to-HBM gather over RCCL: -> (DeviceResult on the root / None elsewhere, rank_row_begin list).
+        same_batch=True: the ranks ran shards of one batch (per-site integer sums are added up);
+        otherwise site_base shifts this rank's site indices into the global numbering."""
+        self._alive()
+        opts = _lib.GatherOpts(int(site_base), 1 if same_batch else 0, (C.c_uint8 * 3)())
+        h = C.c_void_p()
+        begins = (C.c_uint64 * (self.world + 1))()
+        _lib.check(self.lib.lgmi_comm_gather(self.handle, dresult.handle, int(root), C.byref(opts), C.byref(h), begins))
+        return (DeviceResult(self, h) if h else None), [int(b) for b in begins]
 
     def comm_gather_rows(self, dresult: 'DeviceResult', root=0):
         """every rank's (row_i, row_j, row_mi[, row_p]) concatenated in rank order on `root`"""

@@ -74,6 +74,57 @@ def test_two_rank_gloo_path():
     assert np.allclose(a['gathered']['mi'], np.repeat(costs[a['shards'][0] + a['shards'][1]], 3))
 
 
+def _shard_worker(rank, world, port, q):
+    """tile-level sharding of ONE block: every rank plans its own shard with the C ABI's host-only planner, "computes"
+    its rows (taken from the oracle's rows of the whole block) and the rows are gathered in rank order"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import lgmi
+        from oracle import c_oracle
+        from test_shard_plan import item_of_rows
+        from util_synth import pack_class_matrix, random_block
+        rng = np.random.Generator(np.random.PCG64(2024))
+        pb = pack_class_matrix([random_block(rng, 300, 900, tri_frac=0.2, het_frac=0.3)])    # same block on every rank
+        ora = c_oracle.run(pb, min_common=5, het_only=True)
+        plan = lgmi.plan_shard(pb, True, (rank, world))
+        items = item_of_rows(pb, plan, ora['row_i'], ora['row_j'])
+        mine = (items >= plan['item_begin']) & (items < plan['item_end'])
+        table = {'row_i': ora['row_i'][mine], 'row_j': ora['row_j'][mine], 'row_mi': ora['row_mi'][mine],
+                 'rank': np.full(int(mine.sum()), rank, np.uint32)}
+        got = gather_tables_host(dist, table, root=0)
+        q.put({'rank': rank, 'n_mine': int(mine.sum()), 'n_examined': plan['n_examined'],
+               'n_examined_total': plan['n_examined_total'],
+               'same': None if got is None else bool(
+                   (got['row_i'] == ora['row_i']).all() and (got['row_j'] == ora['row_j']).all()
+                   and (got['row_mi'] == ora['row_mi']).all() and (np.diff(got['rank'].astype(int)) >= 0).all()),
+               'n_total': len(ora['row_i'])})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_block():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=180) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = outs
+    assert a['same'] is True and b['same'] is None                 # merged rows == the single-rank order
+    assert a['n_mine'] > 0 and b['n_mine'] > 0 and a['n_mine'] + b['n_mine'] == a['n_total']
+    assert a['n_examined'] + b['n_examined'] == a['n_examined_total']
+    assert abs(a['n_examined'] - b['n_examined']) <= 0.1 * a['n_examined_total']
+
+
 def test_shard_by_cost_edge_cases():
     assert shard_by_cost([], 4) == [[], [], [], []]
     assert shard_by_cost([5.0], 2) == [[0], []]
