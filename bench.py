@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — site-pair MI throughput of the MI355X engine on BASELINE.json's metric.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shuffles S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--shuffles S] [--scaling strong|weak]
 
-A "step" is one pass of the hot path (pair counts -> MI -> ordered rows -> per-site
-mean MI [-> permutation p]) over one synthetic chromosome that is already resident
-in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-owns its own chromosome (weak scaling: blocks never share pairs); the
-only collective on the data path is the final RCCL gather of per-rank row counts.
+A "step" is one pass of the hot path (pair counts -> MI -> ordered rows -> per-site mean MI -> permutation p) over
+one synthetic batch that is already resident in HBM, ending with the result rows resident in HBM — on ONE GPU at
+N = 1; at N > 1 on rank 0's GPU after the final gather.
+
+N > 1 (one process per GPU; the driver launches them with torch.distributed.run, which only has to export RANK,
+LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT — no torch is imported here, the 128-byte RCCL id and the barriers
+travel over lgmi.dist.SocketGroup):
+  --scaling strong (default; BASELINE.json north_star: "a 50k-site x 200k-read synthetic chromosome at 1/2/4/8
+      MI355X"): every rank holds the SAME chromosome (input replicated), computes shard rank/N of its
+      site-pair tiles and rows (lgmi_params.shard_*), and the rows of all ranks are gathered HBM-to-HBM over
+      RCCL/xGMI onto rank 0 INSIDE the timed region (lgmi_comm_gather, same_batch: per-site integer sums reduced).
+  --scaling weak: every rank owns its own chromosome (blocks dealt to ranks), same gather with per-rank site bases.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -29,26 +36,36 @@ WORKLOADS = {
     'small_dense_2kx20k': dict(n_sites=2_000, n_reads=20_000),
     # the long-read-like regime of SURVEY 8d: 25 (footprint, strand) blocks, each site sees ~70 reads
     'north_star_banded_50kx200k': dict(n_sites=50_000, n_reads=200_000, regime='banded'),
+    # BASELINE.json configs[2]: whole-genome scale, 22 chromosomes, 200k sites x 1M reads in one batch
+    'cfg3_22x9091x45455': dict(n_sites=9_091, n_reads=45_455, n_blocks=22),
+    # BASELINE.json configs[4]: coverage depth x 4, mi_min_common_read = 6, 10,000 shuffles
+    'cfg5_dense_depthx4_S10000': dict(n_sites=9_091, n_reads=181_820, n_blocks=22, shuffles=10_000),
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # non-packed VALU: one wave64 instruction per 4 cycles per SIMD (MI355X_MICROARCH.md 'vector-instruction ISSUE
 # cost': v_add_f32 4 cyc; the 157.3 TF fp32 peak counts packed 2-wide FMAs).  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz.
 # Measured with tools/ubench_valu.hip: 40.4e12 lane-ops/s for v_and_b32 + v_add_u32 (profiles/r01_ubench_valu.txt).
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # 3.93e13
+VALU_WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4  # 6.1e11 wave64 instructions / s (one per 4 cycles per SIMD)
 WORD_OP_LANE_OPS = 4                  # one 64-bit AND+POPC = 2 v_and_b32 + 2 v_bcnt_u32_b32
 MFMA_I8_PEAK_TOPS = 5000.0            # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (2.5 PF dense) per clock
 MFMA_FP4_PEAK_TOPS = 10000.0          # MI355X_MICROARCH.md: FP4/FP6 MFMA ~10 PF dense
 
 
-def pmc_traffic(workload, mfma=False):
-    """HBM bytes per k_count launch from the committed PMC passes (profiles/r01_pmc_k_count.json): rocprofv3
-    cannot be driven from inside this process, so the counters are collected by the separate --pmc runs
-    described in that file and looked up here by workload name."""
+def committed_profile(name):
+    """figures rocprofv3 cannot give from inside this process (PMC passes are separate runs, see profiles/README.md):
+    the newest committed profiles/rNN_<name>.json"""
+    d = os.path.join(ROOT, 'profiles')
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_k_count.json')) as f:
-            return json.load(f).get(workload + ('_mfma' if mfma else ''), {}).get('hbm_bytes')
+        cands = sorted(f for f in os.listdir(d) if f.endswith('_' + name + '.json'))
+        if cands:
+            with open(os.path.join(d, cands[-1])) as f:
+                out = json.load(f)
+            out['_file'] = 'profiles/' + cands[-1]
+            return out
     except OSError:
-        return None
+        pass
+    return {}
 
 
 def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
@@ -67,8 +84,8 @@ def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
         return {'value': out['n_examined'] / dt, 'unit': 'site-pairs/s', 'cores': cores, 'kind': 'port',
                 'sample': 'the whole banded workload: %d examined pairs, %d emitted, %.1f s wall'
                           % (out['n_examined'], len(out['row_i']), dt)}
-    # ~2.5e9 pair-words keeps 16 host cores busy for ~10-20 s
-    target_pair_words = 2.5e9 * max(1, cores) / 16
+    # ~2.5e9 pair-words keeps 16 host cores busy for ~10-20 s; the permutation stage of the sample scales with S
+    target_pair_words = 2.5e9 * max(1, cores) / 16 / max(1.0, n_shuffles / 1000.0)
     words = (n_reads + 63) // 64
     p = int(max(60, min(wl['n_sites'], (target_pair_words / words / 0.18) ** 0.5)))
     spec = lgmi.default_synth_spec(p, n_reads, seed=seed)
@@ -79,9 +96,9 @@ def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
     out = c_oracle.run(pb, min_common=min_common, het_only=True, n_shuffles=n_shuffles, seed=seed, threads=cores)
     dt = time.perf_counter() - t0
     return {'value': out['n_examined'] / dt, 'unit': 'site-pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': 'same generator and read count (%d reads), first-principles subsample of %d sites: '
-                      '%d examined pairs, %d emitted, %.1f s wall' % (n_reads, p, out['n_examined'],
-                                                                      len(out['row_i']), dt)}
+            'sample': 'same generator and read count (%d reads), first-principles subsample of %d sites of one '
+                      'chromosome: %d examined pairs, %d emitted, %.1f s wall' % (n_reads, p, out['n_examined'],
+                                                                                  len(out['row_i']), dt)}
 
 
 def main():
@@ -90,15 +107,13 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='north_star_dense_50kx200k', choices=sorted(WORKLOADS))
-    ap.add_argument('--shuffles', type=int, default=1000)     # BASELINE.json configs[1]: 1000-shuffle permutation p
+    ap.add_argument('--shuffles', type=int, default=None,
+                    help='default 1000 (BASELINE.json configs[1]: 1000-shuffle permutation p); cfg5: 10000')
     ap.add_argument('--min-common', type=int, default=6)      # l-giremi CLI default (script/giremi.py:212-216)
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                    help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path '
-                         'with several ranks on one GPU: set LGMI_BENCH_DEVICE=0)')
-    ap.add_argument('--lib-comm', action='store_true',
-                    help='final gather through liblgmi\'s own RCCL communicator (lgmi_comm_*) instead of '
-                         'torch.distributed (which is RCCL too); only exercised with one rank so far')
+    ap.add_argument('--no-host-to-host', action='store_true')
+    ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the row gather (kernel-only scaling)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -109,49 +124,45 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
         args.gpus = world
 
-    import torch
     import lgmi
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-    tdev = 'cuda' if args.backend == 'nccl' else 'cpu'
+    from lgmi.dist import group_from_env
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    group = group_from_env()                                   # plain sockets; a no-op object at N = 1
     device = int(os.environ.get('LGMI_BENCH_DEVICE', local_rank))
 
     eng = lgmi.Engine(device)
     wl = WORKLOADS[args.workload]
-    seed = 20250808 + 1000 * rank
+    n_shuffles = args.shuffles if args.shuffles is not None else wl.get('shuffles', 1000)
+    strong = args.scaling == 'strong' or world == 1
+    seed = 20250808 + (0 if strong else 1000 * rank)           # strong: the same chromosome on every rank
+    n_blocks = wl.get('n_blocks', 1)
     if wl.get('regime') == 'banded':
         from lgmi.synth import banded_chromosome
         db = eng.upload(banded_chromosome(wl['n_sites'], wl['n_reads'], seed=seed))
     else:
-        spec = lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed)
-        db = eng.synth_dense(spec)                             # input resident in HBM before timing
-    if world > 1 and args.lib_comm:
-        eng.comm_init_torch(dist, rank, world)
+        db = eng.synth_dense(lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed, n_blocks=n_blocks))
+    if world > 1:
+        eng.comm_init_group(group)                             # RCCL communicator inside liblgmi (csrc/comm.cpp)
+    shard = (rank, world) if (strong and world > 1) else None
+    n_sites_rank = wl['n_sites'] * n_blocks
 
     def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        eng.synchronize()
+        if world > 1:
+            group.barrier()
+            eng.synchronize()
 
     def step():
-        dr = eng.run_device(db, min_common=args.min_common, n_shuffles=args.shuffles, seed=seed, het_only=True)
+        dr = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
         info = dr.info()
-        if world > 1:                                                      # final gather (RCCL over xGMI)
-            if args.lib_comm:
-                info['world_rows'] = eng.comm_allgather_u64(info['n_rows'])
-            else:
-                mine = torch.tensor([info['n_rows']], dtype=torch.int64, device=tdev)
-                allr = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(allr, mine)
-                info['world_rows'] = [int(t.item()) for t in allr]
+        if world > 1 and not args.no_gather:                   # the final gather: rows HBM -> rank 0's HBM over xGMI
+            t0 = time.perf_counter()
+            g, begins = eng.comm_gather(dr, root=0, site_base=0 if strong else rank * n_sites_rank, same_batch=strong)
+            info['ms_gather'] = 1e3 * (time.perf_counter() - t0)
+            info['world_rows'] = [begins[k + 1] - begins[k] for k in range(world)]
+            if g is not None:
+                info['gathered_rows'] = g.info()['n_rows']
+                g.free()
         dr.free()
         return info
 
@@ -161,17 +172,17 @@ def main():
     t0 = time.perf_counter()
     infos = [step() for _ in range(args.steps)]
     sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.allreduce_max(time.perf_counter() - t0)
+    per_rank = group.gather({k: sum(i[k] for i in infos) / len(infos) for k in
+                             ('ms_total', 'ms_count', 'ms_emit', 'ms_perm', 'n_examined', 'n_rows', 'n_tile_pairs')})
 
     info = infos[-1]
-    examined = info['n_examined']
     ms_count = sum(i['ms_count'] for i in infos) / len(infos)
     out = None
     if rank == 0:
+        examined_job = info['n_examined_total'] if strong else sum(int(p['n_examined']) for p in per_rank)
+        rows_job = sum(info.get('world_rows', [info['n_rows']]))
+        general_job = info['n_general_rows']                    # this rank's; scaled below for the job-wide rate
         # dominant kernel: k_count.  Algorithmic HBM bytes per launch:
         # every column's planes once (16 B per 64-read word) + site metadata + the 4 count planes
         # of every computed slot (16 B).
@@ -180,32 +191,60 @@ def main():
         word_ops = 4 * info['word_pairs']                      # 4 mandatory AND+POPC per pair-word
         secs = ms_count * 1e-3
         out = {
-            'metric': 'MI site-pairs/sec (incl. permutation p)' if args.shuffles else 'MI site-pairs/sec',
-            'value': examined * world * args.steps / elapsed,
+            'metric': 'MI site-pairs/sec (incl. permutation p)' if n_shuffles else 'MI site-pairs/sec',
+            'value': examined_job * args.steps / elapsed,
             'unit': 'site-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': {2: 'u64 bit planes -> fp4 (e2m1) MFMA operands, f32 counts (exact < 2^24), f64 MI',
                       1: 'u64 bit planes -> int8 MFMA operands, i32 counts, f64 MI'}.get(
                           info.get('mfma_dtype', 0), 'u64 bit planes (AND + popcount), u32 counts, f64 MI'),
             'data': 'synthetic',
             'config': {'workload': args.workload, 'n_sites': wl['n_sites'], 'n_reads': wl['n_reads'],
-                       'regime': wl.get('regime', 'dense'), 'het_every': 5, 'min_common': args.min_common,
-                       'n_shuffles': args.shuffles, 'examined_pairs_per_gpu': examined,
-                       'emitted_pairs_per_gpu': info['n_rows'], 'parallelism': 'dp%d' % world},
-            'stage_ms': {k: sum(i[k] for i in infos) / len(infos)
-                         for k in ('ms_total', 'ms_prep', 'ms_count', 'ms_emit', 'ms_perm', 'ms_mean')},
+                       'n_blocks': n_blocks, 'regime': wl.get('regime', 'dense'), 'het_every': 5,
+                       'min_common': args.min_common, 'n_shuffles': n_shuffles,
+                       'examined_pairs_job': examined_job, 'emitted_pairs_job': rows_job,
+                       'parallelism': ('1 gpu' if world == 1 else
+                                       ('tile shards of one batch x%d, RCCL row gather to rank 0' % world if strong else
+                                        'one chromosome per rank x%d, RCCL row gather to rank 0' % world)),
+                       'timed_region': 'resident batch -> result rows resident in HBM'
+                                       + (' of rank 0 (gather included)' if world > 1 and not args.no_gather else '')},
+            'stage_ms': {k: sum(i.get(k, 0.0) for i in infos) / len(infos)
+                         for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
+                                   'ms_perm_general', 'ms_mean', 'ms_gather')},
         }
-        # emitted pairs/s and pair-shuffles/s beside the examined-pair rate (whole job)
-        rows_all = sum(info.get('world_rows', [info['n_rows']]))
-        out['rates'] = {'emitted_pairs_per_s': rows_all * args.steps / elapsed,
-                        'pair_shuffles_per_s': rows_all * args.shuffles * args.steps / elapsed}
+        if world > 1:
+            out['per_rank'] = per_rank
+        out['rates'] = {'emitted_pairs_per_s': rows_job * args.steps / elapsed}
+        if n_shuffles:
+            # the permutation stage, priced on what it really draws: a 2 x 2 row costs ONE binomial
+            # variate against its exact tail mass; only the larger tables draw n_shuffles tables each.  VALU issue
+            # and lane occupancy come from the committed SQ counter pass of this workload.
+            sq = committed_profile('pmc_sq_perm').get(args.workload, {})
+            ms_gen = sum(i['ms_perm_general'] for i in infos) / len(infos)
+            ms_fast = sum(i['ms_perm_fast'] for i in infos) / len(infos)
+            draws = general_job * n_shuffles
+            pr = {'general_rows': general_job, 'two_by_two_rows': info['n_rows'] - general_job,
+                  'table_draws': draws, 'ms_general': ms_gen, 'ms_fast': ms_fast,
+                  'table_draws_per_s': draws / (ms_gen * 1e-3) if ms_gen > 0 else None,
+                  'two_by_two_rows_per_s': (info['n_rows'] - general_job) / (ms_fast * 1e-3) if ms_fast > 0 else None,
+                  'bound': 'valu_issue', 'unit': 'wave64 VALU instructions/s',
+                  'peak': VALU_WAVE_INSTR_PEAK, 'counters': sq.get('_file') or committed_profile('pmc_sq_perm').get('_file')}
+            for k in ('k_perm_general', 'k_perm_fast'):
+                c = sq.get(k)
+                if c and c.get('valu_insts') and c.get('ms'):
+                    pr[k] = {'valu_issue_frac': c['valu_insts'] / (c['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
+                             'active_lane_frac': c.get('active_lanes', 0) / 64.0,
+                             'valu_insts_per_table_draw' if k == 'k_perm_general' else 'valu_insts_per_row':
+                                 c['valu_insts'] * 64.0 / (c.get('units') or 1)}
+            out['perm_roofline'] = pr
+        traffic = committed_profile('pmc_k_count').get(args.workload + ('_mfma' if mfma else ''), {}).get('hbm_bytes')
         hbm = {'kernel': 'count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes, 'achieved': alg_bytes / secs / 1e9,
                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
-               'traffic': pmc_traffic(args.workload, mfma),
+               'traffic': traffic,
                'note': 'bytes per launch; the count kernel is compute-bound, not HBM-bound.  traffic = L2-miss bytes '
-                       '(FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_k_count.json)'}
+                       '(FETCH_SIZE x2 + WRITE_SIZE, newest profiles/rNN_pmc_k_count.json)'}
         valu = {'kernel': 'k_count', 'bound': 'valu_popcount', 'achieved': word_ops / secs / 1e12,
                 'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12, 'unit': 'T word-ops/s (64-bit AND+POPC)',
                 'frac': word_ops / secs / (VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS)}
@@ -217,9 +256,10 @@ def main():
             out['roofline'] = {'kernel': 'k_count_mfma_fp4' if fp4 else 'k_count_mfma', 'bound': 'mfma',
                                'achieved': ops / secs / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                                'op_kind': ('fp4 (e2m1)' if fp4 else 'int8') + ' multiply-add ops (tera-ops/s), dense MFMA peak',
-                               'frac': ops / secs / 1e12 / peak, 'traffic': hbm['traffic'],
-                               'algorithmic_ops': ops,
-                               'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2); '
+                               'frac': ops / secs / 1e12 / peak, 'traffic': traffic,
+                               'algorithmic_ops': ops, 'ms_kernel': ms_count,
+                               'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2) of this '
+                                       'rank\'s shard; '
                                        + ('v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands and unit scales, exact in f32 below 2^24 reads; '
                                           if fp4 else 'v_mfma_i32_32x32x32_i8; ')
                                        + 'weighted-bit operands made from the bit planes in registers (AND / shift-AND per operand dword)'}
@@ -227,14 +267,27 @@ def main():
         else:
             out['roofline'] = hbm
             out['valu_roofline'] = valu
+        if world == 1 and not args.no_host_to_host:
+            # SURVEY §8d's other wall time: packed batch in HOST memory -> result rows in HOST memory (upload + layout
+            # prep + kernels + fetch), through lgmi_run.  Never `value`.
+            pb = db.download()
+            t1 = time.perf_counter()
+            hi = eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+            dt = time.perf_counter() - t1
+            out['host_to_host'] = {'ms': 1e3 * dt, 'site_pairs_per_s': hi['n_examined'] / dt,
+                                   'h2d_bytes': int(pb.planes.nbytes + 25 * len(pb.site_pos)),
+                                   'd2h_bytes': int(hi['bytes_out'] + 12 * len(pb.site_pos)),
+                                   'kernels_ms': hi['ms_total'],
+                                   'note': 'one lgmi_run call from pageable host memory: validation + H2D + layout prep '
+                                           '+ kernels + D2H of (i, j, mi, p, exceed) per row'}
+            del pb
         if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
-            out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, args.shuffles, seed)
+            out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)
     db.free()
-    if dist is not None:
-        dist.barrier()
+    if world > 1:
+        group.barrier()
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
     if out is not None:
         print(json.dumps(out))
 

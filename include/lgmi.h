@@ -182,6 +182,9 @@ typedef struct lgmi_synth_spec {
     uint32_t tri_per_1024;   /* sites with a third allele, per 1024   (20)         */
     uint32_t tri_frac_u16;   /* P(third allele | covered) * 65536     (3277)       */
     uint32_t snp_per_1024;   /* non-het sites typed 'snp', per 1024   (10)         */
+    uint32_t n_blocks;       /* 0 or 1: one chromosome; k > 1: k chromosomes (blocks) of n_sites x n_reads each in one
+                                batch, block c drawn with seed + c (BASELINE.json configs[2]: 22 chromosomes)          */
+    uint32_t reserved;       /* must be 0 */
 } lgmi_synth_spec;
 
 typedef struct lgmi_ctx     lgmi_ctx;     /* one device, one stream, workspace */
@@ -262,6 +265,12 @@ typedef struct lgmi_shard_plan {
 int  lgmi_plan_shard(const lgmi_batch* batch, int het_only, uint32_t shard_rank, uint32_t shard_world,
                      lgmi_shard_plan* out);
 void lgmi_shard_plan_free(lgmi_shard_plan* plan);
+
+/* device self-test of the one place where the permutation kernels use the hardware's f32 exp (perm.hip: le_exp):
+ * for every k: fast[k] = le_exp(x2[k], t[k]), det[k] = (x2[k] <= det_exp(t[k])), e_hw[k] = (double)__expf((float)t[k]),
+ * e_det[k] = det_exp(t[k]).  Host arrays of length n. */
+int  lgmi_selftest_le_exp(lgmi_ctx* ctx, uint64_t n, const double* x2, const double* t, uint8_t* fast, uint8_t* det,
+                          double* e_hw, double* e_det);
 
 /* wait for everything queued on the context's stream (the bench's device sync) */
 int  lgmi_ctx_synchronize(lgmi_ctx* ctx);

@@ -362,23 +362,32 @@ extern "C" int lgmi_synth_dense(lgmi_ctx* ctx, const lgmi_synth_spec* sp, lgmi_d
     if (sp->n_sites == 0 || sp->n_reads == 0) return fail(LGMI_E_ARG, "n_sites and n_reads must be > 0");
     if (sp->dropout_u16 > 65536 || sp->het_noise_u16 > 65536 || sp->tri_frac_u16 > 65536)
         return fail(LGMI_E_ARG, "u16 probabilities must be <= 65536");
+    if (sp->reserved) return fail(LGMI_E_ARG, "reserved must be 0");
+    const uint32_t nb = sp->n_blocks ? sp->n_blocks : 1u;
+    if ((uint64_t)nb * sp->n_sites >= 0x7FFFFFF0ull) return fail(LGMI_E_ARG, "too many sites");
     HIPCHK(hipSetDevice(ctx->device));
     lgmi_dbatch* db = new lgmi_dbatch();
     db->ctx = ctx;
     struct Guard { lgmi_dbatch* p; ~Guard() { if (p) { free_dbatch_device(p); delete p; } } } guard{db};
-    const uint32_t ns = sp->n_sites, W = (sp->n_reads + 63) / 64;
-    db->d.n_blocks = 1;
+    const uint32_t P = sp->n_sites, ns = nb * P, W = (sp->n_reads + 63) / 64;
+    db->d.n_blocks = nb;
     db->d.n_sites = ns;
-    db->block_site_begin = {0, ns};
-    db->block_n_reads = {sp->n_reads};
+    db->block_site_begin.resize(nb + 1);
+    for (uint32_t c = 0; c <= nb; ++c) db->block_site_begin[c] = (uint64_t)c * P;
+    db->block_n_reads.assign(nb, sp->n_reads);
     db->max_reads = sp->n_reads;
     db->pos.resize(ns); db->type.resize(ns); db->tri.resize(ns);
     db->pseudo_of_site.assign(ns, NONE);
-    for (uint32_t s = 0; s < ns; ++s) {
-        SynthSite ss = synth_site(*sp, s);
-        db->pos[s] = 10000 + 37ll * s;
-        db->type[s] = ss.het ? LGMI_TYPE_HET_SNP : (ss.snp ? LGMI_TYPE_SNP : LGMI_TYPE_MISMATCH);
-        db->tri[s] = ss.tri ? 1 : 0;
+    for (uint32_t c = 0; c < nb; ++c) {
+        lgmi_synth_spec bs = *sp;
+        bs.seed = sp->seed + c;                     // block c of a multi-chromosome batch == a one-block batch with seed + c
+        for (uint32_t s = 0; s < P; ++s) {
+            const SynthSite ss = synth_site(bs, s);
+            const uint32_t g = c * P + s;
+            db->pos[g] = 10000 + 37ll * s;
+            db->type[g] = ss.het ? LGMI_TYPE_HET_SNP : (ss.snp ? LGMI_TYPE_SNP : LGMI_TYPE_MISMATCH);
+            db->tri[g] = ss.tri ? 1 : 0;
+        }
     }
     db->cols.resize(ns);
     for (uint32_t s = 0; s < ns; ++s) db->cols[s] = Col{(uint64_t)s * W, 0u, W};
@@ -405,8 +414,12 @@ extern "C" int lgmi_synth_dense(lgmi_ctx* ctx, const lgmi_synth_spec* sp, lgmi_d
     HIPCHK(hipMalloc((void**)&d_depth, (size_t)ns * 3 * sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(d_depth, 0, (size_t)ns * 3 * sizeof(uint32_t), st));
     if ((rc = dev_copy_new(&d_pos_, db->pseudo_of_site.data(), ns, st))) return rc;
-    launch_synth_depth(st, *sp, W, d_depth);
-    launch_synth_write(st, *sp, W, d_depth, d_pos_, db->d.d_cplanes);
+    for (uint32_t c = 0; c < nb; ++c) {
+        lgmi_synth_spec bs = *sp;
+        bs.seed = sp->seed + c;
+        launch_synth_depth(st, bs, W, d_depth + (size_t)3 * c * P);
+        launch_synth_write(st, bs, W, d_depth + (size_t)3 * c * P, d_pos_ + (size_t)c * P, db->d.d_cplanes, c * P);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     guard.p = nullptr;
@@ -894,6 +907,34 @@ extern "C" int lgmi_site_mean(lgmi_ctx* ctx, uint64_t n_rows, const uint32_t* ro
     if (n_sites) {
         HIPCHK(hipMemcpyAsync(mean_out, dmean, n_sites * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(n_out, dc, n_sites * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return LGMI_OK;
+}
+
+// ---------------------------------------------------------------- device self-test of le_exp (perm.hip)
+extern "C" int lgmi_selftest_le_exp(lgmi_ctx* ctx, uint64_t n, const double* x2, const double* t, uint8_t* fast,
+                                    uint8_t* det, double* e_hw, double* e_det) {
+    if (!ctx || (n && (!x2 || !t || !fast || !det || !e_hw || !e_det))) return fail(LGMI_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    Pool& pool = ctx->pool;
+    std::vector<void*> scratch;
+    struct Guard { Pool& p; std::vector<void*>& s; ~Guard() { for (void* q : s) p.release(q); } } guard{pool, scratch};
+    auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
+    double *dx, *dt, *dh, *dd; uint8_t *df, *ddet;
+    int rc;
+    if ((rc = salloc((void**)&dx, n * 8)) || (rc = salloc((void**)&dt, n * 8)) || (rc = salloc((void**)&dh, n * 8)) ||
+        (rc = salloc((void**)&dd, n * 8)) || (rc = salloc((void**)&df, n)) || (rc = salloc((void**)&ddet, n))) return rc;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(dx, x2, n * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dt, t, n * 8, hipMemcpyHostToDevice, st));
+        launch_selftest_le_exp(st, n, dx, dt, df, ddet, dh, dd);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(fast, df, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(det, ddet, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(e_hw, dh, n * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(e_det, dd, n * 8, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
     return LGMI_OK;

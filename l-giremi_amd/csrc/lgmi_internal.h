@@ -141,6 +141,8 @@ struct PermArgs {
 };
 void launch_perm_fast(hipStream_t st, const PermArgs& a);
 void launch_perm_general(hipStream_t st, const PermArgs& a);
+void launch_selftest_le_exp(hipStream_t st, uint64_t n, const double* x2, const double* t, uint8_t* fast, uint8_t* det,
+                            double* e_hw, double* e_det);
 
 // ecdf.hip
 size_t ecdf_sort_temp_bytes(uint32_t n);
@@ -156,6 +158,6 @@ void launch_prep_cols(hipStream_t st, uint32_t n_cols, uint32_t n_sites, const C
                       const uint64_t* planes, ulonglong2* cplanes);
 void launch_synth_depth(hipStream_t st, const lgmi_synth_spec& sp, uint32_t W, uint32_t* depth3);
 void launch_synth_write(hipStream_t st, const lgmi_synth_spec& sp, uint32_t W, const uint32_t* depth3,
-                        const uint32_t* pseudo_of_site, ulonglong2* cplanes);
+                        const uint32_t* pseudo_of_site, ulonglong2* cplanes, uint32_t site_base);
 
 }  // namespace lgmi

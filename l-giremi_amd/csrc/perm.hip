@@ -22,8 +22,10 @@
 //                   scheme for small samples, Stadlober's HRUA otherwise).
 //
 // Every outcome-deciding operation is integer arithmetic or IEEE +,-,*,/ on doubles
-// (-ffp-contract=off) over host-built tables, so results do not depend on the device's
-// libm; exp/log/sqrt are the explicit routines below.
+// (-ffp-contract=off) over host-built tables; exp/log/sqrt are the explicit routines below.
+// One shortcut: le_exp() lets the hardware's f32 exp decide the HRUA acceptances that are not
+// within 1e-4 of the boundary (same decisions as det_exp as long as the hardware value is
+// within 1e-4 of it — measured 2e-7, pinned by a device-side sweep in the GPU tests).
 #include "lgmi_internal.h"
 #include "philox.h"
 
@@ -94,9 +96,11 @@ __device__ __forceinline__ double det_exp(double x) {
 }
 
 // x2 <= exp(t) with the decision of det_exp(t) at a fraction of its cost: the hardware's single-precision exp is
-// within 1e-5 of det_exp (1 ulp of f32 plus the rounding of t, |t| < 88 where it does not underflow), so it
+// within 1e-5 of det_exp (1 ulp of f32 plus the rounding of t, |t| < 87 where it is a normal number), so it
 // decides every case that is not within 1e-4 of the boundary; only those go through det_exp.  When the f32 value
-// underflows, exp(t) < 1.2e-38 is below any x2 the callers pass (x2 >= 2^-66).
+// underflows, exp(t) < 1.2e-38 is below any x2 the callers pass (x2 >= 2^-66).  The bound is not taken on trust:
+// tests/test_gpu_parity.py::test_hardware_exp_stays_inside_the_guard sweeps t on the device (lgmi_selftest_le_exp)
+// and checks |__expf / det_exp - 1| < 2.5e-5 and that le_exp never disagrees with det_exp on adversarial x2.
 __device__ __forceinline__ bool le_exp(double x2, double t) {
     const double e = (double)__expf((float)t);
     if (x2 <= e * 0.9999) return true;
@@ -952,6 +956,26 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
             out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
         }
     }
+}
+
+// self-test hook (lgmi_selftest_le_exp): the decision of le_exp, the decision of det_exp alone, and both exponentials
+__global__ void k_selftest_le_exp(uint64_t n, const double* __restrict__ x2, const double* __restrict__ t,
+                                  uint8_t* __restrict__ fast, uint8_t* __restrict__ det, double* __restrict__ e_hw,
+                                  double* __restrict__ e_det)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    fast[k] = le_exp(x2[k], t[k]) ? 1 : 0;
+    const double d = det_exp(t[k]);
+    det[k] = x2[k] <= d ? 1 : 0;
+    e_hw[k] = (double)__expf((float)t[k]);
+    e_det[k] = d;
+}
+void launch_selftest_le_exp(hipStream_t st, uint64_t n, const double* x2, const double* t, uint8_t* fast, uint8_t* det,
+                            double* e_hw, double* e_det)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_selftest_le_exp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, x2, t, fast, det, e_hw, e_det);
 }
 
 void launch_perm_fast(hipStream_t st, const PermArgs& a)

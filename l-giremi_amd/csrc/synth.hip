@@ -130,7 +130,7 @@ __host__ __device__ inline void synth_rank(bool tri, const uint32_t d[3], uint32
 
 __global__ __launch_bounds__(256) void k_synth_write(lgmi_synth_spec sp, uint32_t W, const uint32_t* __restrict__ depth3,
                                                      const uint32_t* __restrict__ pseudo_of_site,
-                                                     ulonglong2* __restrict__ cplanes)
+                                                     ulonglong2* __restrict__ cplanes, uint32_t site_base)
 {
     const uint32_t chunks = (W + 255u) / 256u;
     const uint32_t s = blockIdx.x / chunks;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_synth_write(lgmi_synth_spec sp, uint32_
     ulonglong2 v;
     v.x = cov;
     v.y = major == 0u ? a0 : (major == 1u ? a1 : a2);
-    cplanes[(uint64_t)s * W + w] = v;
+    cplanes[(uint64_t)(site_base + s) * W + w] = v;     // depth3 / pseudo_of_site point at the block's first site
     const uint32_t pc = pseudo_of_site[s];
     if (pc != NONE) {
         v.y = minor == 0u ? a0 : (minor == 1u ? a1 : a2);
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256) void k_synth_write(lgmi_synth_spec sp, uint32_
 }
 
 void launch_synth_write(hipStream_t st, const lgmi_synth_spec& sp, uint32_t W, const uint32_t* depth3,
-                        const uint32_t* pseudo_of_site, ulonglong2* cplanes) {
+                        const uint32_t* pseudo_of_site, ulonglong2* cplanes, uint32_t site_base) {
     hipLaunchKernelGGL(k_synth_write, dim3(((W + 255) / 256) * sp.n_sites), dim3(256), 0, st, sp, W, depth3,
-                       pseudo_of_site, cplanes);
+                       pseudo_of_site, cplanes, site_base);
 }
 
 }  // namespace lgmi

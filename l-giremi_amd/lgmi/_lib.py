@@ -72,7 +72,8 @@ class GatherOpts(C.Structure):
 class SynthSpec(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('n_sites', C.c_uint32), ('n_reads', C.c_uint32),
                 ('het_every', C.c_uint32), ('dropout_u16', C.c_uint32), ('het_noise_u16', C.c_uint32),
-                ('tri_per_1024', C.c_uint32), ('tri_frac_u16', C.c_uint32), ('snp_per_1024', C.c_uint32)]
+                ('tri_per_1024', C.c_uint32), ('tri_frac_u16', C.c_uint32), ('snp_per_1024', C.c_uint32),
+                ('n_blocks', C.c_uint32), ('reserved', C.c_uint32)]
 
 
 class LgmiError(RuntimeError):
@@ -105,6 +106,7 @@ SYMBOLS = {
     'lgmi_plan_shard': (C.c_int, [C.POINTER(Batch), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(ShardPlan)]),
     'lgmi_shard_plan_free': (None, [C.POINTER(ShardPlan)]),
     'lgmi_ctx_synchronize': (C.c_int, [VP]),
+    'lgmi_selftest_le_exp': (C.c_int, [VP, C.c_uint64, f64p, f64p, u8p, u8p, f64p, f64p]),
     'lgmi_comm_unique_id': (C.c_int, [VP]),
     'lgmi_comm_init': (C.c_int, [VP, VP, C.c_int, C.c_int]),
     'lgmi_comm_allgather_u64': (C.c_int, [VP, C.c_uint64, u64p]),

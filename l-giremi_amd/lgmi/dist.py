@@ -58,3 +58,174 @@ def gather_tables_host(dist, table: dict, root: int = 0):
         return None
     keys = list(table.keys())
     return {k: np.concatenate([np.asarray(t[k]) for t in box]) for k in keys}
+
+
+class SocketGroup:
+    """The few host-side exchanges a multi-GPU run needs — the 128-byte RCCL id, a barrier, a max over ranks, small
+    object gathers — over plain TCP sockets, so that neither the library nor the bench needs torch.distributed.
+    Rank 0 listens; every collective is "everyone sends to rank 0, rank 0 answers everyone": fine for a node's 8
+    ranks.  Where rank 0 listens:
+      port > 0        on (addr, port) — the launcher guarantees the port is free (mpirun-style launch, tests);
+      port == 0       on an ephemeral port that it publishes in `rdzv_file` (one node, shared /tmp): what
+                      group_from_env() picks under torch.distributed.run, whose agent already owns MASTER_PORT."""
+
+    def __init__(self, rank: int, world: int, addr: str = '127.0.0.1', port: int = 29500, timeout: float = 300.0,
+                 rdzv_file: Optional[str] = None):
+        import os
+        import socket
+        import time
+        self.rank, self.world = int(rank), int(world)
+        self.peers = {}
+        self.sock = None
+        self.rdzv_file = None
+        if world == 1:
+            return
+        if port == 0 and not rdzv_file:
+            raise ValueError('an ephemeral port needs a rendezvous file')
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            token = os.urandom(8).hex()
+            if port == 0:
+                tmp = '%s.%d.tmp' % (rdzv_file, os.getpid())
+                with open(tmp, 'w') as f:
+                    f.write('%d %s\n' % (srv.getsockname()[1], token))
+                os.replace(tmp, rdzv_file)                       # atomic: readers see nothing or the whole line
+                self.rdzv_file = rdzv_file
+            try:
+                while len(self.peers) < world - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    hello = self._recv_exact(conn, 20)
+                    r = int.from_bytes(hello[:4], 'little')
+                    if port == 0 and hello[4:].decode('ascii', 'replace') != token:
+                        conn.close()                             # somebody else's (stale) rendezvous
+                        continue
+                    conn.sendall(b'ok')
+                    self.peers[r] = conn
+            finally:
+                srv.close()
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    to_port, token = port, '0' * 16
+                    if port == 0:
+                        with open(rdzv_file) as f:
+                            a, token = f.read().split()
+                        to_port = int(a)
+                    s = socket.create_connection((addr, to_port), timeout=5.0)
+                    s.settimeout(timeout)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.sendall(self.rank.to_bytes(4, 'little') + token.encode('ascii'))
+                    if self._recv_exact(s, 2) == b'ok':
+                        break
+                    s.close()
+                except (OSError, ValueError, ConnectionError):
+                    pass
+                if time.time() > deadline:
+                    raise TimeoutError('rank %d could not reach the rendezvous of rank 0' % self.rank)
+                time.sleep(0.1)
+            self.sock = s
+
+    @staticmethod
+    def _recv_exact(conn, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = conn.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError('peer closed the rendezvous socket')
+            buf += chunk
+        return bytes(buf)
+
+    def _send_msg(self, conn, payload: bytes):
+        conn.sendall(len(payload).to_bytes(8, 'little') + payload)
+
+    def _recv_msg(self, conn) -> bytes:
+        return self._recv_exact(conn, int.from_bytes(self._recv_exact(conn, 8), 'little'))
+
+    def gather(self, obj, root: int = 0):
+        """-> list of every rank's object on rank 0 (root must be 0), None elsewhere"""
+        import pickle
+        assert root == 0
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj] + [None] * (self.world - 1)
+            for r, conn in self.peers.items():
+                out[r] = pickle.loads(self._recv_msg(conn))
+            return out
+        self._send_msg(self.sock, pickle.dumps(obj))
+        return None
+
+    def broadcast(self, obj, src: int = 0):
+        import pickle
+        assert src == 0
+        if self.world == 1:
+            return obj
+        if self.rank == 0:
+            data = pickle.dumps(obj)
+            for conn in self.peers.values():
+                self._send_msg(conn, data)
+            return obj
+        return pickle.loads(self._recv_msg(self.sock))
+
+    def allgather(self, obj):
+        return self.broadcast(self.gather(obj))
+
+    def barrier(self):
+        self.allgather(None)
+
+    def allreduce_max(self, value: float) -> float:
+        return max(self.allgather(float(value)))
+
+    def broadcast_object_list(self, box, src: int = 0):      # the one torch.distributed call exchange_unique_id() uses
+        box[0] = self.broadcast(box[0], src)
+
+    def get_world_size(self):
+        return self.world
+
+    def get_rank(self):
+        return self.rank
+
+    def gather_object(self, obj, box, dst: int = 0):         # what gather_tables_host() uses
+        got = self.gather(obj, dst)
+        if got is not None:
+            box[:] = got
+
+    def close(self):
+        import os
+        for conn in self.peers.values():
+            conn.close()
+        if self.sock is not None:
+            self.sock.close()
+        if self.rdzv_file:
+            try:
+                os.remove(self.rdzv_file)
+            except OSError:
+                pass
+        self.peers, self.sock, self.rdzv_file = {}, None, None
+
+
+def group_from_env(timeout: float = 300.0) -> SocketGroup:
+    """SocketGroup from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT).
+    LGMI_RDZV_PORT=<port>: rank 0 listens there (any launcher, several nodes).  Under torch.distributed.run
+    (TORCHELASTIC_USE_AGENT_STORE=True: the agent itself listens on MASTER_PORT) rank 0 takes an ephemeral port
+    and publishes it in a file under the temp directory keyed by MASTER_PORT, the run id and the agent's pid
+    (the ranks of one node share all three).  Otherwise MASTER_PORT is free and rank 0 listens on it."""
+    import os
+    import tempfile
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    if os.environ.get('LGMI_RDZV_PORT'):
+        return SocketGroup(rank, world, addr, int(os.environ['LGMI_RDZV_PORT']), timeout)
+    if os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True':
+        key = 'lgmi_rdzv_%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
+                                     os.getppid())
+        return SocketGroup(rank, world, '127.0.0.1' if addr in ('localhost', '') else addr, 0, timeout,
+                           rdzv_file=os.path.join(tempfile.gettempdir(), key))
+    return SocketGroup(rank, world, addr, int(os.environ.get('MASTER_PORT', '29500')), timeout)

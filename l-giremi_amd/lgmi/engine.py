@@ -82,10 +82,11 @@ def plan_shard(batch: PackedBatch, het_only=True, shard=(0, 1)) -> dict:
         lib.lgmi_shard_plan_free(C.byref(sp))
 
 
-def default_synth_spec(n_sites, n_reads, seed=20250808) -> _lib.SynthSpec:
+def default_synth_spec(n_sites, n_reads, seed=20250808, n_blocks=1) -> _lib.SynthSpec:
     """SURVEY §8d dense regime: 10 % dropout, het SNP every 5th site with 2 % noise,
-    2 % tri-allelic sites with a 5 % third allele, 1 % of the other sites typed snp"""
-    return _lib.SynthSpec(int(seed), int(n_sites), int(n_reads), 5, 6554, 1311, 20, 3277, 10)
+    2 % tri-allelic sites with a 5 % third allele, 1 % of the other sites typed snp;
+    n_blocks chromosomes of n_sites x n_reads each (block c is the one-block batch of seed + c)"""
+    return _lib.SynthSpec(int(seed), int(n_sites), int(n_reads), 5, 6554, 1311, 20, 3277, 10, int(n_blocks), 0)
 
 
 class DeviceBatch:
@@ -192,6 +193,18 @@ class Engine:
         finally:
             self.lib.lgmi_result_free(C.byref(res))
 
+    def run_raw(self, batch: PackedBatch, **kw) -> dict:
+        """lgmi_run (upload + kernels + fetch into library-owned host memory) without copying the rows into
+        numpy: what the bench times as host-to-host.  -> run info"""
+        self._alive()
+        st, prm = batch.as_struct(), make_params(**kw)
+        res, info = _lib.Result(), _lib.RunInfo()
+        _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
+        d = info.as_dict()
+        d['host_rows'] = int(res.n_rows)
+        self.lib.lgmi_result_free(C.byref(res))
+        return d
+
     # ---- resident path (bench, multi-GPU)
     def upload(self, batch: PackedBatch) -> DeviceBatch:
         self._alive()
@@ -205,12 +218,29 @@ class Engine:
         _lib.check(self.lib.lgmi_synth_dense(self.handle, C.byref(spec), C.byref(h)))
         return DeviceBatch(self, h)
 
+    def synth_chromosomes(self, n_blocks, n_sites, n_reads, seed=20250808) -> DeviceBatch:
+        """n_blocks dense chromosomes of n_sites x n_reads in one resident batch (BASELINE.json configs[2])"""
+        return self.synth_dense(default_synth_spec(n_sites, n_reads, seed=seed, n_blocks=n_blocks))
+
     def run_device(self, dbatch: DeviceBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
                    emit_counts=False, exact_2x2=False, shard=None) -> DeviceResult:
         self._alive()
         prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard), C.c_void_p()
         _lib.check(self.lib.lgmi_run_device(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
         return DeviceResult(self, h)
+
+    def selftest_le_exp(self, x2, t):
+        """-> (le_exp decisions, det_exp decisions, hardware f32 exp, det_exp) for the pairs (x2[k], t[k])"""
+        self._alive()
+        x2 = np.ascontiguousarray(x2, np.float64)
+        t = np.ascontiguousarray(t, np.float64)
+        n = len(t)
+        fast, det = np.empty(n, np.uint8), np.empty(n, np.uint8)
+        e_hw, e_det = np.empty(n, np.float64), np.empty(n, np.float64)
+        _lib.check(self.lib.lgmi_selftest_le_exp(self.handle, n, x2.ctypes.data_as(_lib.f64p), t.ctypes.data_as(_lib.f64p),
+                                                 fast.ctypes.data_as(_lib.u8p), det.ctypes.data_as(_lib.u8p),
+                                                 e_hw.ctypes.data_as(_lib.f64p), e_det.ctypes.data_as(_lib.f64p)))
+        return fast.astype(bool), det.astype(bool), e_hw, e_det
 
     def site_mean(self, row_i, row_j, row_mi, n_sites):
         self._alive()
@@ -254,6 +284,11 @@ class Engine:
         buf = C.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)
         _lib.check(self.lib.lgmi_comm_init(self.handle, buf, int(rank), int(world)))
         self.rank, self.world = int(rank), int(world)
+
+    def comm_init_group(self, group):
+        """rank 0 creates the RCCL unique id; `group` (lgmi.dist.SocketGroup, or a torch.distributed-like module)
+        carries the 128 bytes"""
+        self.comm_init_torch(group, group.get_rank(), group.get_world_size())
 
     def comm_init_torch(self, dist, rank: int, world: int):
         """rank 0 creates the RCCL unique id; torch.distributed carries the 128 bytes"""

@@ -68,6 +68,21 @@ class PackedBatch:
                    np.zeros(ns, bool))
 
 
+def concat_batches(parts: Sequence['PackedBatch']) -> 'PackedBatch':
+    """several packed batches as one (blocks keep their order; site and plane offsets are shifted)"""
+    bsb, poff, site0, plane0 = [np.zeros(1, np.uint64)], [], 0, 0
+    for p in parts:
+        bsb.append(p.block_site_begin[1:].astype(np.uint64) + np.uint64(site0))
+        poff.append(p.site_plane_off.astype(np.uint64) + np.uint64(plane0))
+        site0 += p.n_sites
+        plane0 += p.planes.size
+    cat = lambda f, dt: np.concatenate([getattr(p, f) for p in parts]).astype(dt)
+    return PackedBatch(np.concatenate(bsb), cat('block_n_reads', np.uint32), cat('site_pos', np.int64),
+                       cat('site_type', np.uint8), cat('site_word_off', np.uint32), cat('site_n_words', np.uint32),
+                       np.concatenate(poff), cat('planes', np.uint64), sum((list(p.type_names) for p in parts), []),
+                       np.concatenate([p.bad_sites if p.bad_sites is not None else np.zeros(p.n_sites, bool) for p in parts]))
+
+
 def _site_classes(site: dict, read_index: Dict[str, int]):
     """(read indices, classes) of one site; new read names get the next index."""
     read_allele: Dict[str, str] = {}

@@ -56,6 +56,8 @@ def load():
         lib.lgo_num_threads.restype = C.c_int
         lib.lgo_perm_rows.restype = C.c_int
         lib.lgo_perm_rows.argtypes = [C.c_uint64, u32p, u32p, u32p, C.c_uint32, C.c_uint64, f64p, u32p, C.c_int]
+        lib.lgo_perm_rows_exact.restype = C.c_int
+        lib.lgo_perm_rows_exact.argtypes = [C.c_uint64, u32p, f64p]
         _lib = lib
     return _lib
 
@@ -103,3 +105,29 @@ def run(pb, min_common=5, het_only=True, n_shuffles=0, seed=0, threads=0):
 def mi_from_table(table9):
     t = np.ascontiguousarray(table9, np.uint32).reshape(9)
     return float(load().lgo_mi_from_table(t.ctypes.data_as(u32p)))
+
+
+def perm_rows(row_i, row_j, counts, n_shuffles, seed, threads=0):
+    """the permutation specification on caller-supplied tables -> (p, exceed)"""
+    lib = load()
+    ri = np.ascontiguousarray(row_i, np.uint32)
+    rj = np.ascontiguousarray(row_j, np.uint32)
+    c = np.ascontiguousarray(counts, np.uint32).reshape(-1, 9)
+    p = np.empty(len(ri), np.float64)
+    e = np.empty(len(ri), np.uint32)
+    rc = lib.lgo_perm_rows(len(ri), _ptr(ri, u32p), _ptr(rj, u32p), _ptr(c, u32p), int(n_shuffles),
+                           int(seed) & (2**64 - 1), _ptr(p, f64p), _ptr(e, u32p), int(threads))
+    if rc:
+        raise RuntimeError('lgo_perm_rows failed: %d' % rc)
+    return p, e
+
+
+def perm_rows_exact(counts):
+    """exact permutation p of <= 2 x 2 tables (NaN for larger ones): what lgmi_params.exact_2x2 returns"""
+    lib = load()
+    c = np.ascontiguousarray(counts, np.uint32).reshape(-1, 9)
+    p = np.empty(len(c), np.float64)
+    rc = lib.lgo_perm_rows_exact(len(c), _ptr(c, u32p), _ptr(p, f64p))
+    if rc:
+        raise RuntimeError('lgo_perm_rows_exact failed: %d' % rc)
+    return p

@@ -638,6 +638,26 @@ int lgo_perm_rows(uint64_t n_rows, const uint32_t* row_i, const uint32_t* row_j,
     return 0;
 }
 
+/* exact permutation p of the rows with at most 2 x 2 non-empty classes (lgmi_params.exact_2x2): the mass of the tables
+ * with S >= S_obs, summed as in ptail22; 1.0 for degenerate tables; NaN for larger tables (they keep the Monte-Carlo
+ * estimate) */
+int lgo_perm_rows_exact(uint64_t n_rows, const uint32_t* counts, double* p_out)
+{
+    perm_tables t;
+    uint32_t max_n = 0;
+    uint64_t r;
+    for (r = 0; r < n_rows; ++r) {
+        uint32_t n = 0;
+        int k;
+        for (k = 0; k < 9; ++k) n += counts[9 * r + k];
+        if (n > max_n) max_n = n;
+    }
+    if (tables_init(&t, max_n)) return -1;
+    for (r = 0; r < n_rows; ++r) (void)perm_one(&t, counts + 9 * r, 0, 1, 0, 0, &p_out[r]);
+    free(t.G); free(t.LF);
+    return 0;
+}
+
 /* ---- hooks for the statistical tests of this specification (tests/test_perm_oracle.py) ---- */
 int lgo_hg_draw_many2(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed, uint32_t n, uint32_t* out, int use_table)
 {

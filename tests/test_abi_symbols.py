@@ -35,7 +35,7 @@ def test_abi_version_and_struct_sizes():
     assert C.sizeof(_lib.RunInfo) == 120
     assert C.sizeof(_lib.ShardPlan) == 152
     assert C.sizeof(_lib.GatherOpts) == 8
-    assert C.sizeof(_lib.SynthSpec) == 40
+    assert C.sizeof(_lib.SynthSpec) == 48
 
 
 def test_no_gpu_means_loud_failure():

@@ -125,6 +125,52 @@ def test_two_ranks_share_one_block():
     assert abs(a['n_examined'] - b['n_examined']) <= 0.1 * a['n_examined_total']
 
 
+def _socket_worker(rank, world, port, q):
+    from lgmi.dist import SocketGroup, exchange_unique_id, gather_tables_host
+    g = SocketGroup(rank, world, '127.0.0.1', port, timeout=60.0)
+    uid = exchange_unique_id(g, (lambda: bytes(range(128))) if rank == 0 else None)
+    tab = gather_tables_host(g, {'v': np.arange(3) + 10 * rank}, root=0)
+    q.put({'rank': rank, 'uid_ok': uid == bytes(range(128)), 'max': g.allreduce_max(rank + 0.5),
+           'all': g.allgather(rank), 'tab': None if tab is None else tab['v'].tolist()})
+    g.barrier()
+    g.close()
+
+
+def test_socket_group_three_ranks():
+    """the torch-free rendezvous the bench uses (plain launcher: rank 0 listens on MASTER_PORT)"""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_socket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(o['uid_ok'] and o['max'] == 2.5 and o['all'] == [0, 1, 2] for o in outs)
+    assert outs[0]['tab'] == [0, 1, 2, 10, 11, 12, 20, 21, 22] and outs[1]['tab'] is None
+
+
+def test_rendezvous_under_torch_distributed_run(tmp_path):
+    """exactly how the driver launches bench.py --gpus N: torchrun's agent owns MASTER_PORT, so the ranks meet on
+    an ephemeral port published through a file; the workers never import torch"""
+    import json
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'rdzv_worker.py')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), worker, str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = [json.load(open(tmp_path / ('rank%d.json' % k))) for k in range(2)]
+    for o in outs:
+        assert o['uid_ok'] and o['ranks'] == [0, 1] and o['max'] == 11.0 and o['agent_store'] == 'True'
+        assert not o['torch_loaded']
+    assert outs[0]['gathered'] == [0, 7] and outs[1]['gathered'] is None
+
+
 def test_shard_by_cost_edge_cases():
     assert shard_by_cost([], 4) == [[], [], [], []]
     assert shard_by_cost([5.0], 2) == [[0], []]

@@ -43,8 +43,8 @@ def engine():
     eng.close()
 
 
-@pytest.mark.parametrize('n_sites,n_reads,n_shuffles', [(10_000, 50_000, 1000), (50_000, 200_000, 0)],
-                         ids=['cfg2_10kx50k_S1000', 'north_star_50kx200k'])
+@pytest.mark.parametrize('n_sites,n_reads,n_shuffles', [(10_000, 50_000, 1000), (50_000, 200_000, 1000)],
+                         ids=['cfg2_10kx50k_S1000', 'north_star_50kx200k_S1000'])
 def test_full_size_properties(engine, n_sites, n_reads, n_shuffles):
     import lgmi
     spec = lgmi.default_synth_spec(n_sites, n_reads, seed=20250808)
@@ -91,6 +91,15 @@ def test_full_size_properties(engine, n_sites, n_reads, n_shuffles):
     assert res.row_mi[hh].mean() > 20 * res.row_mi[~hh].mean()
     if n_shuffles:
         S = n_shuffles
+        # the permutation counts of the sampled rows (2 x 2 and larger tables alike) against the CPU specification
+        # run on those rows' tables: bit-exact at the bench's own size and shuffle count
+        from oracle import c_oracle
+        general = np.nonzero(((res.row_counts.sum(axis=2) > 0).sum(axis=1) > 2) |
+                             ((res.row_counts.sum(axis=1) > 0).sum(axis=1) > 2))[0]
+        assert info['n_general_rows'] == len(general)
+        pick = np.concatenate([sample, rng.choice(general, min(300, len(general)), replace=False)])
+        _, e_spec = c_oracle.perm_rows(res.row_i[pick], res.row_j[pick], res.row_counts[pick], S, 11)
+        np.testing.assert_array_equal(res.row_exceed[pick], e_spec)
         np.testing.assert_array_equal(res.row_p, (1.0 + res.row_exceed) / (S + 1.0))
         assert (res.row_exceed[hh] == 0).all()                        # haplotype-linked: never matched by a shuffle
         # independent pairs: p-values are (discretely) uniform — Kolmogorov distance on a sample of 2e5 rows
@@ -99,3 +108,89 @@ def test_full_size_properties(engine, n_sites, n_reads, n_shuffles):
         d = np.max(np.abs(np.sort(pn) - (np.arange(len(pn)) + 0.5) / len(pn)))
         assert d < 0.01, d
         assert 0.45 < pn.mean() < 0.55
+
+
+def test_cfg3_slice_three_dense_blocks_against_the_oracle(engine):
+    """BASELINE.json configs[2] (22 chromosomes of 9,091 sites x 45,455 reads in one batch), down-scaled to what the
+    CPU oracle finishes in seconds: 3 blocks of 300 sites x 45,455 reads, S = 0 and 1000 — counts and exceed bit-exact"""
+    import lgmi
+    from oracle import c_oracle
+    from lgmi.pack import concat_batches
+    parts = []
+    for c in range(3):
+        db = engine.synth_dense(lgmi.default_synth_spec(300, 45_455, seed=20250810 + c))
+        parts.append(db.download())
+        db.free()
+    pb = concat_batches(parts)
+    assert pb.n_blocks == 3 and len(pb.site_pos) == 900
+    for S in (0, 1000):
+        res = engine.run(pb, min_common=6, het_only=True, n_shuffles=S, seed=21, emit_counts=True)
+        ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=S, seed=21)
+        np.testing.assert_array_equal(res.row_i, ora['row_i'])
+        np.testing.assert_array_equal(res.row_j, ora['row_j'])
+        np.testing.assert_array_equal(res.row_counts, ora['row_counts'])
+        assert np.max(np.abs(res.row_mi - ora['row_mi'])) <= 1e-6
+        if S:
+            np.testing.assert_array_equal(res.row_exceed, ora['row_exceed'])
+    # pairs never cross a block
+    bsb = pb.block_site_begin.astype(np.int64)
+    assert (np.searchsorted(bsb, res.row_i, side='right') == np.searchsorted(bsb, res.row_j, side='right')).all()
+
+
+def test_cfg5_slice_ten_thousand_shuffles_deep_coverage(engine):
+    """BASELINE.json configs[4] (coverage depth x 4, mi_min_common_read = 6, 10,000 shuffles), down-scaled: 40 sites x
+    181,820 reads (= 4 x 45,455), S = 10,000 — exceed bit-exact against the CPU specification"""
+    import lgmi
+    from oracle import c_oracle
+    spec = lgmi.default_synth_spec(40, 181_820, seed=20250812)
+    spec.tri_per_1024 = 200
+    db = engine.synth_dense(spec)
+    pb = db.download()
+    res = engine.run_device(db, min_common=6, het_only=True, n_shuffles=10_000, seed=9, emit_counts=True).fetch()
+    db.free()
+    ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=10_000, seed=9)
+    np.testing.assert_array_equal(res.row_counts, ora['row_counts'])
+    np.testing.assert_array_equal(res.row_exceed, ora['row_exceed'])
+    np.testing.assert_array_equal(res.row_p, (1.0 + res.row_exceed) / 10_001.0)
+    assert res.info['n_general_rows'] > 0
+
+
+@pytest.mark.parametrize('name,n_blocks,n_sites,n_reads,n_shuffles',
+                         [('cfg3_22x9091x45455', 22, 9_091, 45_455, 1000), ('cfg5_22x9091x181820_S10000', 3, 9_091, 181_820, 10_000)])
+def test_multi_block_full_size_properties(engine, name, n_blocks, n_sites, n_reads, n_shuffles):
+    """cfg3 at its full single-batch size (22 dense blocks, 200k sites x 1M reads) and one GPU's share of cfg5
+    (3 of its 22 blocks at depth x 4, 10,000 shuffles): ordering, block confinement, sampled tables against numpy
+    popcounts, sampled exceed counts against the CPU specification"""
+    import lgmi
+    from oracle import c_oracle
+    db = engine.synth_chromosomes(n_blocks, n_sites, n_reads, seed=20250810)
+    dr = engine.run_device(db, min_common=6, het_only=True, n_shuffles=n_shuffles, seed=13, emit_counts=True)
+    info = dr.info()
+    res = dr.fetch()
+    dr.free()
+    pb = db.download()
+    db.free()
+    P = n_sites
+    het = pb.site_type == 2
+    H = int(het[:P].sum())
+    per_block = H * (P - H) + H * (H - 1) // 2
+    assert info['n_examined'] == n_blocks * per_block == res.n_rows
+    i, j = res.row_i.astype(np.int64), res.row_j.astype(np.int64)
+    assert (i < j).all() and (i // P == j // P).all() and (het[i] | het[j]).all()
+    assert (np.diff(i * (n_blocks * P) + j) > 0).all()
+    rng = np.random.default_rng(5)
+    sample = rng.choice(res.n_rows, 600, replace=False)
+    planes = {}
+    for r in sample:
+        a, b = int(i[r]), int(j[r])
+        for s in (a, b):
+            if s not in planes:
+                planes[s] = site_class_planes(pb, s)
+        tab = np.array([[popcount64(planes[a][x] & planes[b][y]).sum() for y in range(3)] for x in range(3)])
+        assert (tab == res.row_counts[r]).all(), (a, b)
+        assert abs(mi_numpy(tab) - res.row_mi[r]) <= 1e-6
+    general = np.nonzero(((res.row_counts.sum(axis=2) > 0).sum(axis=1) > 2) | ((res.row_counts.sum(axis=1) > 0).sum(axis=1) > 2))[0]
+    assert info['n_general_rows'] == len(general)
+    pick = np.concatenate([sample, rng.choice(general, min(100 if n_shuffles > 1000 else 300, len(general)), replace=False)])
+    _, e_spec = c_oracle.perm_rows(res.row_i[pick], res.row_j[pick], res.row_counts[pick], n_shuffles, 13)
+    np.testing.assert_array_equal(res.row_exceed[pick], e_spec)

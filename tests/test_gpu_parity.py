@@ -252,6 +252,58 @@ def test_permutation_p_large_counts_and_tri_sites(engine, n_reads, S):
     db.free()
 
 
+def test_exact_2x2_p_matches_cpu_specification(engine):
+    """lgmi_params.exact_2x2: rows with at most 2 x 2 non-empty classes return the exact mass of the tables at least
+    as extreme (bit-equal to the CPU specification, itself checked against brute-force enumeration in
+    tests/test_perm_oracle.py); larger tables keep the Monte-Carlo estimate, or NaN when n_shuffles == 0"""
+    from lgmi._lib import EXCEED_EXACT
+    from oracle import c_oracle
+    pb = random_batch(8181, n_blocks=3, tri_frac=0.3, R=(6, 900))
+    base = engine.run(pb, min_common=3, het_only=False, n_shuffles=60, seed=4, emit_counts=True)
+    exact = c_oracle.perm_rows_exact(base.row_counts)
+    small = ~np.isnan(exact)
+    assert small.any() and (~small).any()
+    only = engine.run(pb, min_common=3, het_only=False, n_shuffles=0, exact_2x2=True, emit_counts=True)
+    np.testing.assert_array_equal(only.row_counts, base.row_counts)
+    np.testing.assert_array_equal(only.row_p, exact)                         # NaN-aware, bit for bit
+    assert (only.row_exceed == EXCEED_EXACT).all()
+    assert ((only.row_p[small] >= 0) & (only.row_p[small] <= 1)).all()
+    both = engine.run(pb, min_common=3, het_only=False, n_shuffles=60, seed=4, exact_2x2=True, emit_counts=True)
+    np.testing.assert_array_equal(both.row_p[small], exact[small])
+    assert (both.row_exceed[small] == EXCEED_EXACT).all()
+    np.testing.assert_array_equal(both.row_exceed[~small], base.row_exceed[~small])
+    np.testing.assert_array_equal(both.row_p[~small], base.row_p[~small])
+    # the Monte-Carlo estimate of the same rows scatters around the exact value like a binomial proportion
+    z = (base.row_exceed[small] - 60 * exact[small]) / np.sqrt(60 * exact[small] * (1 - exact[small]) + 1e-9)
+    assert abs(np.mean(z)) < 0.2 and np.mean(np.abs(z) < 3.5) > 0.99
+
+
+def test_hardware_exp_stays_inside_the_guard(engine):
+    """perm.hip le_exp(): the hardware's f32 exp decides an HRUA acceptance unless x2 is within 1e-4 of exp(t); that
+    is the same decision as det_exp's as long as |__expf / det_exp - 1| < 1e-4.  Swept on the device over the
+    whole range where the f32 value is a normal number, then adversarial x2 right at the guard's edges."""
+    rng = np.random.default_rng(17)
+    t = np.concatenate([np.linspace(-87.0, 0.0, 400_001), -rng.random(200_000) * 87.0, -rng.random(100_000) * 1e-3,
+                        -np.exp(rng.uniform(-30, 4.4, 100_000))])
+    t = t[t >= -87.0]
+    _, _, e_hw, e_det = engine.selftest_le_exp(np.ones_like(t), t)
+    rel = np.abs(e_hw / e_det - 1.0)
+    assert rel.max() < 2.5e-5, rel.max()                                       # a quarter of the 1e-4 guard
+    assert np.max(np.abs(e_det / np.exp(t) - 1.0)) < 1e-12                     # det_exp itself
+    # below the normal range of f32 the hardware value may flush to 0: then exp(t) < 1.2e-38 < 2^-66 <= x2
+    tl = -rng.uniform(87.0, 120.0, 50_000)
+    fast, det, e_hw2, e_det2 = engine.selftest_le_exp(np.full_like(tl, 2.0 ** -66), tl)
+    assert (e_det2 < 2.0 ** -66).all() and not fast.any() and not det.any()
+    # decisions: x2 = exp(t) * (1 + d) for d on both sides of the guard and of the boundary itself
+    ds = np.array([0.0, 1e-15, -1e-15, 2e-5, -2e-5, 9.0e-5, -9.0e-5, 0.99e-4, -0.99e-4, 1.01e-4, -1.01e-4, 3e-4, -3e-4,
+                   0.3, -0.3])
+    tt = np.repeat(-rng.random(60_000) * 45.0, len(ds))                       # x2 >= 2^-66 as in the callers
+    x2 = np.exp(tt) * (1.0 + np.tile(ds, 60_000))
+    keep = x2 >= 2.0 ** -66
+    fast, det, _, _ = engine.selftest_le_exp(x2[keep], tt[keep])
+    np.testing.assert_array_equal(fast, det)
+
+
 def test_permutation_seed_changes_draws_not_counts(engine):
     pb = random_batch(4242, n_blocks=1, P=(30, 30), R=(300, 300))
     a = engine.run(pb, min_common=5, n_shuffles=500, seed=1, emit_counts=True)
