@@ -272,14 +272,18 @@ def main():
             # prep + kernels + fetch), through lgmi_run.  Never `value`.
             pb = db.download()
             t1 = time.perf_counter()
+            eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+            dt_first = time.perf_counter() - t1                # pays the pinning of the result buffers (cached after)
+            t1 = time.perf_counter()
             hi = eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
             dt = time.perf_counter() - t1
-            out['host_to_host'] = {'ms': 1e3 * dt, 'site_pairs_per_s': hi['n_examined'] / dt,
+            out['host_to_host'] = {'ms': 1e3 * dt, 'ms_first_call': 1e3 * dt_first, 'site_pairs_per_s': hi['n_examined'] / dt,
                                    'h2d_bytes': int(pb.planes.nbytes + 25 * len(pb.site_pos)),
                                    'd2h_bytes': int(hi['bytes_out'] + 12 * len(pb.site_pos)),
                                    'kernels_ms': hi['ms_total'],
                                    'note': 'one lgmi_run call from pageable host memory: validation + H2D + layout prep '
-                                           '+ kernels + D2H of (i, j, mi, p, exceed) per row'}
+                                           '+ kernels + D2H of (i, j, mi, p, exceed) per row into pinned buffers the '
+                                           'context caches (the first call pins them)'}
             del pb
         if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
             out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -87,6 +89,31 @@ struct Pool {
     }
 };
 
+// Grow-only cache of PINNED host buffers for fetched results.  Pinning is what costs (0.9 s per 4 GiB measured,
+// tools/ubench_copy.hip) and a fresh pageable destination copies at 12 GB/s instead of 50: a caller that fetches
+// result after result (every footprint batch of a run) pays the pinning once.  Shared between the context and
+// the results it handed out, so either may die first.
+struct PinnedPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_;
+    void* take(size_t bytes, size_t* got) {
+        const size_t n = std::max<size_t>(4096, (bytes + 4095) & ~size_t(4095));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_.lower_bound(n);
+            if (it != free_.end() && it->first <= 2 * n + (1u << 20)) {
+                void* p = it->second; *got = it->first; free_.erase(it); return p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *got = n;
+        return p;
+    }
+    void give(void* p, size_t n) { if (p) { std::lock_guard<std::mutex> lk(mu); free_.emplace(n, p); } }
+    ~PinnedPool() { for (auto& kv : free_) (void)hipHostFree(kv.second); }
+};
+
 // ---------------------------------------------------------------- objects
 struct lgmi_ctx {
     int device = 0;
@@ -99,6 +126,7 @@ struct lgmi_ctx {
     void* comm = nullptr;       // ncclComm_t (comm.cpp)
     int rank = 0, world = 1;
     size_t mem_total = 0;       // device memory, for the "allocate rows by their upper bound" decision
+    std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
 };
 
 struct lgmi_dbatch {
@@ -131,9 +159,16 @@ struct lgmi_dresult {
     bool sharded = false;                  // per-site figures cover this shard's rows only
 };
 
-struct HostResult : ResultOwner {  // owner_ of a host lgmi_result
-    std::vector<uint32_t> i, j, exceed, counts, npairs;
-    std::vector<double> mi, p, mean;
+struct HostResult : ResultOwner {  // owner_ of a host lgmi_result: pinned buffers that go back to the context's cache
+    std::shared_ptr<PinnedPool> pool;
+    std::vector<std::pair<void*, size_t>> bufs;
+    template <class T> T* take(size_t count) {
+        size_t got = 0;
+        void* p = pool->take(std::max<size_t>(count, 1) * sizeof(T), &got);
+        if (p) bufs.emplace_back(p, got);
+        return static_cast<T*>(p);
+    }
+    ~HostResult() override { for (auto& b : bufs) pool->give(b.first, b.second); }
 };
 
 // ---------------------------------------------------------------- basics
@@ -820,34 +855,35 @@ extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out) {
     memset(out, 0, sizeof *out);
     HIPCHK(hipSetDevice(r->ctx->device));
     HostResult* h = new HostResult();
+    h->pool = r->ctx->pinned;
     struct Guard { HostResult* p; ~Guard() { delete p; } } guard{h};
     const size_t n = (size_t)r->n_rows, ns = (size_t)r->n_sites;
     hipStream_t st = r->ctx->stream;
+    uint32_t* hi = h->take<uint32_t>(n); uint32_t* hj = h->take<uint32_t>(n); double* hmi = h->take<double>(n);
+    double* hmean = h->take<double>(ns); uint32_t* hnp = h->take<uint32_t>(ns);
+    double* hp = r->has_p ? h->take<double>(n) : nullptr;
+    uint32_t* hex = r->has_p ? h->take<uint32_t>(n) : nullptr;
+    uint32_t* hc = r->has_counts ? h->take<uint32_t>(n * 9) : nullptr;
+    if (!hi || !hj || !hmi || !hmean || !hnp || (r->has_p && (!hp || !hex)) || (r->has_counts && !hc))
+        return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
     auto d2h = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
     };
-    h->i.resize(n); h->j.resize(n); h->mi.resize(n); h->mean.resize(ns); h->npairs.resize(ns);
-    HIPCHK(d2h(h->i.data(), r->d_i, n * 4));
-    HIPCHK(d2h(h->j.data(), r->d_j, n * 4));
-    HIPCHK(d2h(h->mi.data(), r->d_mi, n * 8));
-    HIPCHK(d2h(h->mean.data(), r->d_mean, ns * 8));
-    HIPCHK(d2h(h->npairs.data(), r->d_npairs, ns * 4));
+    HIPCHK(d2h(hi, r->d_i, n * 4));
+    HIPCHK(d2h(hj, r->d_j, n * 4));
+    HIPCHK(d2h(hmi, r->d_mi, n * 8));
+    HIPCHK(d2h(hmean, r->d_mean, ns * 8));
+    HIPCHK(d2h(hnp, r->d_npairs, ns * 4));
     if (r->has_p) {
-        h->p.resize(n); h->exceed.resize(n);
-        HIPCHK(d2h(h->p.data(), r->d_p, n * 8));
-        HIPCHK(d2h(h->exceed.data(), r->d_exceed, n * 4));
+        HIPCHK(d2h(hp, r->d_p, n * 8));
+        HIPCHK(d2h(hex, r->d_exceed, n * 4));
     }
-    if (r->has_counts) {
-        h->counts.resize(n * 9);
-        HIPCHK(d2h(h->counts.data(), r->d_counts, n * 36));
-    }
+    if (r->has_counts) HIPCHK(d2h(hc, r->d_counts, n * 36));
     HIPCHK(hipStreamSynchronize(st));
     out->n_rows = n; out->n_sites = ns;
-    out->row_i = h->i.data(); out->row_j = h->j.data(); out->row_mi = h->mi.data();
-    out->row_p = r->has_p ? h->p.data() : nullptr;
-    out->row_exceed = r->has_p ? h->exceed.data() : nullptr;
-    out->row_counts = r->has_counts ? h->counts.data() : nullptr;
-    out->site_mean_mi = h->mean.data(); out->site_n_pairs = h->npairs.data();
+    out->row_i = hi; out->row_j = hj; out->row_mi = hmi;
+    out->row_p = hp; out->row_exceed = hex; out->row_counts = hc;
+    out->site_mean_mi = hmean; out->site_n_pairs = hnp;
     out->owner_ = static_cast<ResultOwner*>(h);
     guard.p = nullptr;
     return LGMI_OK;
