@@ -683,7 +683,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
 
     BlockPlan* d_plans; uint32_t* d_xlist; uint32_t* d_ylist; SiteMap* d_smap; Tile* d_tiles; Tile* d_mtiles; uint2* d_items;
-    uint32_t *sN, *sR, *sC, *sA, *d_rowcnt; uint64_t* d_rowstart; uint32_t* d_cnt;
+    uint4* d_slots; uint32_t* d_rowcnt; uint64_t* d_rowstart; uint32_t* d_cnt;
     int* d_err; unsigned long long* d_wordpairs;
     if ((rc = salloc((void**)&d_plans, pl.plans.size() * sizeof(BlockPlan)))) return rc;
     if ((rc = salloc((void**)&d_xlist, pl.xlist.size() * 4))) return rc;
@@ -692,10 +692,10 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if ((rc = salloc((void**)&d_smap, pl.smap.size() * sizeof(SiteMap)))) return rc;
     if ((rc = salloc((void**)&d_tiles, pl.tiles.size() * sizeof(Tile)))) return rc;
     if ((rc = salloc((void**)&d_mtiles, pl.mtiles.size() * sizeof(Tile)))) return rc;
-    if ((rc = salloc((void**)&sN, pl.total_slots * 4))) return rc;
-    if ((rc = salloc((void**)&sR, pl.total_slots * 4))) return rc;
-    if ((rc = salloc((void**)&sC, pl.total_slots * 4))) return rc;
-    if ((rc = salloc((void**)&sA, pl.total_slots * 4))) return rc;
+    if ((rc = salloc((void**)&d_slots, pl.total_slots * sizeof(uint4)))) return rc;
+    uint4* d_ops = nullptr; OpGroup* d_opgroups = nullptr;
+    if ((rc = salloc((void**)&d_ops, std::max<uint64_t>(pl.op_total, 1) * sizeof(uint4)))) return rc;
+    if ((rc = salloc((void**)&d_opgroups, std::max<size_t>(pl.op_groups.size(), 1) * sizeof(OpGroup)))) return rc;
     if ((rc = salloc((void**)&d_rowcnt, std::max<size_t>(n_items, 1) * 4))) return rc;
     if ((rc = salloc((void**)&d_rowstart, (n_items + 1) * 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
@@ -718,16 +718,23 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(h2d(d_smap, pl.smap.data(), pl.smap.size() * sizeof(SiteMap)));
     HIPCHK(h2d(d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)));
     HIPCHK(h2d(d_mtiles, pl.mtiles.data(), pl.mtiles.size() * sizeof(Tile)));
+    HIPCHK(h2d(d_opgroups, pl.op_groups.data(), pl.op_groups.size() * sizeof(OpGroup)));
     if (ns) HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 16, st));
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
 
+    // FP4 matrix-core blocks: operands re-laid in wave-load order (part of "prep": ~2 ms at north-star)
+    if (pl.mfma_fp4 && !pl.mtiles.empty())
+        launch_gather_ops(st, (uint32_t)pl.op_groups.size(), pl.op_max_steps, d_opgroups, d_plans, d_xlist, d_ylist,
+                          db->d.d_cols, db->d.d_cplanes, d_ops);
     HIPCHK(hipEventRecord(ctx->ev[1], st));
-    (pl.mfma_fp4 ? launch_count_mfma_fp4 : launch_count_mfma)(
-        st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
-        db->d.d_cplanes + db->d.n_pairs16, sN, sR, sC, sA);
+    if (pl.mfma_fp4)
+        launch_count_mfma_fp4(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_ops, d_slots);
+    else
+        launch_count_mfma(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
+                          db->d.d_cplanes + db->d.n_pairs16, d_slots);
     launch_count(st, (uint32_t)pl.tiles.size(), d_tiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
-                 sN, sR, sC, sA);
+                 d_slots);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[2], st));
 
@@ -735,7 +742,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     ea.n_sites = ns; ea.min_common = prm->min_common; ea.het_only = prm->het_only != 0;
     ea.plans = d_plans; ea.smap = d_smap; ea.xlist = d_xlist; ea.cols = db->d.d_cols;
     ea.type = db->d.d_type; ea.tri = db->d.d_tri;
-    ea.sN = sN; ea.sR = sR; ea.sC = sC; ea.sA = sA;
+    ea.slots = d_slots;
     ea.n_items = (uint32_t)n_items; ea.items = d_items;
     ea.row_cnt = d_rowcnt; ea.row_start = d_rowstart;
     ea.site_sum = d_sum; ea.site_cnt = d_cnt; ea.err_flag = d_err; ea.word_pairs = d_wordpairs;

@@ -52,8 +52,7 @@ __global__ __launch_bounds__(256) void k_count(
     uint32_t n_tiles, const Tile* __restrict__ tiles, const BlockPlan* __restrict__ plans,
     const uint32_t* __restrict__ xlist, const uint32_t* __restrict__ ylist,
     const Col* __restrict__ cols, const ulonglong2* __restrict__ cplanes,
-    uint32_t* __restrict__ sN, uint32_t* __restrict__ sR, uint32_t* __restrict__ sC,
-    uint32_t* __restrict__ sA)
+    uint4* __restrict__ slots)
 {
     // [buf][k][x rows 0..63 | y cols 64..127 (permuted)] of (C_lo, C_hi, A_lo, A_hi)
     __shared__ uint4 lds[2][KC][2 * TILE];
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256) void k_count(
         __syncthreads();
     }
 
-    // ---- epilogue: 4 rows x (4 consecutive cols) per thread, one 16-byte store per plane
+    // ---- epilogue: 4 rows x (4 consecutive cols) per thread; a slot is (N, R, C, A), 16 bytes: 64 contiguous bytes per row
     const uint32_t col = t.y0 + 4u * tyl;
     if (col < bp.ny_pad) {
 #pragma unroll
@@ -140,10 +139,8 @@ __global__ __launch_bounds__(256) void k_count(
             const uint32_t row = t.x0 + txl + 16u * a;
             if (row < bp.nx) {
                 const uint64_t o = bp.slot_base + (uint64_t)row * bp.ny_pad + col;
-                *reinterpret_cast<uint4*>(sN + o) = make_uint4(accN[4 * a], accN[4 * a + 1], accN[4 * a + 2], accN[4 * a + 3]);
-                *reinterpret_cast<uint4*>(sR + o) = make_uint4(accR[4 * a], accR[4 * a + 1], accR[4 * a + 2], accR[4 * a + 3]);
-                *reinterpret_cast<uint4*>(sC + o) = make_uint4(accC[4 * a], accC[4 * a + 1], accC[4 * a + 2], accC[4 * a + 3]);
-                *reinterpret_cast<uint4*>(sA + o) = make_uint4(accA[4 * a], accA[4 * a + 1], accA[4 * a + 2], accA[4 * a + 3]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) slots[o + b] = make_uint4(accN[4 * a + b], accR[4 * a + b], accC[4 * a + b], accA[4 * a + b]);
             }
         }
     }
@@ -151,11 +148,11 @@ __global__ __launch_bounds__(256) void k_count(
 
 void launch_count(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
                   const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
-                  const ulonglong2* cplanes, uint32_t* sN, uint32_t* sR, uint32_t* sC, uint32_t* sA)
+                  const ulonglong2* cplanes, uint4* slots)
 {
     if (n_tiles == 0) return;
     hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, st, n_tiles, tiles, plans, xlist, ylist,
-                       cols, cplanes, sN, sR, sC, sA);
+                       cols, cplanes, slots);
 }
 
 }  // namespace lgmi

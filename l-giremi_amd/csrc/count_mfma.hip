@@ -43,8 +43,7 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
     uint32_t n_tiles, const Tile* __restrict__ tiles, const BlockPlan* __restrict__ plans,
     const uint32_t* __restrict__ xlist, const uint32_t* __restrict__ ylist,
     const Col* __restrict__ cols, const ulonglong2* __restrict__ cplanes,
-    const ulonglong2* __restrict__ zero_entry, uint32_t* __restrict__ sN, uint32_t* __restrict__ sR, uint32_t* __restrict__ sC,
-    uint32_t* __restrict__ sA)
+    const ulonglong2* __restrict__ zero_entry, uint4* __restrict__ slots)
 {
     const Tile t = tiles[xcd_remap_m(blockIdx.x, n_tiles)];
     const BlockPlan bp = plans[t.block];
@@ -167,10 +166,8 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
                     const uint32_t row = t.x0 + 64u * wx + 32u * i + (r & 3) + 8 * (r >> 2) + 4u * lh;
                     if (row < bp.nx) {
                         const uint64_t o = bp.slot_base + (uint64_t)row * bp.ny_pad + col;
-                        sN[o] = (uint32_t)acc[i][j][0][r] >> 6;
-                        sR[o] = (uint32_t)acc[i][j][1][r] >> 6;
-                        sC[o] = (uint32_t)acc[i][j][2][r] >> 6;
-                        sA[o] = (uint32_t)acc[i][j][3][r] >> 6;
+                        slots[o] = make_uint4((uint32_t)acc[i][j][0][r] >> 6, (uint32_t)acc[i][j][1][r] >> 6,
+                                              (uint32_t)acc[i][j][2][r] >> 6, (uint32_t)acc[i][j][3][r] >> 6);
                     }
                 }
             }
@@ -180,12 +177,11 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma(
 
 void launch_count_mfma(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
                        const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
-                       const ulonglong2* cplanes, const ulonglong2* zero_entry, uint32_t* sN, uint32_t* sR, uint32_t* sC,
-                       uint32_t* sA)
+                       const ulonglong2* cplanes, const ulonglong2* zero_entry, uint4* slots)
 {
     if (n_tiles == 0) return;
     hipLaunchKernelGGL(k_count_mfma, dim3(n_tiles), dim3(256), 0, st, n_tiles, tiles, plans, xlist, ylist,
-                       cols, cplanes, zero_entry, sN, sR, sC, sA);
+                       cols, cplanes, zero_entry, slots);
 }
 
 }  // namespace lgmi

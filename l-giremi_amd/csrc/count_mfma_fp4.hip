@@ -29,12 +29,50 @@ typedef float v16f __attribute__((ext_vector_type(16)));
                                                           v8i{b.x, b.y, b.z, b.w, 0, 0, 0, 0}, acc, 4, 4, 0, \
                                                           0x7F7F7F7F, 0, 0x7F7F7F7F)
 
+// ---- operand re-layout (once per run, ~2 ms at north-star): the column-major (C, A) entries of every 32-column
+// group in the order the count kernel's waves load them, so that each of its loads is one contiguous kilobyte
+// instead of 64 partial cache lines (the L1 tag pipeline was the count kernel's second bound).
+// One workgroup = one group x two steps; thread -> (step, plane, lane).
+__global__ __launch_bounds__(256) void k_gather_ops(
+    const OpGroup* __restrict__ groups, const BlockPlan* __restrict__ plans, const uint32_t* __restrict__ xlist,
+    const uint32_t* __restrict__ ylist, const Col* __restrict__ cols, const ulonglong2* __restrict__ cplanes,
+    uint4* __restrict__ ops)
+{
+    const OpGroup g = groups[blockIdx.x];
+    const BlockPlan bp = plans[g.block];
+    const uint32_t step = 2u * blockIdx.y + (threadIdx.x >> 7);
+    if (step >= bp.op_steps) return;
+    const uint32_t plane = (threadIdx.x >> 6) & 1u, lane = threadIdx.x & 63u;
+    const uint32_t idx = 32u * g.group + (lane & 31u);
+    uint32_t col = NONE;
+    if (g.is_y) { if (idx < bp.ny) col = ylist[bp.yl_off + idx]; }
+    else        { if (idx < bp.nx) col = xlist[bp.xl_off + idx]; }
+    uint4 out = make_uint4(0u, 0u, 0u, 0u);
+    if (col != NONE) {
+        const Col ci = cols[col];
+        const uint32_t kw = 4u * step + 2u * (lane >> 5);
+        const ulonglong2* base = cplanes + ci.off - ci.w0;
+        uint4 e0 = make_uint4(0u, 0u, 0u, 0u), e1 = e0;
+        if (kw >= ci.w0 && kw < ci.w0 + ci.nw) e0 = *reinterpret_cast<const uint4*>(base + kw);
+        if (kw + 1u >= ci.w0 && kw + 1u < ci.w0 + ci.nw) e1 = *reinterpret_cast<const uint4*>(base + kw + 1u);
+        out = plane ? make_uint4(e0.z, e0.w, e1.z, e1.w) : make_uint4(e0.x, e0.y, e1.x, e1.y);
+    }
+    const uint64_t o = (g.is_y ? bp.yop_off : bp.xop_off) + ((uint64_t)g.group * bp.op_steps + step) * 128u + 64u * plane + lane;
+    ops[o] = out;
+}
+
+void launch_gather_ops(hipStream_t st, uint32_t n_groups, uint32_t max_steps, const OpGroup* groups, const BlockPlan* plans,
+                       const uint32_t* xlist, const uint32_t* ylist, const Col* cols, const ulonglong2* cplanes,
+                       uint4* ops)
+{
+    if (!n_groups || !max_steps) return;
+    hipLaunchKernelGGL(k_gather_ops, dim3(n_groups, (max_steps + 1u) / 2u), dim3(256), 0, st, groups, plans, xlist, ylist,
+                       cols, cplanes, ops);
+}
+
 __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     uint32_t n_tiles, const Tile* __restrict__ tiles, const BlockPlan* __restrict__ plans,
-    const uint32_t* __restrict__ xlist, const uint32_t* __restrict__ ylist,
-    const Col* __restrict__ cols, const ulonglong2* __restrict__ cplanes,
-    const ulonglong2* __restrict__ zero_entry, uint32_t* __restrict__ sN, uint32_t* __restrict__ sR, uint32_t* __restrict__ sC,
-    uint32_t* __restrict__ sA)
+    const uint4* __restrict__ ops, uint4* __restrict__ slots)
 {
     const Tile t = tiles[xcd_remap_m(blockIdx.x, n_tiles)];
     const BlockPlan bp = plans[t.block];
@@ -42,14 +80,20 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     const uint32_t wx = wave >> 1, wy = wave & 1u;        // 2 x 2 waves over the 128 x 128 tile
     const uint32_t lh = lane >> 5, r32 = lane & 31u;
 
-    // the four columns this lane feeds: row r32 of x groups 0, 1 and of y groups 0, 1 of its wave
-    MStageCol cx0, cx1, cy0, cy1;
+    // this lane's stream of the four 32-column groups its wave feeds (x groups 0, 1 and y groups 0, 1): 16 bytes per
+    // plane and step, the wave's 64 lanes contiguous (k_gather_ops); groups beyond the lists were never laid out and
+    // are never stored from, so they read group 0 instead of unwritten memory
+    const uint32_t t0 = t.k0 >> 2;                          // first 4-word step
+    const uint32_t gxn = (bp.nx + 31u) / 32u, gyn = (bp.ny + 31u) / 32u;
+    const v4i *cx0, *cx1, *cy0, *cy1;
     {
-        const uint32_t rx = t.x0 + 64u * wx + r32, ry = t.y0 + 64u * wy + r32;
-        cx0 = m_col(rx < bp.nx ? xlist[bp.xl_off + rx] : NONE, cols, cplanes);
-        cx1 = m_col(rx + 32u < bp.nx ? xlist[bp.xl_off + rx + 32u] : NONE, cols, cplanes);
-        cy0 = m_col(ry < bp.ny ? ylist[bp.yl_off + ry] : NONE, cols, cplanes);
-        cy1 = m_col(ry + 32u < bp.ny ? ylist[bp.yl_off + ry + 32u] : NONE, cols, cplanes);
+        const uint32_t gx = (t.x0 >> 5) + 2u * wx, gy = (t.y0 >> 5) + 2u * wy;
+        const v4i* xb = reinterpret_cast<const v4i*>(ops + bp.xop_off) + lane;
+        const v4i* yb = reinterpret_cast<const v4i*>(ops + bp.yop_off) + lane;
+        cx0 = xb + ((uint64_t)(gx < gxn ? gx : 0u) * bp.op_steps + t0) * 128u;
+        cx1 = xb + ((uint64_t)(gx + 1u < gxn ? gx + 1u : 0u) * bp.op_steps + t0) * 128u;
+        cy0 = yb + ((uint64_t)(gy < gyn ? gy : 0u) * bp.op_steps + t0) * 128u;
+        cy1 = yb + ((uint64_t)(gy + 1u < gyn ? gy + 1u : 0u) * bp.op_steps + t0) * 128u;
     }
 
     v16f acc[2][2][4];     // [x group][y group][N, R, C, A]
@@ -91,16 +135,11 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
         if ((I) == 3) { O.a[q_] = (R.x[q_] >> 3) & 0x11111111; O.b[q_] = (R.y[q_] >> 1) & 0x44444444; }  \
     }
 #endif
-    // the two words of this lane's half of column C at step word KW -> plane quads (C, A)
+    // plane quads (C, A) of step ST (relative to the tile's first step) of group stream C
 #if LGMI_ABL & 2
-#define LGMI_LOAD2(QC, QA, C, KW) { QC = v4i{(int)(KW), 1, 2, 3}; QA = v4i{4, 5, (int)(KW), 7}; }
+#define LGMI_LOAD2(QC, QA, C, ST) { QC = v4i{(int)(ST), 1, 2, 3}; QA = v4i{4, 5, (int)(ST), 7}; }
 #else
-#define LGMI_LOAD2(QC, QA, C, KW)                                                                     \
-    {                                                                                                 \
-        const uint4 e0_ = m_ld_entry(C, (KW), zero_entry), e1_ = m_ld_entry(C, (KW) + 1u, zero_entry);    \
-        QC = v4i{(int)e0_.x, (int)e0_.y, (int)e1_.x, (int)e1_.y};                                       \
-        QA = v4i{(int)e0_.z, (int)e0_.w, (int)e1_.z, (int)e1_.w};                                       \
-    }
+#define LGMI_LOAD2(QC, QA, C, ST) { QC = C[(ST) * 128u]; QA = C[(ST) * 128u + 64u]; }
 #endif
     // one slot = the 16 MFMAs of a k-step with V VALU operations of the next k-step's preparation between them;
     // nothing moves across a slot boundary
@@ -128,26 +167,25 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     LGMI_OPS(Q, CUR, 3) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                                 \
     LGMI_OPS(P, NXT, 0) LGMI_MFMA16(Q) LGMI_SLOT_END(3)
 
-    const uint32_t n_words = t.k1 - t.k0;
-    const uint32_t n_trip = (n_words + 11u) / 12u;        // steps go three at a time; words past k1 are outside every band -> zeros
+    const uint32_t n_words = t.k1 - 4u * t0;
+    const uint32_t n_trip = (n_words + 11u) / 12u;        // steps go three at a time; steps past the block's words hold zeros
     Raw ra, rb, rc;
 #if LGMI_ABL & 4
-    const uint32_t kw0_ = t.k0 + 2u * lh + 8u;
-    LGMI_LOAD2(rc.x[0], rc.x[1], cx0, kw0_) LGMI_LOAD2(rc.x[2], rc.x[3], cx1, kw0_)
-    LGMI_LOAD2(rc.y[0], rc.y[1], cy0, kw0_) LGMI_LOAD2(rc.y[2], rc.y[3], cy1, kw0_)
+    LGMI_LOAD2(rc.x[0], rc.x[1], cx0, 2u) LGMI_LOAD2(rc.x[2], rc.x[3], cx1, 2u)
+    LGMI_LOAD2(rc.y[0], rc.y[1], cy0, 2u) LGMI_LOAD2(rc.y[2], rc.y[3], cy1, 2u)
 #endif
     Ops P, Q;
-    uint32_t kw = t.k0 + 2u * lh;                         // first of this lane's two words of the step
-    LGMI_LOAD2(ra.x[0], ra.x[1], cx0, kw) LGMI_LOAD2(ra.x[2], ra.x[3], cx1, kw)
-    LGMI_LOAD2(ra.y[0], ra.y[1], cy0, kw) LGMI_LOAD2(ra.y[2], ra.y[3], cy1, kw)
-    LGMI_LOAD2(rb.x[0], rb.x[1], cx0, kw + 4u) LGMI_LOAD2(rb.x[2], rb.x[3], cx1, kw + 4u)
-    LGMI_LOAD2(rb.y[0], rb.y[1], cy0, kw + 4u) LGMI_LOAD2(rb.y[2], rb.y[3], cy1, kw + 4u)
+    uint32_t st = 0u;                                     // current step, relative to t0
+    LGMI_LOAD2(ra.x[0], ra.x[1], cx0, 0u) LGMI_LOAD2(ra.x[2], ra.x[3], cx1, 0u)
+    LGMI_LOAD2(ra.y[0], ra.y[1], cy0, 0u) LGMI_LOAD2(ra.y[2], ra.y[3], cy1, 0u)
+    LGMI_LOAD2(rb.x[0], rb.x[1], cx0, 1u) LGMI_LOAD2(rb.x[2], rb.x[3], cx1, 1u)
+    LGMI_LOAD2(rb.y[0], rb.y[1], cy0, 1u) LGMI_LOAD2(rb.y[2], rb.y[3], cy1, 1u)
     LGMI_OPS(P, ra, 0)
     for (uint32_t s = 0; s < n_trip; ++s) {
-        LGMI_STEP(ra, rb, rc, kw + 8u)
-        LGMI_STEP(rb, rc, ra, kw + 12u)
-        LGMI_STEP(rc, ra, rb, kw + 16u)
-        kw += 12u;
+        LGMI_STEP(ra, rb, rc, st + 2u)
+        LGMI_STEP(rb, rc, ra, st + 3u)
+        LGMI_STEP(rc, ra, rb, st + 4u)
+        st += 3u;
     }
 
     // ---- epilogue: reg r of lane l is (x row (r&3) + 8 (r>>2) + 4 (l>>5), y col l&31) of its 32 x 32 tile
@@ -162,10 +200,8 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
                     const uint32_t row = t.x0 + 64u * wx + 32u * i + (r & 3) + 8 * (r >> 2) + 4u * lh;
                     if (row < bp.nx) {
                         const uint64_t o = bp.slot_base + (uint64_t)row * bp.ny_pad + col;
-                        sN[o] = (uint32_t)acc[i][j][0][r];
-                        sR[o] = (uint32_t)acc[i][j][1][r];
-                        sC[o] = (uint32_t)acc[i][j][2][r];
-                        sA[o] = (uint32_t)acc[i][j][3][r];
+                        slots[o] = make_uint4((uint32_t)acc[i][j][0][r], (uint32_t)acc[i][j][1][r],
+                                              (uint32_t)acc[i][j][2][r], (uint32_t)acc[i][j][3][r]);
                     }
                 }
             }
@@ -174,13 +210,10 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
 }
 
 void launch_count_mfma_fp4(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
-                           const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
-                           const ulonglong2* cplanes, const ulonglong2* zero_entry, uint32_t* sN, uint32_t* sR,
-                           uint32_t* sC, uint32_t* sA)
+                           const uint4* ops, uint4* slots)
 {
     if (n_tiles == 0) return;
-    hipLaunchKernelGGL(k_count_mfma_fp4, dim3(n_tiles), dim3(256), 0, st, n_tiles, tiles, plans, xlist, ylist,
-                       cols, cplanes, zero_entry, sN, sR, sC, sA);
+    hipLaunchKernelGGL(k_count_mfma_fp4, dim3(n_tiles), dim3(256), 0, st, n_tiles, tiles, plans, ops, slots);
 }
 
 }  // namespace lgmi

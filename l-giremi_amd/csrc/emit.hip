@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
         bool valid = false;
         uint32_t j = 0, n_common = 0;
         uint64_t slot = 0;
+        uint4 sl = make_uint4(0u, 0u, 0u, 0u);
         SiteMap mj;
         if (q < q_end) {
             j = i_in_x ? (i + 1u + q) : a.xlist[bp.xl_off + q0 + q];
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
                 const uint32_t xr = i_in_x ? mi_.xrow : mj.xrow;
                 const uint32_t yc = i_in_x ? mj.ycol : mi_.ycol;
                 slot = bp.slot_base + (uint64_t)xr * bp.ny_pad + yc;
-                n_common = a.sN[slot];
+                sl = a.slots[slot];
+                n_common = sl.x;
             }
             valid = (n_common >= a.min_common);
         }
@@ -112,21 +114,23 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
                     const bool tri_y = i_in_x ? tri_j : tri_i;
                     const SiteMap& mx = i_in_x ? mi_ : mj;
                     const SiteMap& my = i_in_x ? mj : mi_;
-                    const uint32_t N = n_common, r2 = a.sR[slot], c2 = a.sC[slot], n22 = a.sA[slot];
+                    const uint32_t N = n_common, r2 = sl.y, c2 = sl.z, n22 = sl.w;
                     uint32_t R1 = N - r2, C1 = N - c2, t12 = c2 - n22, t21 = r2 - n22;
                     if (tri_x) {
                         const uint64_t sb = bp.slot_base + (uint64_t)mx.prow * bp.ny_pad + my.ycol;
-                        R1 = a.sR[sb];
-                        t12 = a.sA[sb];
+                        const uint4 sp = a.slots[sb];
+                        R1 = sp.y;
+                        t12 = sp.w;
                     }
                     if (tri_y) {
                         const uint64_t sc = bp.slot_base + (uint64_t)mx.xrow * bp.ny_pad + my.pcol;
-                        C1 = a.sC[sc];
-                        t21 = a.sA[sc];
+                        const uint4 sp = a.slots[sc];
+                        C1 = sp.z;
+                        t21 = sp.w;
                     }
                     uint32_t t11;
                     if (tri_x && tri_y) {
-                        t11 = a.sA[bp.slot_base + (uint64_t)mx.prow * bp.ny_pad + my.pcol];
+                        t11 = a.slots[bp.slot_base + (uint64_t)mx.prow * bp.ny_pad + my.pcol].w;
                     } else if (tri_y) {
                         t11 = C1 - t21;
                     } else {

@@ -33,6 +33,13 @@ struct BlockPlan {
     uint32_t nxs;        // number of real x sites (prefix of the x list)
     uint32_t site_begin; // first global site of the block
     uint32_t site_end;
+    // matrix-core blocks (FP4 kernel): the operands re-laid in the order the waves load them (k_gather_ops):
+    // group g of 32 consecutive x rows (y columns), step t of 4 words -> 128 uint4 at op_off + (g * op_steps + t) * 128:
+    // [plane C | plane A][lane], lane = column (lane & 31) + 32 * half, the half's two words of the plane
+    uint64_t xop_off;    // in uint4 units; valid when op_steps > 0
+    uint64_t yop_off;
+    uint32_t op_steps;   // steps laid out per group (covers the block's words + the kernel's prefetch overrun, zeros beyond)
+    uint32_t op_pad;
 };
 
 // one 64 x 64 tile of a block's slot matrix and the word range it must sweep
@@ -84,17 +91,24 @@ struct DevBatch {  // what lgmi_dbatch owns on the device
 // count.hip
 void launch_count(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
                   const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
-                  const ulonglong2* cplanes, uint32_t* sN, uint32_t* sR, uint32_t* sC, uint32_t* sA);
+                  const ulonglong2* cplanes, uint4* slots);
 
 // count_mfma.hip (128 x 128 tiles on the int8 matrix cores; same slot planes)
 void launch_count_mfma(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
                        const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
-                       const ulonglong2* cplanes, const ulonglong2* zero_entry, uint32_t* sN, uint32_t* sR,
-                       uint32_t* sC, uint32_t* sA);
+                       const ulonglong2* cplanes, const ulonglong2* zero_entry, uint4* slots);
 void launch_count_mfma_fp4(hipStream_t st, uint32_t n_tiles, const Tile* tiles, const BlockPlan* plans,
-                           const uint32_t* xlist, const uint32_t* ylist, const Col* cols,
-                           const ulonglong2* cplanes, const ulonglong2* zero_entry, uint32_t* sN, uint32_t* sR,
-                           uint32_t* sC, uint32_t* sA);
+                           const uint4* ops, uint4* slots);
+// one entry per 32-column group whose operands a run needs
+struct OpGroup {
+    uint32_t block;
+    uint32_t is_y;       // 0: group of the x list, 1: of the y list
+    uint32_t group;      // rows / columns [32 * group, 32 * group + 32) of the list
+    uint32_t pad;
+};
+void launch_gather_ops(hipStream_t st, uint32_t n_groups, uint32_t max_steps, const OpGroup* groups, const BlockPlan* plans,
+                       const uint32_t* xlist, const uint32_t* ylist, const Col* cols, const ulonglong2* cplanes,
+                       uint4* ops);
 
 // emit.hip
 struct EmitArgs {
@@ -107,7 +121,7 @@ struct EmitArgs {
     const Col* cols;
     const uint8_t* type;
     const uint8_t* tri;
-    const uint32_t* sN; const uint32_t* sR; const uint32_t* sC; const uint32_t* sA;
+    const uint4* slots;       // one (N, R, C, A) per slot: common reads, class-2 reads of x, of y, of both
     // work items of the two emit passes: a site row is cut into segments of EMIT_SEG partners so that the long
     // rows of x sites (up to the whole block) spread over many waves; items are in (site, segment) order
     uint32_t n_items;

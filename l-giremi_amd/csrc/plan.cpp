@@ -203,6 +203,33 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         }
     }
     for (uint64_t s = 0; s < ns; ++s) pl.bytes_in += 16ull * in.cols[s].nw + 17ull;
+
+    // ---- FP4 matrix-core blocks: operand groups the shard's tiles read, and where each block's groups live
+    if (pl.mfma_fp4 && !pl.mtiles.empty()) {
+        std::vector<uint8_t> needx, needy;
+        size_t k = 0;
+        while (k < pl.mtiles.size()) {
+            const uint32_t b = pl.mtiles[k].block;
+            BlockPlan& bp = pl.plans[b];
+            const uint32_t gx = (bp.nx + 31u) / 32u, gy = (bp.ny + 31u) / 32u;
+            const uint32_t words = (in.block_n_reads[b] + 63u) / 64u;
+            bp.op_steps = (words + 3u) / 4u + 8u;          // + the software pipeline's read-ahead past the last step
+            needx.assign(gx, 0); needy.assign(gy, 0);
+            for (; k < pl.mtiles.size() && pl.mtiles[k].block == b; ++k) {
+                const Tile& t = pl.mtiles[k];
+                for (uint32_t g = t.x0 / 32u; g < std::min(gx, t.x0 / 32u + 4u); ++g) needx[g] = 1;
+                for (uint32_t g = t.y0 / 32u; g < std::min(gy, t.y0 / 32u + 4u); ++g) needy[g] = 1;
+            }
+            // every group of the block has its place (a tile addresses its groups by index); only the needed ones are filled
+            bp.xop_off = pl.op_total;
+            pl.op_total += (uint64_t)gx * bp.op_steps * 128u;
+            bp.yop_off = pl.op_total;
+            pl.op_total += (uint64_t)gy * bp.op_steps * 128u;
+            pl.op_max_steps = std::max(pl.op_max_steps, bp.op_steps);
+            for (uint32_t g = 0; g < gx; ++g) if (needx[g]) pl.op_groups.push_back(OpGroup{b, 0u, g, 0u});
+            for (uint32_t g = 0; g < gy; ++g) if (needy[g]) pl.op_groups.push_back(OpGroup{b, 1u, g, 0u});
+        }
+    }
 }
 
 }  // namespace lgmi

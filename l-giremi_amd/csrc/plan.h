@@ -30,6 +30,9 @@ struct Plan {
     bool mfma_fp4 = true;           // every matrix-core block has fewer than 2^24 reads: f32 accumulation is exact
     std::vector<Tile> tiles;        // 64 x 64 tiles for k_count (VALU popcount) — this shard's
     std::vector<Tile> mtiles;       // 128 x 128 tiles for the matrix-core count kernels — this shard's
+    std::vector<OpGroup> op_groups; // FP4 matrix-core blocks: the 32-column operand groups this shard's tiles read
+    uint64_t op_total = 0;          // uint4 entries of the re-laid operand buffer
+    uint32_t op_max_steps = 0;
     std::vector<uint2> items;       // emit work items of the WHOLE batch: (site, segment of EMIT_SEG partners), in row order
     uint64_t item_begin = 0, item_end = 0;   // this shard's items
     uint64_t total_slots = 0, n_examined = 0, n_examined_total = 0, bytes_in = 0;

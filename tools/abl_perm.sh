@@ -8,7 +8,7 @@ S=1000
 if [ "${1:-}" = "-s" ]; then S=$2; shift 2; fi
 mkdir -p gpurun_out l-giremi_amd/build_abl
 for a in "$@"; do
-  if ! make -C l-giremi_amd -s BUILD=build_abl/obj_$a LIB=build_abl/liblgmi_abl.so EXTRA="-DLGMI_PABL=$a" > gpurun_out/ablp_$a.build.log 2>&1; then
+  if ! make -C l-giremi_amd -s -j8 BUILD=build_abl/obj_$a LIB=build_abl/liblgmi_abl.so EXTRA="-DLGMI_PABL=$a" > gpurun_out/ablp_$a.build.log 2>&1; then
     echo "PABL $a: build refused (see gpurun_out/ablp_$a.build.log)"; continue
   fi
   LGMI_LIB=$PWD/l-giremi_amd/build_abl/liblgmi_abl.so timeout -k 10 200 python bench.py --no-cpu-baseline --steps 2 --warmup 1 --shuffles $S \
