@@ -1,0 +1,113 @@
+/*
+ * lgmi_io.h — C ABI of liblgmi_io.so: streaming, indexed BGZF/BAM access for the l-giremi-compatible CLI
+ * (SURVEY §8f N2).  Host only (zlib), no GPU.
+ *
+ * What it replaces in the reference (gxiaolab/L-GIREMI v0.2.4): the pysam.AlignmentFile the CLI opens at
+ * src/giremi/script/giremi.py:21-24 and the three things the MI path does with it —
+ *     sam.fetch(chromosome)                          src/giremi/footprint.py:6-28 (read intervals -> footprints)
+ *     sam.fetch(chromosome, start, end)              src/giremi/mismatch.py:69-149 (cs-tag walk per read)
+ *     sam.pileup(chromosome, start, end)             src/giremi/mismatch.py:160-190 (reference-allele read names)
+ * pysam/htslib cannot be installed here, so the format is read from its specification (SAM/BAM v1, sections 4.1
+ * BGZF, 4.2 BAM, 5.2 BAI).  A query reads only the BGZF blocks the index points at: memory is proportional to the
+ * region, not to the file.  Without a .bai next to the BAM the index is built in memory by one streaming pass
+ * (lgio_bam_build_index writes a standard .bai that samtools / pysam accept as well).
+ *
+ * Conventions: 0 on success, negative LGIO_E_* otherwise, message from lgio_last_error() (thread-local); results
+ * are library-owned and released by the matching *_free(); coordinates are 0-based half-open like pysam's.
+ */
+#ifndef LGMI_IO_H
+#define LGMI_IO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGIO_ABI_VERSION 1
+#define LGIO_OK        0
+#define LGIO_E_ARG    -1
+#define LGIO_E_IO     -2   /* open / read / seek failed                     */
+#define LGIO_E_FORMAT -3   /* not BGZF / BAM / BAI, or a truncated record   */
+#define LGIO_E_OOM    -4
+
+/* what lgio_bam_fetch() materialises per read, beyond the fixed columns */
+#define LGIO_NAMES  1u
+#define LGIO_CIGAR  2u
+#define LGIO_SEQ    4u   /* sequence (ASCII) and qualities */
+#define LGIO_CS     8u   /* text of the cs:Z tag (minimap2 --cs) */
+#define LGIO_AUX   16u   /* the raw auxiliary bytes (every tag)  */
+#define LGIO_ALL   31u
+
+typedef struct lgio_bam lgio_bam;
+
+/* reads overlapping a region, in file (coordinate) order; variable-length fields are CSR-packed:
+ * field k of read r is bytes [off[r], off[r+1]) of the pool */
+typedef struct lgio_reads {
+    uint64_t n;
+    const int32_t*  tid;          /* [n] reference id                          */
+    const int64_t*  start;        /* [n] 0-based leftmost position             */
+    const int64_t*  end;          /* [n] one past the last aligned position    */
+    const uint16_t* flag;         /* [n]                                       */
+    const uint8_t*  mapq;         /* [n]                                       */
+    const uint64_t* name_off;     /* [n+1] into names (no terminator)          */
+    const char*     names;
+    const uint64_t* cigar_off;    /* [n+1] into cigar, in operations           */
+    const uint32_t* cigar;        /* BAM encoding: length << 4 | op (MIDNSHP=X)*/
+    const uint64_t* seq_off;      /* [n+1] into seq and qual, in bases         */
+    const char*     seq;          /* ASCII, =ACMGRSVTWYHKDBN                   */
+    const uint8_t*  qual;         /* phred, 0xFF when absent                   */
+    const uint64_t* cs_off;       /* [n+1] into cs                             */
+    const char*     cs;
+    const uint8_t*  has_cs;       /* [n]                                       */
+    const uint64_t* aux_off;      /* [n+1] into aux                            */
+    const uint8_t*  aux;
+    void* owner_;
+} lgio_reads;
+
+/* pile-up columns with pysam's defaults (stepper 'samtools': unmapped, secondary, QC-failed and duplicate reads
+ * and orphans of paired reads are skipped; bases below min_base_quality are dropped; at most max_depth reads per
+ * column; columns are NOT truncated to the requested interval; a read that has a deletion or a reference skip at
+ * the column contributes base 0 — pysam's empty string).  read[k] indexes `reads`. */
+typedef struct lgio_pileup {
+    uint64_t n_cols;
+    const int64_t*  pos;          /* [n_cols] increasing                       */
+    const uint64_t* col_off;      /* [n_cols+1] into read / base               */
+    const uint32_t* read;
+    const char*     base;
+    lgio_reads reads;             /* names only                                */
+    void* owner_;
+} lgio_pileup;
+
+int         lgio_abi_version(void);
+const char* lgio_last_error(void);
+
+int  lgio_bam_open(const char* path, lgio_bam** out);    /* loads <path>.bai (or <stem>.bai) when present */
+void lgio_bam_close(lgio_bam* bam);
+int  lgio_bam_n_refs(const lgio_bam* bam);
+const char* lgio_bam_ref_name(const lgio_bam* bam, int tid);
+int64_t     lgio_bam_ref_length(const lgio_bam* bam, int tid);
+const char* lgio_bam_header_text(const lgio_bam* bam);
+int  lgio_bam_has_index_file(const lgio_bam* bam);       /* 1: a .bai was loaded, 0: the index was built in memory */
+
+/* one streaming pass over bam_path -> standard BAI at bai_path (NULL: <bam_path>.bai) */
+int  lgio_bam_build_index(const char* bam_path, const char* bai_path_or_null);
+
+/* reads overlapping [start, end) of reference tid (start < 0: the whole reference), unmapped reads skipped;
+ * `what` = LGIO_* bits */
+int  lgio_bam_fetch(lgio_bam* bam, int tid, int64_t start, int64_t end, uint32_t what, lgio_reads* out);
+void lgio_reads_free(lgio_reads* reads);
+
+int  lgio_bam_pileup(lgio_bam* bam, int tid, int64_t start, int64_t end, int min_base_quality, int max_depth,
+                     lgio_pileup* out);
+void lgio_pileup_free(lgio_pileup* pile);
+
+/* bytes of compressed file read so far through this handle (tests use it to show that a region query does not
+ * read the whole file) */
+uint64_t lgio_bam_bytes_read(const lgio_bam* bam);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGMI_IO_H */

@@ -1,0 +1,584 @@
+// bamio.cpp — liblgmi_io.so (include/lgmi_io.h): streaming BGZF/BAM reader with BAI random access, pysam-default
+// pile-up, and a BAI writer.  Written from the SAM/BAM specification (v1: 4.1 BGZF, 4.2 BAM records, 5.2 BAI, 5.3
+// reg2bin / reg2bins); zlib does the raw inflate.  Replaces the pysam.AlignmentFile of
+// src/giremi/script/giremi.py:21-24 for what the MI path calls on it (footprint.py:6-28, mismatch.py:69-190).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lgmi_io.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+// ---------------------------------------------------------------- BGZF (spec 4.1): a series of gzip members, each with a
+// 'BC' extra subfield holding its total size - 1; a virtual offset is (file offset of the block << 16) | offset inside it
+struct Bgzf {
+    FILE* f = nullptr;
+    uint64_t block_addr = ~0ull;        // file offset of the block in `data`
+    uint64_t next_addr = 0;             // file offset of the block after it
+    std::vector<uint8_t> data;          // its uncompressed bytes
+    size_t upos = 0;
+    uint64_t bytes_read = 0;
+    std::vector<uint8_t> comp;
+
+    ~Bgzf() { if (f) fclose(f); }
+
+    // 0 ok, 1 clean end of file, negative error
+    int load(uint64_t addr) {
+        if (addr == block_addr) return 0;
+        if (fseeko(f, (off_t)addr, SEEK_SET) != 0) return fail(LGIO_E_IO, "seek to %llu failed", (unsigned long long)addr);
+        uint8_t h[18];
+        const size_t got = fread(h, 1, 18, f);
+        if (got == 0) return 1;
+        if (got != 18) return fail(LGIO_E_FORMAT, "truncated BGZF block header at %llu", (unsigned long long)addr);
+        bytes_read += 18;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(LGIO_E_FORMAT, "not a BGZF block at %llu", (unsigned long long)addr);
+        const uint32_t xlen = le16(h + 10);
+        // the BC subfield is normally the first (and only) one; walk the extra field otherwise
+        uint32_t bsize = 0;
+        if (xlen == 6 && h[12] == 'B' && h[13] == 'C') {
+            bsize = le16(h + 16);
+        } else {
+            std::vector<uint8_t> extra(xlen);
+            memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
+            if (xlen > 6) {
+                if (fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) return fail(LGIO_E_FORMAT, "truncated BGZF extra field");
+                bytes_read += xlen - 6;
+            }
+            bool found = false;
+            for (uint32_t p = 0; p + 4 <= xlen;) {
+                const uint32_t slen = le16(&extra[p + 2]);
+                if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) { bsize = le16(&extra[p + 4]); found = true; break; }
+                p += 4 + slen;
+            }
+            if (!found) return fail(LGIO_E_FORMAT, "gzip member without a BC subfield at %llu (plain gzip, not BGZF?)", (unsigned long long)addr);
+            if (fseeko(f, (off_t)(addr + 12 + xlen), SEEK_SET) != 0) return fail(LGIO_E_IO, "seek failed");
+        }
+        const uint64_t total = (uint64_t)bsize + 1;
+        if (total < 12ull + xlen + 8) return fail(LGIO_E_FORMAT, "bad BGZF block size at %llu", (unsigned long long)addr);
+        const size_t clen = (size_t)(total - 12 - xlen - 8);
+        comp.resize(clen + 8);
+        if (fread(comp.data(), 1, clen + 8, f) != clen + 8) return fail(LGIO_E_FORMAT, "truncated BGZF block at %llu", (unsigned long long)addr);
+        bytes_read += clen + 8;
+        const uint32_t isize = le32(comp.data() + clen + 4);
+        if (isize > 65536) return fail(LGIO_E_FORMAT, "BGZF block larger than 64 KiB at %llu", (unsigned long long)addr);
+        data.resize(isize);
+        if (isize) {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) return fail(LGIO_E_OOM, "inflateInit2 failed");
+            zs.next_in = comp.data(); zs.avail_in = (uInt)clen;
+            zs.next_out = data.data(); zs.avail_out = isize;
+            const int zr = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (zr != Z_STREAM_END || zs.total_out != isize) return fail(LGIO_E_FORMAT, "inflate failed at block %llu", (unsigned long long)addr);
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), data.data(), isize) != le32(comp.data() + clen))
+                return fail(LGIO_E_FORMAT, "CRC mismatch in BGZF block %llu", (unsigned long long)addr);
+        }
+        block_addr = addr;
+        next_addr = addr + total;
+        upos = 0;
+        return 0;
+    }
+    int seek(uint64_t voff) {
+        const int rc = load(voff >> 16);
+        if (rc) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "virtual offset beyond the end of the file");
+        upos = (size_t)(voff & 0xFFFF);
+        if (upos > data.size()) return fail(LGIO_E_FORMAT, "virtual offset beyond its block");
+        return 0;
+    }
+    // the offset of the NEXT byte to be read: a position at the end of a block belongs to the following block
+    uint64_t tell() {
+        if (upos >= data.size() && block_addr != ~0ull) return next_addr << 16;
+        return (block_addr << 16) | upos;
+    }
+    // 0 ok, 1 end of file before the first byte, negative error (including EOF in the middle)
+    int read(void* dst, size_t n) {
+        uint8_t* out = static_cast<uint8_t*>(dst);
+        size_t done = 0;
+        while (done < n) {
+            if (block_addr == ~0ull || upos >= data.size()) {
+                const int rc = load(block_addr == ~0ull ? 0 : next_addr);
+                if (rc == 1) return done ? fail(LGIO_E_FORMAT, "file ends inside a record") : 1;
+                if (rc) return rc;
+                continue;               // (an empty block — the EOF marker — simply moves on)
+            }
+            const size_t take = std::min(n - done, data.size() - upos);
+            memcpy(out + done, data.data() + upos, take);
+            upos += take;
+            done += take;
+        }
+        return 0;
+    }
+};
+
+// ---------------------------------------------------------------- BAI (spec 5.2)
+int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>& out) {
+    out.clear();
+    --end;
+    out.push_back(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (end >> 26); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (end >> 23); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (end >> 20); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (end >> 17); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); ++k) out.push_back((uint32_t)k);
+}
+
+struct Chunk { uint64_t beg, end; };
+struct RefIndex {
+    std::map<uint32_t, std::vector<Chunk>> bins;
+    std::vector<uint64_t> linear;       // 16 kb windows: smallest virtual offset of a read overlapping the window
+};
+const int64_t MAX_POS = (int64_t)1 << 29;   // what a BAI can address
+
+struct Record {     // one alignment, decoded
+    int32_t tid; int64_t pos, end; uint16_t flag; uint8_t mapq;
+    uint32_t l_name, n_cigar, l_seq;
+    std::vector<uint8_t> raw;           // the record without its block_size word
+    const uint8_t* name() const { return raw.data() + 32; }
+    const uint8_t* cigar() const { return name() + l_name; }
+    const uint8_t* seq() const { return cigar() + 4ull * n_cigar; }
+    const uint8_t* qual() const { return seq() + (l_seq + 1) / 2; }
+    const uint8_t* aux() const { return qual() + l_seq; }
+    size_t aux_len() const { return raw.size() - (size_t)(aux() - raw.data()); }
+};
+
+// 0 ok, 1 end of file, negative error
+int read_record(Bgzf& z, Record& r) {
+    uint8_t len4[4];
+    int rc = z.read(len4, 4);
+    if (rc) return rc;
+    const uint32_t bs = le32(len4);
+    if (bs < 32 || bs > (1u << 29)) return fail(LGIO_E_FORMAT, "implausible BAM record size %u", bs);
+    r.raw.resize(bs);
+    rc = z.read(r.raw.data(), bs);
+    if (rc) return rc == 1 ? fail(LGIO_E_FORMAT, "file ends inside a record") : rc;
+    const uint8_t* p = r.raw.data();
+    r.tid = (int32_t)le32(p);
+    r.pos = (int32_t)le32(p + 4);
+    r.l_name = p[8];
+    r.mapq = p[9];
+    r.n_cigar = le16(p + 12);
+    r.flag = le16(p + 14);
+    r.l_seq = le32(p + 16);
+    const uint64_t need = 32ull + r.l_name + 4ull * r.n_cigar + (r.l_seq + 1ull) / 2 + r.l_seq;
+    if (need > bs || r.l_name == 0) return fail(LGIO_E_FORMAT, "BAM record fields exceed the record");
+    int64_t span = 0;
+    const uint8_t* c = r.cigar();
+    for (uint32_t k = 0; k < r.n_cigar; ++k) {
+        const uint32_t v = le32(c + 4 * k), op = v & 0xF;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4;      // M D N = X consume the reference
+    }
+    r.end = r.pos + (span > 0 ? span : 1);       // htslib: a read without reference-consuming operations spans 1
+    return 0;
+}
+
+}  // namespace
+
+struct lgio_bam {
+    Bgzf z;
+    std::string path, header_text;
+    std::vector<std::string> ref_names;
+    std::vector<int64_t> ref_lens;
+    std::vector<RefIndex> index;
+    uint64_t first_record_voff = 0;
+    bool index_from_file = false;
+};
+
+namespace {
+
+int read_header(lgio_bam* b) {
+    uint8_t magic[4], w[4];
+    int rc = b->z.read(magic, 4);
+    if (rc) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "empty file");
+    if (memcmp(magic, "BAM\1", 4) != 0) return fail(LGIO_E_FORMAT, "%s is not a BAM file", b->path.c_str());
+    if ((rc = b->z.read(w, 4))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
+    const uint32_t l_text = le32(w);
+    b->header_text.resize(l_text);
+    if (l_text && (rc = b->z.read(&b->header_text[0], l_text))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
+    while (!b->header_text.empty() && b->header_text.back() == '\0') b->header_text.pop_back();
+    if ((rc = b->z.read(w, 4))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
+    const uint32_t n_ref = le32(w);
+    for (uint32_t k = 0; k < n_ref; ++k) {
+        if ((rc = b->z.read(w, 4))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
+        const uint32_t ln = le32(w);
+        if (ln == 0 || ln > 65536) return fail(LGIO_E_FORMAT, "bad reference name length");
+        std::string name(ln, '\0');
+        if ((rc = b->z.read(&name[0], ln))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
+        name.resize(ln - 1);
+        if ((rc = b->z.read(w, 4))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
+        b->ref_names.push_back(name);
+        b->ref_lens.push_back((int32_t)le32(w));
+    }
+    b->first_record_voff = b->z.tell();
+    return 0;
+}
+
+// one pass over the records: bins, chunks and the linear index of every reference
+int scan_index(lgio_bam* b, std::vector<RefIndex>& idx) {
+    idx.assign(b->ref_names.size(), RefIndex());
+    int rc = b->z.seek(b->first_record_voff);
+    if (rc) return rc;
+    Record r;
+    int32_t last_tid = -1; int64_t last_pos = -1;
+    for (;;) {
+        const uint64_t v0 = b->z.tell();
+        rc = read_record(b->z, r);
+        if (rc == 1) break;
+        if (rc) return rc;
+        const uint64_t v1 = b->z.tell();
+        if (r.tid < 0) continue;                            // unplaced reads sit at the end
+        if ((size_t)r.tid >= idx.size()) return fail(LGIO_E_FORMAT, "record refers to reference %d of %zu", r.tid, idx.size());
+        if (r.tid < last_tid || (r.tid == last_tid && r.pos < last_pos))
+            return fail(LGIO_E_FORMAT, "the BAM is not sorted by coordinate (reference %d, position %lld after %lld)", r.tid,
+                        (long long)r.pos, (long long)last_pos);
+        last_tid = r.tid; last_pos = r.pos;
+        if (r.pos < 0 || r.end > MAX_POS) return fail(LGIO_E_FORMAT, "position beyond 2^29: a BAI cannot index it");
+        RefIndex& ri = idx[r.tid];
+        std::vector<Chunk>& ch = ri.bins[(uint32_t)reg2bin(r.pos, r.end)];
+        if (!ch.empty() && ch.back().end == v0) ch.back().end = v1;   // consecutive records of a bin form one chunk
+        else ch.push_back(Chunk{v0, v1});
+        const size_t w0 = (size_t)(r.pos >> 14), w1 = (size_t)((r.end - 1) >> 14);
+        if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+        for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == 0) ri.linear[w] = v0;   // file order: the first is the smallest
+    }
+    // windows no read starts in or crosses inherit the previous window's offset (what samtools writes)
+    for (RefIndex& ri : idx)
+        for (size_t w = 1; w < ri.linear.size(); ++w) if (ri.linear[w] == 0) ri.linear[w] = ri.linear[w - 1];
+    return 0;
+}
+
+int load_bai(const std::string& path, size_t n_ref, std::vector<RefIndex>& idx) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return 1;
+    std::vector<uint8_t> buf;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    size_t p = 0;
+    auto need = [&](size_t k) { return p + k <= buf.size(); };
+    if (!need(8) || memcmp(buf.data(), "BAI\1", 4) != 0) return fail(LGIO_E_FORMAT, "%s is not a BAI file", path.c_str());
+    p = 4;
+    const uint32_t nr = le32(&buf[p]); p += 4;
+    if (nr != n_ref) return fail(LGIO_E_FORMAT, "%s indexes %u references, the BAM has %zu", path.c_str(), nr, n_ref);
+    idx.assign(n_ref, RefIndex());
+    for (uint32_t r = 0; r < nr; ++r) {
+        if (!need(4)) return fail(LGIO_E_FORMAT, "truncated BAI");
+        const uint32_t n_bin = le32(&buf[p]); p += 4;
+        for (uint32_t k = 0; k < n_bin; ++k) {
+            if (!need(8)) return fail(LGIO_E_FORMAT, "truncated BAI");
+            const uint32_t bin = le32(&buf[p]), n_chunk = le32(&buf[p + 4]); p += 8;
+            if (!need(16ull * n_chunk)) return fail(LGIO_E_FORMAT, "truncated BAI");
+            if (bin != 37450) {                             // 37450 is the metadata pseudo-bin
+                std::vector<Chunk>& ch = idx[r].bins[bin];
+                for (uint32_t c = 0; c < n_chunk; ++c) ch.push_back(Chunk{le64(&buf[p + 16 * c]), le64(&buf[p + 16 * c + 8])});
+            }
+            p += 16ull * n_chunk;
+        }
+        if (!need(4)) return fail(LGIO_E_FORMAT, "truncated BAI");
+        const uint32_t n_intv = le32(&buf[p]); p += 4;
+        if (!need(8ull * n_intv)) return fail(LGIO_E_FORMAT, "truncated BAI");
+        idx[r].linear.resize(n_intv);
+        for (uint32_t w = 0; w < n_intv; ++w) idx[r].linear[w] = le64(&buf[p + 8 * w]);
+        p += 8ull * n_intv;
+    }
+    return 0;
+}
+
+int write_bai(const std::string& path, const std::vector<RefIndex>& idx) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return fail(LGIO_E_IO, "cannot write %s", path.c_str());
+    auto w32 = [&](uint32_t v) { uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; fwrite(b, 1, 4, f); };
+    auto w64 = [&](uint64_t v) { w32((uint32_t)v); w32((uint32_t)(v >> 32)); };
+    fwrite("BAI\1", 1, 4, f);
+    w32((uint32_t)idx.size());
+    for (const RefIndex& ri : idx) {
+        w32((uint32_t)ri.bins.size());
+        for (const auto& kv : ri.bins) {
+            w32(kv.first);
+            w32((uint32_t)kv.second.size());
+            for (const Chunk& c : kv.second) { w64(c.beg); w64(c.end); }
+        }
+        w32((uint32_t)ri.linear.size());
+        for (uint64_t v : ri.linear) w64(v);
+    }
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok ? 0 : fail(LGIO_E_IO, "write error on %s", path.c_str());
+}
+
+// chunks that can hold reads overlapping [beg, end), merged and sorted
+void query_chunks(const RefIndex& ri, int64_t beg, int64_t end, std::vector<Chunk>& out) {
+    out.clear();
+    std::vector<uint32_t> bins;
+    reg2bins(beg, end, bins);
+    const size_t w = (size_t)(beg >> 14);
+    const uint64_t min_off = ri.linear.empty() ? 0 : (w < ri.linear.size() ? ri.linear[w] : ri.linear.back());
+    for (uint32_t bn : bins) {
+        auto it = ri.bins.find(bn);
+        if (it == ri.bins.end()) continue;
+        for (const Chunk& c : it->second) if (c.end > min_off) out.push_back(Chunk{std::max(c.beg, min_off), c.end});
+    }
+    std::sort(out.begin(), out.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
+    size_t k = 0;
+    for (size_t i = 0; i < out.size(); ++i) {
+        if (k && out[i].beg <= out[k - 1].end) out[k - 1].end = std::max(out[k - 1].end, out[i].end);
+        else out[k++] = out[i];
+    }
+    out.resize(k);
+}
+
+struct ReadsOwner {
+    std::vector<int32_t> tid; std::vector<int64_t> start, end; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, has_cs;
+    std::vector<uint64_t> name_off{0}, cigar_off{0}, seq_off{0}, cs_off{0}, aux_off{0};
+    std::vector<char> names, seq, cs; std::vector<uint32_t> cigar; std::vector<uint8_t> qual, aux;
+    void add(const Record& r, uint32_t what) {
+        tid.push_back(r.tid); start.push_back(r.pos); end.push_back(r.end); flag.push_back(r.flag); mapq.push_back(r.mapq);
+        if (what & LGIO_NAMES) names.insert(names.end(), r.name(), r.name() + r.l_name - 1);
+        name_off.push_back(names.size());
+        if (what & LGIO_CIGAR) for (uint32_t k = 0; k < r.n_cigar; ++k) cigar.push_back(le32(r.cigar() + 4 * k));
+        cigar_off.push_back(cigar.size());
+        if (what & LGIO_SEQ) {
+            static const char code[] = "=ACMGRSVTWYHKDBN";
+            const uint8_t* s = r.seq();
+            for (uint32_t k = 0; k < r.l_seq; ++k) seq.push_back(code[(s[k >> 1] >> ((~k & 1) << 2)) & 0xF]);
+            qual.insert(qual.end(), r.qual(), r.qual() + r.l_seq);
+        }
+        seq_off.push_back(seq.size());
+        uint8_t found = 0;
+        if (what & LGIO_CS) {
+            // auxiliary fields: tag[2] type value...; the cs tag is a 'Z' string
+            const uint8_t* a = r.aux();
+            const size_t n = r.aux_len();
+            size_t p = 0;
+            while (p + 3 <= n) {
+                const uint8_t t0 = a[p], t1 = a[p + 1], ty = a[p + 2];
+                p += 3;
+                size_t len = 0;
+                if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+                else if (ty == 's' || ty == 'S') len = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+                else if (ty == 'Z' || ty == 'H') { while (p + len < n && a[p + len]) ++len; if (t0 == 'c' && t1 == 's' && ty == 'Z') { cs.insert(cs.end(), a + p, a + p + len); found = 1; } ++len; }
+                else if (ty == 'B') {
+                    if (p + 5 > n) break;
+                    const uint8_t sub = a[p];
+                    const uint32_t cnt = le32(a + p + 1);
+                    const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                    len = 5 + es * cnt;
+                } else break;
+                p += len;
+                if (found) break;
+            }
+        }
+        has_cs.push_back(found);
+        cs_off.push_back(cs.size());
+        if (what & LGIO_AUX) aux.insert(aux.end(), r.aux(), r.aux() + r.aux_len());
+        aux_off.push_back(aux.size());
+    }
+    void view(lgio_reads* out) {
+        out->n = tid.size();
+        out->tid = tid.data(); out->start = start.data(); out->end = end.data(); out->flag = flag.data(); out->mapq = mapq.data();
+        out->name_off = name_off.data(); out->names = names.data();
+        out->cigar_off = cigar_off.data(); out->cigar = cigar.data();
+        out->seq_off = seq_off.data(); out->seq = seq.data(); out->qual = qual.data();
+        out->cs_off = cs_off.data(); out->cs = cs.data(); out->has_cs = has_cs.data();
+        out->aux_off = aux_off.data(); out->aux = aux.data();
+        out->owner_ = this;
+    }
+};
+
+// calls fn(record) for every mapped read of `tid` overlapping [beg, end) (beg < 0: the whole reference)
+template <class F>
+int for_each_overlap(lgio_bam* b, int tid, int64_t beg, int64_t end, F fn) {
+    if (tid < 0 || (size_t)tid >= b->ref_names.size()) return fail(LGIO_E_ARG, "reference id %d out of range", tid);
+    if (beg < 0) { beg = 0; end = MAX_POS; }
+    if (end > MAX_POS) end = MAX_POS;
+    if (beg >= end) return 0;
+    std::vector<Chunk> chunks;
+    query_chunks(b->index[tid], beg, end, chunks);
+    Record r;
+    for (const Chunk& c : chunks) {
+        int rc = b->z.seek(c.beg);
+        if (rc) return rc;
+        while (b->z.tell() < c.end) {
+            rc = read_record(b->z, r);
+            if (rc == 1) break;
+            if (rc) return rc;
+            if (r.tid != tid || r.pos >= end) { if (r.tid > tid || (r.tid == tid && r.pos >= end)) goto next_chunk; continue; }
+            if (r.end <= beg || (r.flag & 4)) continue;
+            fn(r);
+        }
+    next_chunk:;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int lgio_abi_version(void) { return LGIO_ABI_VERSION; }
+extern "C" const char* lgio_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lgio_bam_open(const char* path, lgio_bam** out) {
+    if (!path || !out) return fail(LGIO_E_ARG, "NULL argument");
+    *out = nullptr;
+    lgio_bam* b = new lgio_bam();
+    b->path = path;
+    b->z.f = fopen(path, "rb");
+    if (!b->z.f) { delete b; return fail(LGIO_E_IO, "cannot open %s", path); }
+    int rc = read_header(b);
+    if (rc) { delete b; return rc; }
+    std::string stem = b->path;
+    if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".bam") == 0) stem.resize(stem.size() - 4);
+    rc = load_bai(b->path + ".bai", b->ref_names.size(), b->index);
+    if (rc == 1) rc = load_bai(stem + ".bai", b->ref_names.size(), b->index);
+    if (rc < 0) { delete b; return rc; }
+    b->index_from_file = (rc == 0);
+    if (rc == 1 && (rc = scan_index(b, b->index))) { delete b; return rc; }
+    *out = b;
+    return LGIO_OK;
+}
+
+extern "C" void lgio_bam_close(lgio_bam* b) { delete b; }
+extern "C" int lgio_bam_n_refs(const lgio_bam* b) { return b ? (int)b->ref_names.size() : 0; }
+extern "C" const char* lgio_bam_ref_name(const lgio_bam* b, int tid) {
+    return (b && tid >= 0 && (size_t)tid < b->ref_names.size()) ? b->ref_names[tid].c_str() : nullptr;
+}
+extern "C" int64_t lgio_bam_ref_length(const lgio_bam* b, int tid) {
+    return (b && tid >= 0 && (size_t)tid < b->ref_lens.size()) ? b->ref_lens[tid] : -1;
+}
+extern "C" const char* lgio_bam_header_text(const lgio_bam* b) { return b ? b->header_text.c_str() : nullptr; }
+extern "C" int lgio_bam_has_index_file(const lgio_bam* b) { return b && b->index_from_file ? 1 : 0; }
+extern "C" uint64_t lgio_bam_bytes_read(const lgio_bam* b) { return b ? b->z.bytes_read : 0; }
+
+extern "C" int lgio_bam_build_index(const char* bam_path, const char* bai_path) {
+    if (!bam_path) return fail(LGIO_E_ARG, "NULL argument");
+    lgio_bam b;
+    b.path = bam_path;
+    b.z.f = fopen(bam_path, "rb");
+    if (!b.z.f) return fail(LGIO_E_IO, "cannot open %s", bam_path);
+    int rc = read_header(&b);
+    if (rc) return rc;
+    std::vector<RefIndex> idx;
+    if ((rc = scan_index(&b, idx))) return rc;
+    return write_bai(bai_path ? std::string(bai_path) : b.path + ".bai", idx);
+}
+
+extern "C" void lgio_reads_free(lgio_reads* r) {
+    if (!r) return;
+    delete static_cast<ReadsOwner*>(r->owner_);
+    memset(r, 0, sizeof *r);
+}
+
+extern "C" int lgio_bam_fetch(lgio_bam* b, int tid, int64_t start, int64_t end, uint32_t what, lgio_reads* out) {
+    if (!b || !out) return fail(LGIO_E_ARG, "NULL argument");
+    memset(out, 0, sizeof *out);
+    ReadsOwner* o = new ReadsOwner();
+    const int rc = for_each_overlap(b, tid, start, end, [&](const Record& r) { o->add(r, what); });
+    if (rc) { delete o; return rc; }
+    o->view(out);
+    return LGIO_OK;
+}
+
+namespace {
+struct PileOwner { ReadsOwner reads; std::vector<int64_t> pos; std::vector<uint64_t> col_off; std::vector<uint32_t> read; std::vector<char> base; };
+}
+
+extern "C" void lgio_pileup_free(lgio_pileup* p) {
+    if (!p) return;
+    delete static_cast<PileOwner*>(p->owner_);
+    memset(p, 0, sizeof *p);
+}
+
+extern "C" int lgio_bam_pileup(lgio_bam* b, int tid, int64_t start, int64_t end, int min_bq, int max_depth, lgio_pileup* out) {
+    if (!b || !out) return fail(LGIO_E_ARG, "NULL argument");
+    memset(out, 0, sizeof *out);
+    if (max_depth <= 0) max_depth = 8000;
+    PileOwner* o = new PileOwner();
+    // pass 1: the reads (records kept whole: the second pass walks their CIGARs)
+    std::vector<Record> recs;
+    int rc = for_each_overlap(b, tid, start, end, [&](const Record& r) {
+        if (r.flag & (4 | 256 | 512 | 1024)) return;            // unmapped, secondary, QC-fail, duplicate
+        if ((r.flag & 1) && !(r.flag & 2)) return;              // orphan of a paired read
+        recs.push_back(r);
+    });
+    if (rc) { delete o; return rc; }
+    if (!recs.empty()) {
+        int64_t lo = recs[0].pos, hi = recs[0].end;
+        for (const Record& r : recs) { lo = std::min(lo, r.pos); hi = std::max(hi, r.end); }
+        const size_t span = (size_t)(hi - lo);
+        // columns are not truncated to [start, end): every position any of the reads aligns to
+        std::vector<uint32_t> depth(span, 0);
+        static const char code[] = "=ACMGRSVTWYHKDBN";
+        // walk(r, emit): emit(ref position, base or 0) for every reference position of the read
+        auto walk = [&](const Record& r, auto emit) {
+            int64_t ref = r.pos; uint32_t q = 0;
+            const uint8_t *c = r.cigar(), *s = r.seq(), *ql = r.qual();
+            for (uint32_t k = 0; k < r.n_cigar; ++k) {
+                const uint32_t v = le32(c + 4 * k), op = v & 0xF, n = v >> 4;
+                if (op == 0 || op == 7 || op == 8) {
+                    for (uint32_t j = 0; j < n; ++j, ++ref, ++q) {
+                        if (q < r.l_seq && ql[q] != 0xFF && ql[q] < (uint32_t)min_bq) continue;
+                        emit(ref, q < r.l_seq ? code[(s[q >> 1] >> ((~q & 1) << 2)) & 0xF] : 'N');
+                    }
+                } else if (op == 2 || op == 3) {
+                    for (uint32_t j = 0; j < n; ++j, ++ref) emit(ref, (char)0);
+                } else if (op == 1 || op == 4) q += n;
+            }
+        };
+        for (const Record& r : recs)
+            walk(r, [&](int64_t p, char) { uint32_t& d = depth[(size_t)(p - lo)]; if (d < (uint32_t)max_depth) ++d; });
+        std::vector<uint64_t> at(span + 1, 0);
+        for (size_t k = 0; k < span; ++k) at[k + 1] = at[k] + depth[k];
+        o->read.resize((size_t)at[span]); o->base.resize((size_t)at[span]);
+        std::vector<uint32_t> fill(span, 0);
+        for (size_t ri = 0; ri < recs.size(); ++ri)
+            walk(recs[ri], [&](int64_t p, char bs) {
+                const size_t k = (size_t)(p - lo);
+                if (fill[k] < depth[k]) { o->read[(size_t)at[k] + fill[k]] = (uint32_t)ri; o->base[(size_t)at[k] + fill[k]] = bs; ++fill[k]; }
+            });
+        o->col_off.push_back(0);
+        for (size_t k = 0; k < span; ++k)
+            if (depth[k]) { o->pos.push_back(lo + (int64_t)k); o->col_off.push_back(at[k + 1]); }
+        for (const Record& r : recs) o->reads.add(r, LGIO_NAMES);
+    } else {
+        o->col_off.push_back(0);
+    }
+    o->reads.view(&out->reads);
+    out->reads.owner_ = nullptr;                    // owned by the pile-up
+    out->n_cols = o->pos.size();
+    out->pos = o->pos.data(); out->col_off = o->col_off.data(); out->read = o->read.data(); out->base = o->base.data();
+    out->owner_ = o;
+    return LGIO_OK;
+}

@@ -167,25 +167,36 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     LGMI_OPS(Q, CUR, 3) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                                 \
     LGMI_OPS(P, NXT, 0) LGMI_MFMA16(Q) LGMI_SLOT_END(3)
 
+    // Ring of five raw-word buffers: step s computes on ring[s % 5], prepares bit 0 of ring[(s + 1) % 5] and loads
+    // step s + 4 into ring[(s + 4) % 5] — a load has ~3.7 steps (~3.5 us) to land.  With one wave per SIMD nothing else
+    // hides memory latency: a three-buffer ring (1.7 steps) left the matrix pipe waiting on s_waitcnt (95 ms against
+    // 81 ms for the same kernel without loads, tools/abl_mfma.sh).
     const uint32_t n_words = t.k1 - 4u * t0;
-    const uint32_t n_trip = (n_words + 11u) / 12u;        // steps go three at a time; steps past the block's words hold zeros
-    Raw ra, rb, rc;
+    const uint32_t n_trip = (n_words + 19u) / 20u;        // steps go five at a time; steps past the block's words hold zeros
+    Raw ra, rb, rc, rd, re;
 #if LGMI_ABL & 4
-    LGMI_LOAD2(rc.x[0], rc.x[1], cx0, 2u) LGMI_LOAD2(rc.x[2], rc.x[3], cx1, 2u)
-    LGMI_LOAD2(rc.y[0], rc.y[1], cy0, 2u) LGMI_LOAD2(rc.y[2], rc.y[3], cy1, 2u)
+    LGMI_LOAD2(re.x[0], re.x[1], cx0, 4u) LGMI_LOAD2(re.x[2], re.x[3], cx1, 4u)
+    LGMI_LOAD2(re.y[0], re.y[1], cy0, 4u) LGMI_LOAD2(re.y[2], re.y[3], cy1, 4u)
 #endif
     Ops P, Q;
     uint32_t st = 0u;                                     // current step, relative to t0
-    LGMI_LOAD2(ra.x[0], ra.x[1], cx0, 0u) LGMI_LOAD2(ra.x[2], ra.x[3], cx1, 0u)
-    LGMI_LOAD2(ra.y[0], ra.y[1], cy0, 0u) LGMI_LOAD2(ra.y[2], ra.y[3], cy1, 0u)
-    LGMI_LOAD2(rb.x[0], rb.x[1], cx0, 1u) LGMI_LOAD2(rb.x[2], rb.x[3], cx1, 1u)
-    LGMI_LOAD2(rb.y[0], rb.y[1], cy0, 1u) LGMI_LOAD2(rb.y[2], rb.y[3], cy1, 1u)
+#define LGMI_LOAD_ALL(R, ST)                                                                          \
+    LGMI_LOAD2(R.x[0], R.x[1], cx0, (ST)) LGMI_LOAD2(R.x[2], R.x[3], cx1, (ST))                         \
+    LGMI_LOAD2(R.y[0], R.y[1], cy0, (ST)) LGMI_LOAD2(R.y[2], R.y[3], cy1, (ST))
+    // the barriers keep the prologue's loads in ring order: the loop's s_waitcnt vmcnt(n) counts loads in issue order,
+    // and a prologue the compiler had regrouped by address made it wait for all but the newest 8 loads in every trip
+    LGMI_LOAD_ALL(ra, 0u) __builtin_amdgcn_sched_barrier(0);
+    LGMI_LOAD_ALL(rb, 1u) __builtin_amdgcn_sched_barrier(0);
+    LGMI_LOAD_ALL(rc, 2u) __builtin_amdgcn_sched_barrier(0);
+    LGMI_LOAD_ALL(rd, 3u) __builtin_amdgcn_sched_barrier(0);
     LGMI_OPS(P, ra, 0)
     for (uint32_t s = 0; s < n_trip; ++s) {
-        LGMI_STEP(ra, rb, rc, st + 2u)
-        LGMI_STEP(rb, rc, ra, st + 3u)
-        LGMI_STEP(rc, ra, rb, st + 4u)
-        st += 3u;
+        LGMI_STEP(ra, rb, re, st + 4u)
+        LGMI_STEP(rb, rc, ra, st + 5u)
+        LGMI_STEP(rc, rd, rb, st + 6u)
+        LGMI_STEP(rd, re, rc, st + 7u)
+        LGMI_STEP(re, ra, rd, st + 8u)
+        st += 5u;
     }
 
     // ---- epilogue: reg r of lane l is (x row (r&3) + 8 (r>>2) + 4 (l>>5), y col l&31) of its 32 x 32 tile

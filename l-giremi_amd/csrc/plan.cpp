@@ -213,7 +213,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
             BlockPlan& bp = pl.plans[b];
             const uint32_t gx = (bp.nx + 31u) / 32u, gy = (bp.ny + 31u) / 32u;
             const uint32_t words = (in.block_n_reads[b] + 63u) / 64u;
-            bp.op_steps = (words + 3u) / 4u + 8u;          // + the software pipeline's read-ahead past the last step
+            bp.op_steps = (words + 3u) / 4u + 12u;         // + the software pipeline's read-ahead past the last step (< 8 steps)
             needx.assign(gx, 0); needy.assign(gy, 0);
             for (; k < pl.mtiles.size() && pl.mtiles[k].block == b; ++k) {
                 const Tile& t = pl.mtiles[k];

@@ -71,22 +71,32 @@ def parse_args(argv=None):
 
 def get_footprints(sam, chromosomes, min_read_count=2):
     """[chromosome, start, end, read_count] of merged read intervals with enough reads
-    (src/giremi/footprint.py:6-50: sort by start, fuse while the next start <= the running end)"""
+    (src/giremi/footprint.py:6-50: sort by start, fuse while the next start <= the running end).
+    With the indexed reader the intervals come as two numpy arrays straight from the BAM records and the merge
+    is a running maximum — no per-read Python object."""
+    import numpy as np
     out = []
     for chrom in chromosomes:
         try:
-            spans = sorted(([r.reference_start, r.reference_end] for r in sam.fetch(chrom)), key=lambda iv: iv[0])
+            if hasattr(sam, 'intervals'):
+                starts, ends = sam.intervals(chrom)
+            else:
+                spans = [(r.reference_start, r.reference_end) for r in sam.fetch(chrom)]
+                starts = np.array([a for a, _b in spans], np.int64)
+                ends = np.array([b for _a, b in spans], np.int64)
         except (ValueError, KeyError):           # contig absent from the BAM
             continue
-        merged, counts = [], []
-        for lo, hi in spans:
-            if merged and lo <= merged[-1][1]:
-                merged[-1][1] = max(merged[-1][1], hi)
-                counts[-1] += 1
-            else:
-                merged.append([lo, hi])
-                counts.append(1)
-        out.extend([chrom, iv[0], iv[1], n] for iv, n in zip(merged, counts) if n >= min_read_count)
+        if len(starts) == 0:
+            continue
+        order = np.argsort(starts, kind='stable')
+        s, e = starts[order], ends[order]
+        reach = np.maximum.accumulate(e)
+        first = np.concatenate([[True], s[1:] > reach[:-1]])           # a read starting beyond everything before it
+        idx = np.nonzero(first)[0]
+        last = np.concatenate([idx[1:], [len(s)]]) - 1
+        for lo, hi, n in zip(s[idx].tolist(), reach[last].tolist(), (last - idx + 1).tolist()):
+            if n >= min_read_count:
+                out.append([chrom, lo, hi, n])
     return out
 
 

@@ -1,19 +1,19 @@
-"""Minimal sequence-file access for the l-giremi-compatible CLI.
+"""Sequence-file access for the l-giremi-compatible CLI.
 
-The reference opens its inputs with pysam (src/giremi/script/giremi.py:21-24); pysam/htslib are
-not installable in this environment, so this module provides small pure-Python stand-ins with the
-pysam attributes that the path actually touches (src/giremi/mismatch.py:69-190,
+The reference opens its inputs with pysam (src/giremi/script/giremi.py:21-24); pysam/htslib cannot be installed
+here, so this module provides the pysam attributes that the path actually touches (src/giremi/mismatch.py:69-190,
 src/giremi/footprint.py:6-28, src/giremi/fileio.py:24-30):
 
     BamReader   ~ pysam.AlignmentFile   fetch(), pileup(); reads expose query_name, reference_start,
-                                        reference_end, is_reverse, get_tag()
-    FastaReader ~ pysam.FastaFile       fetch(contig, start, end)
+                                        reference_end, is_reverse, get_tag() ...  A thin ctypes wrapper over
+                                        liblgmi_io.so (csrc/bamio.cpp, include/lgmi_io.h): streaming BGZF reader with
+                                        BAI random access — a region query inflates only the blocks its index chunks
+                                        point at, so memory follows the region, not the file.  Without a .bai the
+                                        index is built in memory by one pass; BamReader.build_index() writes a .bai.
+    FastaReader ~ pysam.FastaFile       fetch(contig, start, end); random access through a .fai (built in memory
+                                        from one pass over the file when absent), uncompressed FASTA
     VcfReader   ~ pysam.VariantFile     fetch(contig, start, end) -> records with .start (0-based)
     BamWriter                           BGZF writer, used to make synthetic BAMs for tests / benchmarks
-
-``open_alignment`` / ``open_fasta`` / ``open_variants`` return pysam objects when pysam is importable
-(real data, indexed random access) and these readers otherwise.  The readers load a whole file into
-memory: adequate for tests and modest inputs, not for a 100-GB BAM.
 
 Pile-up semantics follow pysam's defaults as far as this path depends on them: reads that are unmapped,
 secondary, QC-failed or duplicates are skipped (stepper 'samtools'), orphans of paired reads are skipped,
@@ -22,38 +22,160 @@ requested interval, and a read contributes an empty string where it has a deleti
 """
 from __future__ import annotations
 
+import ctypes as C
 import gzip
+import os
 import struct
 import zlib
 from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
 
 _SEQ = '=ACMGRSVTWYHKDBN'
 _CIGAR = 'MIDNSHP=X'
 _BAM_EOF = bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000')
 
+_HERE = os.path.dirname(os.path.abspath(__file__))
+IO_LIB_PATH = os.environ.get('LGMI_IO_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'liblgmi_io.so'))
+LGIO_NAMES, LGIO_CIGAR, LGIO_SEQ, LGIO_CS, LGIO_AUX, LGIO_ALL = 1, 2, 4, 8, 16, 31
 
-# ---------------------------------------------------------------------------------------------- BAM
+_u8p, _u16p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_i32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
+class _Reads(C.Structure):       # include/lgmi_io.h: lgio_reads
+    _fields_ = [('n', C.c_uint64), ('tid', _i32p), ('start', _i64p), ('end', _i64p), ('flag', _u16p), ('mapq', _u8p),
+                ('name_off', _u64p), ('names', C.c_void_p), ('cigar_off', _u64p), ('cigar', _u32p),
+                ('seq_off', _u64p), ('seq', C.c_void_p), ('qual', _u8p), ('cs_off', _u64p), ('cs', C.c_void_p),
+                ('has_cs', _u8p), ('aux_off', _u64p), ('aux', _u8p), ('owner_', C.c_void_p)]
+
+
+class _Pileup(C.Structure):      # lgio_pileup
+    _fields_ = [('n_cols', C.c_uint64), ('pos', _i64p), ('col_off', _u64p), ('read', _u32p), ('base', C.c_void_p),
+                ('reads', _Reads), ('owner_', C.c_void_p)]
+
+
+IO_SYMBOLS = {
+    'lgio_abi_version': (C.c_int, []),
+    'lgio_last_error': (C.c_char_p, []),
+    'lgio_bam_open': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    'lgio_bam_close': (None, [C.c_void_p]),
+    'lgio_bam_n_refs': (C.c_int, [C.c_void_p]),
+    'lgio_bam_ref_name': (C.c_char_p, [C.c_void_p, C.c_int]),
+    'lgio_bam_ref_length': (C.c_int64, [C.c_void_p, C.c_int]),
+    'lgio_bam_header_text': (C.c_char_p, [C.c_void_p]),
+    'lgio_bam_has_index_file': (C.c_int, [C.c_void_p]),
+    'lgio_bam_build_index': (C.c_int, [C.c_char_p, C.c_char_p]),
+    'lgio_bam_fetch': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(_Reads)]),
+    'lgio_reads_free': (None, [C.POINTER(_Reads)]),
+    'lgio_bam_pileup': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(_Pileup)]),
+    'lgio_pileup_free': (None, [C.POINTER(_Pileup)]),
+    'lgio_bam_bytes_read': (C.c_uint64, [C.c_void_p]),
+}
+_iolib = None
+
+
+def load_io():
+    global _iolib
+    if _iolib is None:
+        if not os.path.exists(IO_LIB_PATH):
+            raise RuntimeError('liblgmi_io.so not found at %s — build it with `make -C l-giremi_amd`' % IO_LIB_PATH)
+        lib = C.CDLL(IO_LIB_PATH)
+        for name, (res, args) in IO_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _iolib = lib
+    return _iolib
+
+
+def _check(rc):
+    if rc:
+        msg = load_io().lgio_last_error().decode('utf-8', 'replace')
+        raise (OSError if rc == -2 else ValueError)('liblgmi_io error %d: %s' % (rc, msg))
+
+
+def _arr(ptr, n, dt):
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+
+
+def _pool(addr, n):
+    return C.string_at(addr, n) if n and addr else b''
+
+
+class _ReadTable:
+    """numpy / bytes copies of an lgio_reads (the library's buffers are released right after the copy)"""
+
+    def __init__(self, rs: _Reads, references):
+        n = int(rs.n)
+        self.n, self.references = n, references
+        self.tid, self.start, self.end = _arr(rs.tid, n, np.int32), _arr(rs.start, n, np.int64), _arr(rs.end, n, np.int64)
+        self.flag, self.mapq = _arr(rs.flag, n, np.uint16), _arr(rs.mapq, n, np.uint8)
+        self.name_off = _arr(rs.name_off, n + 1, np.int64)
+        self.names = _pool(rs.names, int(self.name_off[-1]))
+        self.cigar_off = _arr(rs.cigar_off, n + 1, np.int64)
+        self.cigar = _arr(rs.cigar, int(self.cigar_off[-1]), np.uint32)
+        self.seq_off = _arr(rs.seq_off, n + 1, np.int64)
+        self.seq = _pool(rs.seq, int(self.seq_off[-1]))
+        self.qual = bytes(_arr(rs.qual, int(self.seq_off[-1]) if rs.qual else 0, np.uint8))
+        self.cs_off = _arr(rs.cs_off, n + 1, np.int64)
+        self.cs = _pool(rs.cs, int(self.cs_off[-1]))
+        self.has_cs = _arr(rs.has_cs, n, np.uint8)
+        self.aux_off = _arr(rs.aux_off, n + 1, np.int64)
+        self.aux = bytes(_arr(rs.aux, int(self.aux_off[-1]), np.uint8))
+
+    def name(self, k):
+        return self.names[self.name_off[k]:self.name_off[k + 1]].decode()
+
+
 class BamRead:
-    __slots__ = ('query_name', 'flag', 'reference_id', 'reference_name', 'reference_start', 'mapping_quality',
-                 'cigartuples', 'query_sequence', 'query_qualities', 'tags', 'reference_end')
+    """one alignment of a fetched table, with pysam's attribute names"""
+    __slots__ = ('_t', '_k', '_tags')
+
+    def __init__(self, table: _ReadTable, k: int):
+        self._t, self._k, self._tags = table, k, None
+
+    query_name = property(lambda self: self._t.name(self._k))
+    flag = property(lambda self: int(self._t.flag[self._k]))
+    reference_id = property(lambda self: int(self._t.tid[self._k]))
+    reference_name = property(lambda self: self._t.references[int(self._t.tid[self._k])])
+    reference_start = property(lambda self: int(self._t.start[self._k]))
+    reference_end = property(lambda self: int(self._t.end[self._k]))
+    mapping_quality = property(lambda self: int(self._t.mapq[self._k]))
+    is_reverse = property(lambda self: bool(self._t.flag[self._k] & 16))
+    is_unmapped = property(lambda self: bool(self._t.flag[self._k] & 4))
 
     @property
-    def is_reverse(self):
-        return bool(self.flag & 16)
-
-    @property
-    def is_unmapped(self):
-        return bool(self.flag & 4)
+    def cigartuples(self):
+        c = self._t.cigar[self._t.cigar_off[self._k]:self._t.cigar_off[self._k + 1]]
+        return [(int(v & 0xF), int(v >> 4)) for v in c]
 
     @property
     def cigarstring(self):
         return ''.join('%d%s' % (n, _CIGAR[op]) for op, n in self.cigartuples)
 
+    @property
+    def query_sequence(self):
+        return self._t.seq[self._t.seq_off[self._k]:self._t.seq_off[self._k + 1]].decode()
+
+    @property
+    def query_qualities(self):
+        return self._t.qual[self._t.seq_off[self._k]:self._t.seq_off[self._k + 1]]
+
+    @property
+    def tags(self):
+        if self._tags is None:
+            self._tags = _parse_tags(self._t.aux[self._t.aux_off[self._k]:self._t.aux_off[self._k + 1]])
+            if self._t.has_cs[self._k] and 'cs' not in self._tags:
+                self._tags['cs'] = self._t.cs[self._t.cs_off[self._k]:self._t.cs_off[self._k + 1]].decode()
+        return self._tags
+
     def get_tag(self, name):
-        return self.tags[name]            # KeyError like pysam
+        if name == 'cs' and self._t.has_cs[self._k]:         # the hot one (mismatch.py:76): no aux parsing
+            return self._t.cs[self._t.cs_off[self._k]:self._t.cs_off[self._k + 1]].decode()
+        return self.tags[name]                                # KeyError like pysam
 
     def has_tag(self, name):
-        return name in self.tags
+        return (name == 'cs' and bool(self._t.has_cs[self._k])) or name in self.tags
 
     def aligned_pairs(self) -> Iterator[Tuple[int, Optional[int]]]:
         """(reference position, query index or None for deletion / reference skip) over the reference span"""
@@ -96,72 +218,90 @@ def _parse_tags(buf: bytes) -> Dict[str, object]:
 
 
 class BamReader:
+    """pysam.AlignmentFile stand-in on liblgmi_io.so: indexed, streaming (see the module docstring)"""
+
     def __init__(self, path: str):
-        with gzip.open(path, 'rb') as f:      # BGZF is a series of gzip members
-            data = f.read()
-        if data[:4] != b'BAM\1':
-            raise ValueError('%s is not a BAM file' % path)
-        l_text = struct.unpack_from('<i', data, 4)[0]
-        self.header_text = data[8:8 + l_text].decode(errors='replace')
-        at = 8 + l_text
-        n_ref = struct.unpack_from('<i', data, at)[0]; at += 4
-        self.references, self.lengths = [], []
-        for _ in range(n_ref):
-            ln = struct.unpack_from('<i', data, at)[0]; at += 4
-            self.references.append(data[at:at + ln - 1].decode()); at += ln
-            self.lengths.append(struct.unpack_from('<i', data, at)[0]); at += 4
-        self._by_ref: Dict[str, List[BamRead]] = {r: [] for r in self.references}
-        while at + 4 <= len(data):
-            block = struct.unpack_from('<i', data, at)[0]; at += 4
-            rec = data[at:at + block]; at += block
-            (ref_id, pos, l_name, mapq, _bin, n_cig, flag, l_seq, _nref, _npos, _tlen) = struct.unpack_from('<iiBBHHHiiii', rec, 0)
-            r = BamRead()
-            p = 32
-            r.query_name = rec[p:p + l_name - 1].decode(); p += l_name
-            cig = struct.unpack_from('<%dI' % n_cig, rec, p); p += 4 * n_cig
-            r.cigartuples = [(c & 0xF, c >> 4) for c in cig]
-            nb = (l_seq + 1) // 2
-            packed = rec[p:p + nb]; p += nb
-            r.query_sequence = ''.join(_SEQ[b >> 4] + _SEQ[b & 0xF] for b in packed)[:l_seq]
-            r.query_qualities = rec[p:p + l_seq]; p += l_seq
-            r.tags = _parse_tags(rec[p:])
-            r.flag, r.reference_id, r.reference_start, r.mapping_quality = flag, ref_id, pos, mapq
-            r.reference_name = self.references[ref_id] if ref_id >= 0 else None
-            r.reference_end = pos + sum(n for op, n in r.cigartuples if op in (0, 2, 3, 7, 8))
-            if ref_id >= 0:
-                self._by_ref[r.reference_name].append(r)
+        self._lib = load_io()
+        h = C.c_void_p()
+        _check(self._lib.lgio_bam_open(os.fsencode(path), C.byref(h)))
+        self._h, self.path = h, path
+        n = self._lib.lgio_bam_n_refs(h)
+        self.references = [self._lib.lgio_bam_ref_name(h, k).decode() for k in range(n)]
+        self.lengths = [int(self._lib.lgio_bam_ref_length(h, k)) for k in range(n)]
+        self.header_text = (self._lib.lgio_bam_header_text(h) or b'').decode(errors='replace')
+        self._tid = {r: k for k, r in enumerate(self.references)}
+
+    @staticmethod
+    def build_index(path: str, bai_path: Optional[str] = None):
+        """one streaming pass -> standard .bai next to the BAM"""
+        _check(load_io().lgio_bam_build_index(os.fsencode(path), os.fsencode(bai_path) if bai_path else None))
+
+    @property
+    def has_index_file(self):
+        return bool(self._lib.lgio_bam_has_index_file(self._h))
+
+    @property
+    def bytes_read(self):
+        return int(self._lib.lgio_bam_bytes_read(self._h))
 
     def close(self):
-        pass
+        if self._h:
+            self._lib.lgio_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _table(self, contig, start, stop, what) -> Optional[_ReadTable]:
+        tid = self._tid.get(contig)
+        if tid is None:
+            return None
+        rs = _Reads()
+        _check(self._lib.lgio_bam_fetch(self._h, tid, -1 if start is None else int(start), 0 if stop is None else int(stop),
+                                        what, C.byref(rs)))
+        try:
+            return _ReadTable(rs, self.references)
+        finally:
+            self._lib.lgio_reads_free(C.byref(rs))
+
+    def intervals(self, contig):
+        """(starts, ends) of the mapped reads of a contig as numpy arrays — what the footprint merge needs, without
+        materialising names, sequences or tags (src/giremi/footprint.py:6-28)"""
+        t = self._table(contig, None, None, 0)
+        if t is None:
+            raise KeyError(contig)
+        return t.start, t.end
 
     def fetch(self, contig=None, start=None, stop=None):
-        for r in self._by_ref.get(contig, []):
-            if r.is_unmapped:
-                continue
-            if start is None or (r.reference_end > start and r.reference_start < stop):
-                yield r
+        t = self._table(contig, start, stop, LGIO_ALL)
+        for k in range(t.n if t is not None else 0):
+            yield BamRead(t, k)
 
     def pileup(self, contig=None, start=None, stop=None, min_base_quality=13, max_depth=8000):
-        cols: Dict[int, Tuple[List[str], List[str]]] = {}
-        for r in self.fetch(contig, start, stop):
-            if r.flag & (4 | 256 | 512 | 1024):                    # unmapped, secondary, qc-fail, duplicate
-                continue
-            if (r.flag & 1) and not (r.flag & 2):                  # orphan of a paired read
-                continue
-            seq, qual = r.query_sequence, r.query_qualities
-            for ref_pos, q in r.aligned_pairs():
-                if q is None:
-                    base = ''
-                else:
-                    if qual and qual[q] != 0xFF and qual[q] < min_base_quality:
-                        continue
-                    base = seq[q]
-                names, bases = cols.setdefault(ref_pos, ([], []))
-                if len(names) < max_depth:
-                    names.append(r.query_name)
-                    bases.append(base)
-        for pos in sorted(cols):
-            yield PileupColumn(pos, *cols[pos])
+        tid = self._tid.get(contig)
+        if tid is None:
+            return
+        pl = _Pileup()
+        _check(self._lib.lgio_bam_pileup(self._h, tid, -1 if start is None else int(start), 0 if stop is None else int(stop),
+                                         int(min_base_quality), int(max_depth), C.byref(pl)))
+        try:
+            nc = int(pl.n_cols)
+            pos, off = _arr(pl.pos, nc, np.int64), _arr(pl.col_off, nc + 1, np.int64)
+            ridx = _arr(pl.read, int(off[-1]) if nc else 0, np.int64)
+            base = _pool(pl.base, int(off[-1]) if nc else 0)
+            nr = int(pl.reads.n)
+            noff = _arr(pl.reads.name_off, nr + 1, np.int64)
+            pool = _pool(pl.reads.names, int(noff[-1]) if nr else 0)
+            names = [pool[noff[k]:noff[k + 1]].decode() for k in range(nr)]
+        finally:
+            self._lib.lgio_pileup_free(C.byref(pl))
+        for c in range(nc):
+            a, b = int(off[c]), int(off[c + 1])
+            yield PileupColumn(int(pos[c]), [names[r] for r in ridx[a:b]],
+                               [chr(x) if x else '' for x in base[a:b]])
 
 
 class PileupColumn:
@@ -187,8 +327,8 @@ def _bgzf_block(payload: bytes) -> bytes:
 class BamWriter:
     """writes coordinate-sorted, single-end, mapped records with a cs:Z tag (what minimap2 --cs emits)"""
 
-    def __init__(self, path: str, references: List[Tuple[str, int]]):
-        self.path, self.references = path, list(references)
+    def __init__(self, path: str, references: List[Tuple[str, int]], index: bool = True):
+        self.path, self.references, self.index = path, list(references), index
         self._ids = {name: k for k, (name, _l) in enumerate(self.references)}
         text = '@HD\tVN:1.6\tSO:coordinate\n' + ''.join('@SQ\tSN:%s\tLN:%d\n' % r for r in self.references)
         self._buf = bytearray(b'BAM\1' + struct.pack('<i', len(text)) + text.encode() + struct.pack('<i', len(self.references)))
@@ -196,7 +336,8 @@ class BamWriter:
             self._buf += struct.pack('<i', len(name) + 1) + name.encode() + b'\0' + struct.pack('<i', ln)
 
     def write(self, contig: str, start: int, name: str, is_reverse: bool, cigartuples, sequence: str, cs: str,
-              mapq: int = 60, quality: int = 40):
+              mapq: int = 60, quality=40, flag: int = 0):
+        """quality: one phred value for every base, or a sequence of per-base values; flag: extra SAM flag bits"""
         code = {c: k for k, c in enumerate(_SEQ)}
         seq = sequence.upper()
         packed = bytearray()
@@ -208,8 +349,9 @@ class BamWriter:
         tags = b'csZ' + cs.encode() + b'\0'
         end = start + sum(n for op, n in cigartuples if op in (0, 2, 3, 7, 8))
         core = struct.pack('<iiBBHHHiiii', self._ids[contig], start, len(name) + 1, mapq, _reg2bin(start, end),
-                           len(cigartuples), 16 if is_reverse else 0, len(seq), -1, -1, 0)
-        rec = core + name.encode() + b'\0' + cig + bytes(packed) + bytes([quality]) * len(seq) + tags
+                           len(cigartuples), (16 if is_reverse else 0) | flag, len(seq), -1, -1, 0)
+        quals = bytes([quality]) * len(seq) if isinstance(quality, int) else bytes(quality)
+        rec = core + name.encode() + b'\0' + cig + bytes(packed) + quals + tags
         self._buf += struct.pack('<i', len(rec)) + rec
 
     def close(self):
@@ -218,6 +360,8 @@ class BamWriter:
             for k in range(0, len(data), 60000):
                 f.write(_bgzf_block(data[k:k + 60000]))
             f.write(_BAM_EOF)
+        if self.index:
+            BamReader.build_index(self.path)
 
 
 def _reg2bin(beg: int, end: int) -> int:
@@ -230,28 +374,78 @@ def _reg2bin(beg: int, end: int) -> int:
 
 # ---------------------------------------------------------------------------------------------- FASTA / VCF / repeats
 class FastaReader:
+    """pysam.FastaFile stand-in: random access through the .fai (name, length, offset, bases per line, bytes per
+    line); the index is built in memory by one pass over the file when there is no .fai next to it.  gzip input
+    is read whole (no random access into plain gzip)."""
+
     def __init__(self, path: str):
-        self._seq: Dict[str, str] = {}
-        opener = gzip.open if path.endswith('.gz') else open
-        name, parts = None, []
-        with opener(path, 'rt') as f:
+        self.path = path
+        self._fai: Dict[str, Tuple[int, int, int, int]] = {}
+        self._seq: Optional[Dict[str, str]] = None
+        if path.endswith('.gz'):
+            self._seq = {}
+            name, parts = None, []
+            with gzip.open(path, 'rt') as f:
+                for line in f:
+                    if line.startswith('>'):
+                        if name is not None:
+                            self._seq[name] = ''.join(parts)
+                        name, parts = line[1:].split()[0], []
+                    else:
+                        parts.append(line.strip())
+            if name is not None:
+                self._seq[name] = ''.join(parts)
+            self.references = list(self._seq)
+            self._f = None
+            return
+        if os.path.exists(path + '.fai'):
+            with open(path + '.fai') as f:
+                for line in f:
+                    c = line.rstrip('\n').split('\t')
+                    if len(c) >= 5:
+                        self._fai[c[0]] = (int(c[1]), int(c[2]), int(c[3]), int(c[4]))
+        else:
+            self._fai = self._scan(path)
+        self.references = list(self._fai)
+        self._f = open(path, 'rb')
+
+    @staticmethod
+    def _scan(path):
+        fai, name, length, offset, lb, lw, at = {}, None, 0, 0, 0, 0, 0
+        with open(path, 'rb') as f:
             for line in f:
-                if line.startswith('>'):
+                if line.startswith(b'>'):
                     if name is not None:
-                        self._seq[name] = ''.join(parts)
-                    name, parts = line[1:].split()[0], []
+                        fai[name] = (length, offset, lb, lw)
+                    name, length, offset, lb, lw = line[1:].split()[0].decode(), 0, at + len(line), 0, 0
                 else:
-                    parts.append(line.strip())
+                    body = line.rstrip(b'\r\n')
+                    if lb == 0 and body:
+                        lb, lw = len(body), len(line)
+                    length += len(body)
+                at += len(line)
         if name is not None:
-            self._seq[name] = ''.join(parts)
-        self.references = list(self._seq)
+            fai[name] = (length, offset, lb, lw)
+        return fai
 
     def fetch(self, contig, start=None, end=None):
-        s = self._seq[contig]
-        return s if start is None else s[max(start, 0):end]
+        if self._seq is not None:
+            s = self._seq[contig]
+            return s if start is None else s[max(start, 0):end]
+        length, offset, lb, lw = self._fai[contig]
+        a = 0 if start is None else max(int(start), 0)
+        b = length if end is None else min(int(end), length)
+        if a >= b or lb == 0:
+            return ''
+        first = offset + (a // lb) * lw + a % lb
+        last = offset + ((b - 1) // lb) * lw + (b - 1) % lb + 1
+        self._f.seek(first)
+        return self._f.read(last - first).replace(b'\n', b'').replace(b'\r', b'').decode()
 
     def close(self):
-        pass
+        if getattr(self, '_f', None):
+            self._f.close()
+            self._f = None
 
 
 class _VcfRecord:
@@ -289,24 +483,12 @@ class VcfReader:
 
 
 def open_alignment(path):
-    try:
-        import pysam
-        return pysam.AlignmentFile(path, 'rb')
-    except ImportError:
-        return BamReader(path)
+    return BamReader(path)
 
 
 def open_fasta(path):
-    try:
-        import pysam
-        return pysam.FastaFile(path)
-    except ImportError:
-        return FastaReader(path)
+    return FastaReader(path)
 
 
 def open_variants(path):
-    try:
-        import pysam
-        return pysam.VariantFile(path)
-    except ImportError:
-        return VcfReader(path)
+    return VcfReader(path)

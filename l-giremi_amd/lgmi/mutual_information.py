@@ -85,18 +85,23 @@ def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: O
             raise IndexError('list index out of range')
     bsb = batch.block_site_begin.astype(np.int64)
     pos, names = batch.site_pos.tolist(), batch.type_names
-    row_block = np.searchsorted(bsb, res.row_i.astype(np.int64), side='right') - 1
+    # rows come sorted by block: one slice per block instead of a Python step per row
+    cut = np.searchsorted(res.row_i.astype(np.int64), bsb, side='left')
     ri, rj, rmi = res.row_i.tolist(), res.row_j.tolist(), res.row_mi.tolist()
     rp = res.row_p.tolist() if n_shuffles else None
-    for k, b in enumerate(row_block.tolist()):
+    for b in range(len(bsb) - 1):
+        r0, r1 = int(cut[b]), int(cut[b + 1])
+        if r0 == r1:
+            continue
         records, _means, pvals = out[b >> 1]
-        i, j = ri[k], rj[k]
-        records.append([regions[b >> 1][1], strands[b & 1], pos[i], names[i], pos[j], names[j], rmi[k]])
+        chrom, strand = regions[b >> 1][1], strands[b & 1]
+        records.extend([chrom, strand, pos[i], names[i], pos[j], names[j], m]
+                       for i, j, m in zip(ri[r0:r1], rj[r0:r1], rmi[r0:r1]))
         if pvals is not None:
-            pvals.append(rp[k])
+            pvals.extend(rp[r0:r1])
     npairs, mean = res.site_n_pairs, res.site_mean_mi
-    for s in np.nonzero(npairs)[0].tolist():
-        b = int(np.searchsorted(bsb, s, side='right') - 1)
+    hit = np.nonzero(npairs)[0]
+    for s, b in zip(hit.tolist(), (np.searchsorted(bsb, hit, side='right') - 1).tolist()):
         out[b >> 1][1][strands[b & 1]][pos[s]] = float(mean[s])
     return out
 

@@ -83,66 +83,85 @@ def concat_batches(parts: Sequence['PackedBatch']) -> 'PackedBatch':
                        np.concatenate([p.bad_sites if p.bad_sites is not None else np.zeros(p.n_sites, bool) for p in parts]))
 
 
-def _site_classes(site: dict, read_index: Dict[str, int]):
-    """(read indices, classes) of one site; new read names get the next index."""
-    read_allele: Dict[str, str] = {}
-    for allele, names in site['nt'].items():
-        for name in names:
-            read_allele[name] = allele                      # last allele wins (:15-16)
-    ranked = sorted(site['depth'].items(), key=lambda kv: kv[1], reverse=True)   # stable (:27-28)
-    bad = len(ranked) < 2                                   # the reference raises IndexError (:30,:32)
-    major = ranked[0][0] if ranked else None
-    minor = ranked[1][0] if len(ranked) > 1 else None
-    idx = np.empty(len(read_allele), np.int64)
-    cls = np.empty(len(read_allele), np.uint8)
-    for k, (name, allele) in enumerate(read_allele.items()):
-        r = read_index.get(name)
-        if r is None:
-            r = len(read_index)
-            read_index[name] = r
-        idx[k] = r
-        cls[k] = 2 if allele == major else (1 if allele == minor else 0)
-    return idx, cls, bad
+def _or_scatter(planes: np.ndarray, target: np.ndarray, bits: np.ndarray):
+    """planes[target] |= bits for a SORTED target array: equal targets form runs, one bitwise_or.reduceat folds them"""
+    if target.size == 0:
+        return
+    starts = np.flatnonzero(np.concatenate(([True], target[1:] != target[:-1])))
+    planes[target[starts]] = np.bitwise_or.reduceat(bits, starts)
+
+
+def _pack_one(mismatches: dict):
+    """one block, vectorised: the only per-read Python work is list.extend of the name lists; read numbering,
+    duplicate handling, band limits and the two bit planes are array operations.
+    -> (pos, type names, bad flags, n_reads, word_off, n_words, planes of the block, plane offsets inside it)"""
+    positions = sorted(mismatches.keys())
+    P = len(positions)
+    names_flat: List[str] = []
+    run_len, run_site, run_cls, type_names = [], [], [], []
+    bad = np.zeros(P, bool)
+    for si, p in enumerate(positions):
+        site = mismatches[p]
+        type_names.append(site['type'])
+        ranked = sorted(site['depth'].items(), key=lambda kv: kv[1], reverse=True)   # stable (:27-28)
+        bad[si] = len(ranked) < 2                               # the reference raises IndexError (:30,:32)
+        major = ranked[0][0] if ranked else None
+        minor = ranked[1][0] if len(ranked) > 1 else None
+        for allele, names in site['nt'].items():
+            names_flat.extend(names)
+            run_len.append(len(names))
+            run_site.append(si)
+            run_cls.append(2 if allele == major else (1 if allele == minor else 0))
+    pos = np.asarray(positions, np.int64)
+    n = len(names_flat)
+    if n == 0:
+        z = np.zeros(P, np.int64)
+        return pos, type_names, bad, 0, z, z, np.zeros(0, np.uint64), z
+    # reads are numbered in order of first appearance (sites by position, alleles in `nt` order): what factorize does
+    import pandas as pd
+    code, uniques = pd.factorize(np.asarray(names_flat, dtype=object))
+    R = len(uniques)
+    site_of = np.repeat(np.asarray(run_site, np.int64), run_len)
+    cls_of = np.repeat(np.asarray(run_cls, np.uint8), run_len)
+    # a read listed under several alleles of a site keeps the LAST one (:15-16): first occurrence in reversed order
+    key = site_of * R + code.astype(np.int64)
+    ukey, ridx = np.unique(key[::-1], return_index=True)        # sorted by (site, read)
+    cls_u = cls_of[n - 1 - ridx]
+    site_u, read_u = ukey // R, ukey % R
+    word = read_u >> 6
+    first = np.searchsorted(site_u, np.arange(P), side='left')
+    last = np.searchsorted(site_u, np.arange(P), side='right')
+    has = last > first
+    # reads of a site are NOT sorted by index inside ukey?  they are: ukey is sorted and site-major, so read_u increases
+    w0 = np.where(has, word[np.minimum(first, len(word) - 1)], 0)
+    w1 = np.where(has, word[np.maximum(last - 1, 0)] + 1, 0)
+    nw = w1 - w0
+    poff = 2 * (np.cumsum(nw) - nw)
+    planes = np.zeros(int(2 * nw.sum()), np.uint64)
+    bit = np.left_shift(np.uint64(1), (read_u & 63).astype(np.uint64))
+    lo_at = poff[site_u] + (word - w0[site_u])
+    m_lo, m_hi = cls_u != 2, cls_u != 1                          # class 1 and class 0 set lo; class 2 and class 0 set hi
+    _or_scatter(planes, lo_at[m_lo], bit[m_lo])
+    _or_scatter(planes, (lo_at + nw[site_u])[m_hi], bit[m_hi])
+    return pos, type_names, bad, R, w0, nw, planes, poff
 
 
 def pack_blocks(blocks: Sequence[dict]) -> PackedBatch:
     """one block per ``mismatches[strand]`` dict (positions -> site dict)."""
-    bsb = [0]
-    n_reads, pos, typ, names, woff, nwords, poff, chunks, bad = [], [], [], [], [], [], [], [], []
+    bsb, n_reads, pos, names, woff, nwords, poff, chunks, bad = [0], [], [], [], [], [], [], [], []
     total = 0
-    one = np.uint64(1)
     for mismatches in blocks:
-        read_index: Dict[str, int] = {}
-        for p in sorted(mismatches.keys()):
-            site = mismatches[p]
-            idx, cls, is_bad = _site_classes(site, read_index)
-            if idx.size:
-                w0, w1 = int(idx.min()) >> 6, (int(idx.max()) >> 6) + 1
-            else:
-                w0, w1 = 0, 0
-            nw = w1 - w0
-            lo = np.zeros(nw, np.uint64)
-            hi = np.zeros(nw, np.uint64)
-            if idx.size:
-                word = (idx >> 6) - w0
-                bit = np.left_shift(one, (idx & 63).astype(np.uint64))
-                np.bitwise_or.at(lo, word[cls != 2], bit[cls != 2])   # class 1 and class 0 set lo
-                np.bitwise_or.at(hi, word[cls != 1], bit[cls != 1])   # class 2 and class 0 set hi
-            pos.append(int(p))
-            t = site['type']
-            names.append(t)
-            typ.append(TYPE_CODE.get(t, _lib.TYPE_MISMATCH))
-            woff.append(w0)
-            nwords.append(nw)
-            poff.append(total)
-            chunks.append(lo)
-            chunks.append(hi)
-            total += 2 * nw
-            bad.append(is_bad)
-        bsb.append(len(pos))
-        n_reads.append(len(read_index))
-    planes = np.concatenate(chunks) if chunks else np.zeros(0, np.uint64)
-    return PackedBatch(np.asarray(bsb, np.uint64), np.asarray(n_reads, np.uint32), np.asarray(pos, np.int64),
-                       np.asarray(typ, np.uint8), np.asarray(woff, np.uint32), np.asarray(nwords, np.uint32),
-                       np.asarray(poff, np.uint64), np.ascontiguousarray(planes, np.uint64), names,
-                       np.asarray(bad, bool))
+        p, tn, b, R, w0, nw, planes, po = _pack_one(mismatches)
+        pos.append(p); names.extend(tn); bad.append(b); woff.append(w0); nwords.append(nw)
+        poff.append(po + total)
+        chunks.append(planes)
+        total += planes.size
+        bsb.append(bsb[-1] + len(p))
+        n_reads.append(R)
+
+    def cat(parts, dt):
+        return np.concatenate(parts).astype(dt) if parts else np.zeros(0, dt)
+    typ = np.asarray([TYPE_CODE.get(t, _lib.TYPE_MISMATCH) for t in names], np.uint8)
+    return PackedBatch(np.asarray(bsb, np.uint64), np.asarray(n_reads, np.uint32), cat(pos, np.int64), typ,
+                       cat(woff, np.uint32), cat(nwords, np.uint32), cat(poff, np.uint64),
+                       np.ascontiguousarray(cat(chunks, np.uint64)), names, cat(bad, bool))

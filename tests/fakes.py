@@ -53,6 +53,26 @@ class FakeSam:
             yield FakeColumn(pos, cols[pos][0], cols[pos][1])
 
 
+class FakeSamSkips(FakeSam):
+    """pile-up as pysam produces it on a real BAM with default arguments: a read that has a reference skip (intron)
+    at a column is listed there with an EMPTY base string, and columns are not truncated to [start, stop) — the two
+    pysam behaviours the path's look-ups depend on (mismatch.py:160-190).  Used to run the REFERENCE on exactly what
+    the CLI's BAM reader hands over for the same reads."""
+
+    def pileup(self, contig=None, start=None, stop=None):
+        cols = {}
+        for r in self.reads:
+            if not (r.reference_end > start and r.reference_start < stop):
+                continue
+            aligned = dict(r._blocks)
+            for pos in range(r.reference_start, r.reference_end):
+                cols.setdefault(pos, ([], []))
+                cols[pos][0].append(r.query_name)
+                cols[pos][1].append(aligned.get(pos, ''))
+        for pos in sorted(cols):
+            yield FakeColumn(pos, cols[pos][0], cols[pos][1])
+
+
 class FakeGenome:
     def __init__(self, seq):
         self.seq = seq

@@ -331,6 +331,34 @@ def region_cases():
     return out
 
 
+# the two contigs of the CLI end-to-end test (tests/test_cli.py: regions_fixture) — name, simulate_region kwargs
+CLI_REGIONS = [('chrA', dict(seed=200, n_reads=70)), ('chrB', dict(seed=201, n_reads=100))]
+# the CLI's defaults (src/giremi/script/giremi.py:140-321 as passed on at :62-81)
+CLI_KWARGS = dict(keep_non_spliced_read=False, min_dist_from_splice=4, min_allele_depth=3, min_allele_ratio=0.05,
+                  min_total_depth=2, homopoly_length=5, min_het_snp_ratio=0.35, max_het_snp_ratio=0.65,
+                  mismatch_window_size=100, max_window_mismatch=10, max_window_mismatch_type=3, min_common_reads=6,
+                  mode='cs', read_strand_dict=None)
+
+
+def cli_cases():
+    """what the reference's footprint_bulk_calculation (script/giremi.py:20-93) computes for the CLI test's two
+    footprints: region_mismatch_analysis with the CLI's defaults, on a pysam-like view of the same reads (pile-up
+    with empty strings inside introns, untruncated columns; footprint = [first read start, last read end))"""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from fakes import FakeGenome, FakeSamSkips, simulate_region
+    ref_mm = load_ref_mismatch()
+    out = []
+    for contig, sim_kw in CLI_REGIONS:
+        reads, genome, snps, _ = simulate_region(**sim_kw)
+        lo, hi = min(r.reference_start for r in reads), max(r.reference_end for r in reads)
+        snp_in = sorted(p for p in snps if lo <= p < hi)
+        dfs = ref_mm.region_mismatch_analysis(contig, lo, hi, FakeSamSkips(reads), FakeGenome(genome),
+                                              simple_repeat_intervals=[], snp_positions=snp_in, **CLI_KWARGS)
+        out.append({'contig': contig, 'sim': sim_kw, 'footprint': [lo, hi], 'pair_mi': frame_json(dfs[1]),
+                    'removed': frame_json(dfs[2]), 'mismatch': frame_json(dfs[0])})
+    return out
+
+
 def splice_tables(seed, n_reads, n_sites, n_splice, dup=False):
     """synthetic read-site / read-splice tables for calculate_site_splice_mi.py"""
     import pandas as pd
@@ -387,6 +415,10 @@ def main():
     import scipy
     meta = {'reference': 'gxiaolab/L-GIREMI v0.2.4 imported by file path',
             'sklearn': sklearn.__version__, 'numpy': np.__version__, 'scipy': scipy.__version__}
+    if '--only-cli' in sys.argv:        # added in round 2: leaves the round-1 fixtures byte-for-byte as they are
+        with open(os.path.join(HERE, 'cli.json'), 'w') as f:
+            json.dump({'meta': meta, 'cases': cli_cases()}, f)
+        return
     with open(os.path.join(HERE, 'pairs_edge.json'), 'w') as f:
         json.dump({'meta': meta, 'cases': edge_cases()}, f)
     with open(os.path.join(HERE, 'pairs_random.json'), 'w') as f:
@@ -400,6 +432,8 @@ def main():
         json.dump({'meta': meta, 'cases': splice_cases()}, f)
     with open(os.path.join(HERE, 'region.json'), 'w') as f:
         json.dump({'meta': meta, 'cases': region_cases()}, f)
+    with open(os.path.join(HERE, 'cli.json'), 'w') as f:
+        json.dump({'meta': meta, 'cases': cli_cases()}, f)
     if '--time' in sys.argv:
         time_reference(os.path.join(HERE, 'reference_timing.json'))
 

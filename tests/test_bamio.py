@@ -1,0 +1,182 @@
+"""liblgmi_io.so (csrc/bamio.cpp): the streaming, indexed BAM reader behind the CLI — region queries against a
+brute-force scan of every record, the BAI written by the library against the format's own rules, pile-up filters
+(pysam defaults), and that a region query touches only a small part of the file."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from lgmi.io import BamReader, BamWriter, FastaReader
+
+
+def reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def make_bam(path, seed=3, n_reads=4000, length=3_000_000, index=True):
+    rng = np.random.default_rng(seed)
+    w = BamWriter(str(path), [('chr1', length), ('chrEmpty', 1000), ('chr2', length // 2)], index=index)
+    recs = []
+    for contig, ln, n in (('chr1', length, n_reads), ('chr2', length // 2, n_reads // 3)):
+        starts = np.sort(rng.integers(0, ln - 30_000, n))
+        for k, st in enumerate(starts.tolist()):
+            e1, intron, e2 = int(rng.integers(40, 400)), int(rng.integers(50, 20_000)), int(rng.integers(40, 400))
+            cig = [(0, e1), (3, intron), (0, e2)] if k % 3 else [(4, 5), (0, e1), (1, 2), (0, e2), (2, 3), (0, 7)]
+            qlen = sum(n_ for op, n_ in cig if op in (0, 1, 4))
+            seq = ''.join(rng.choice(list('ACGT'), qlen))
+            flag = [0, 0, 0, 256, 1024, 4][k % 6] if k % 50 == 0 else 0
+            name = '%s_r%05d' % (contig, k)
+            w.write(contig, st, name, bool(k & 1), cig, seq, ':%d' % qlen, quality=rng.integers(5, 41, qlen).astype(np.uint8),
+                    flag=flag)
+            end = st + sum(n_ for op, n_ in cig if op in (0, 2, 3))
+            recs.append((contig, st, end, name, flag, cig, seq))
+    w.close()
+    return recs
+
+
+def test_region_queries_match_a_full_scan(tmp_path):
+    recs = make_bam(tmp_path / 'a.bam')
+    rd = BamReader(str(tmp_path / 'a.bam'))
+    assert rd.has_index_file and rd.references == ['chr1', 'chrEmpty', 'chr2']
+    rng = np.random.default_rng(0)
+    for contig in ('chr1', 'chr2', 'chrEmpty'):
+        mine = [r for r in recs if r[0] == contig and not r[4] & 4]
+        got = list(rd.fetch(contig))
+        assert [g.query_name for g in got] == [r[3] for r in mine]
+        for _ in range(25):
+            a = int(rng.integers(0, 3_000_000))
+            b = a + int(rng.integers(1, 200_000))
+            exp = [r[3] for r in mine if r[2] > a and r[1] < b]
+            got = list(rd.fetch(contig, a, b))
+            assert [g.query_name for g in got] == exp
+            for g in got[:5]:
+                r = next(x for x in mine if x[3] == g.query_name)
+                assert (g.reference_start, g.reference_end, g.cigartuples, g.query_sequence) == (r[1], r[2], r[5], r[6])
+                assert g.get_tag('cs') == ':%d' % len(r[6]) and g.has_tag('cs') and not g.has_tag('NM')
+    assert list(rd.fetch('chrNone')) == []
+    starts, ends = rd.intervals('chr2')
+    assert starts.tolist() == [r[1] for r in recs if r[0] == 'chr2' and not r[4] & 4]
+    assert ends.tolist() == [r[2] for r in recs if r[0] == 'chr2' and not r[4] & 4]
+    with pytest.raises(KeyError):
+        rd.intervals('chrNone')
+
+
+def test_a_region_query_reads_a_small_part_of_the_file(tmp_path):
+    make_bam(tmp_path / 'b.bam', n_reads=20_000)
+    size = os.path.getsize(tmp_path / 'b.bam')
+    rd = BamReader(str(tmp_path / 'b.bam'))
+    before = rd.bytes_read                               # header + index file only: no scan
+    assert before < 0.05 * size
+    got = list(rd.fetch('chr1', 1_500_000, 1_520_000))
+    assert len(got) > 10
+    assert rd.bytes_read - before < 0.06 * size          # a few 64-KiB blocks, not the file
+
+
+def test_index_file_equals_in_memory_index_and_follows_the_format(tmp_path):
+    recs = make_bam(tmp_path / 'c.bam', n_reads=3000, index=False)
+    path = str(tmp_path / 'c.bam')
+    rd0 = BamReader(path)                                # no .bai: one streaming pass builds the index in memory
+    assert not rd0.has_index_file
+    BamReader.build_index(path)
+    rd1 = BamReader(path)
+    assert rd1.has_index_file
+    for a, b in ((0, 10_000), (700_000, 900_000), (2_900_000, 3_000_000)):
+        assert [g.query_name for g in rd0.fetch('chr1', a, b)] == [g.query_name for g in rd1.fetch('chr1', a, b)]
+    # the .bai on disk: magic, one entry per reference, every bin is the reg2bin of a read that lives in it, chunk
+    # offsets increase, linear index entries do not decrease
+    raw = open(path + '.bai', 'rb').read()
+    assert raw[:4] == b'BAI\x01' and struct.unpack_from('<i', raw, 4)[0] == 3
+    at = 8
+    bins_seen = []
+    for ref in range(3):
+        n_bin = struct.unpack_from('<i', raw, at)[0]; at += 4
+        bins = set()
+        for _ in range(n_bin):
+            bn, n_chunk = struct.unpack_from('<Ii', raw, at); at += 8
+            chunks = struct.unpack_from('<%dQ' % (2 * n_chunk), raw, at); at += 16 * n_chunk
+            assert all(chunks[2 * k] < chunks[2 * k + 1] for k in range(n_chunk))
+            assert all(chunks[2 * k + 1] <= chunks[2 * k + 2] for k in range(n_chunk - 1))
+            bins.add(bn)
+        n_intv = struct.unpack_from('<i', raw, at)[0]; at += 4
+        lin = struct.unpack_from('<%dQ' % n_intv, raw, at); at += 8 * n_intv
+        assert all(lin[k] <= lin[k + 1] for k in range(n_intv - 1))
+        bins_seen.append(bins)
+    assert at == len(raw)
+    assert bins_seen[0] == {reg2bin(r[1], r[2]) for r in recs if r[0] == 'chr1'}
+    assert bins_seen[1] == set()
+    assert bins_seen[2] == {reg2bin(r[1], r[2]) for r in recs if r[0] == 'chr2'}
+
+
+def test_pileup_defaults(tmp_path):
+    recs = make_bam(tmp_path / 'd.bam', n_reads=1500, length=400_000)
+    rd = BamReader(str(tmp_path / 'd.bam'))
+    a, b = 100_000, 101_000
+    cols = {c.pos: (c.get_query_names(), c.get_query_sequences()) for c in rd.pileup('chr1', a, b)}
+    # brute force with the documented rules
+    exp = {}
+    path = str(tmp_path / 'd.bam')
+    by_name = {g.query_name: g for g in BamReader(path).fetch('chr1', a, b)}
+    for contig, st, end, name, flag, cig, seq in recs:
+        if contig != 'chr1' or not (end > a and st < b) or flag & (4 | 256 | 512 | 1024):
+            continue
+        qual = by_name[name].query_qualities
+        ref, q = st, 0
+        for op, n in cig:
+            if op == 0:
+                for k in range(n):
+                    if qual[q + k] >= 13:
+                        exp.setdefault(ref + k, ([], []))
+                        exp[ref + k][0].append(name); exp[ref + k][1].append(seq[q + k])
+                ref += n; q += n
+            elif op in (2, 3):
+                for k in range(n):
+                    exp.setdefault(ref + k, ([], []))
+                    exp[ref + k][0].append(name); exp[ref + k][1].append('')
+                ref += n
+            else:
+                q += n
+    assert sorted(cols) == sorted(exp)                          # columns are not truncated to [a, b)
+    assert min(cols) < a and max(cols) >= b
+    for p in exp:
+        assert cols[p] == exp[p]
+    capped = {c.pos: len(c.get_query_names()) for c in rd.pileup('chr1', a, b, max_depth=2)}
+    assert max(capped.values()) == 2 and set(capped) == set(cols)
+    allq = {c.pos: len(c.get_query_names()) for c in rd.pileup('chr1', a, b, min_base_quality=0)}
+    assert sum(allq.values()) > sum(len(v[0]) for v in cols.values())
+
+
+def test_errors_are_reported(tmp_path):
+    with pytest.raises(OSError):
+        BamReader(str(tmp_path / 'missing.bam'))
+    bad = tmp_path / 'bad.bam'
+    bad.write_bytes(b'this is not a bam file at all')
+    with pytest.raises(ValueError):
+        BamReader(str(bad))
+
+
+def test_fasta_random_access(tmp_path):
+    rng = np.random.default_rng(1)
+    seqs = {'c1': ''.join(rng.choice(list('ACGTacgt'), 1234)), 'c2 extra words': ''.join(rng.choice(list('ACGT'), 61)), 'c3': 'A'}
+    fa = tmp_path / 'g.fa'
+    with open(fa, 'w') as f:
+        for name, s in seqs.items():
+            f.write('>%s\n' % name)
+            for k in range(0, len(s), 60):
+                f.write(s[k:k + 60] + '\n')
+    g = FastaReader(str(fa))
+    assert g.references == ['c1', 'c2', 'c3']
+    for name, s in (('c1', seqs['c1']), ('c2', seqs['c2 extra words']), ('c3', 'A')):
+        assert g.fetch(name) == s
+        for a, b in ((0, 1), (59, 61), (60, 120), (100, 1300), (-5, 10), (1233, 1234)):
+            assert g.fetch(name, a, b) == s[max(a, 0):b]
+    # with a samtools-style .fai on disk
+    with open(str(fa) + '.fai', 'w') as f:
+        for name, (ln, off, lb, lw) in g._fai.items():
+            f.write('%s\t%d\t%d\t%d\t%d\n' % (name, ln, off, lb, lw))
+    g2 = FastaReader(str(fa))
+    assert g2.fetch('c1', 100, 200) == seqs['c1'][100:200]

@@ -94,46 +94,61 @@ def test_cli_refuses_what_it_does_not_cover(tmp_path):
         cli.main(['-b', 'x.bam', '--genome_fasta', 'g.fa', '--mi_calculation_only'])   # strand correction
 
 
-@pytest.mark.gpu
-def test_cli_mi_calculation_only(tmp_path):
-    import lgmi
-    from lgmi import cli, region
+def run_cli_and_compare(tmp_path, extra=()):
+    """the CLI on a synthetic BAM (own BGZF/BAI reader) against what the REFERENCE's footprint_bulk_calculation
+    computes for the same reads (tests/golden/cli.json: region_mismatch_analysis with the CLI's defaults, driven
+    by tests/golden/gen_golden.py through a pysam-like pile-up) — .mi.txt and .removed.txt row for row"""
+    from conftest import load_golden
+    from lgmi import cli
+    gold = load_golden('cli.json')['cases']
     regions = regions_fixture()
     bam, fa, vcf = write_inputs(tmp_path, regions)
+    assert os.path.exists(bam + '.bai')
     prefix = str(tmp_path / 'out')
     cli.main(['-b', bam, '-c', 'chrA', 'chrB', '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
-              '--mi_calculation_only', '--skip_strand_correction', '--n_shuffles', '50', '--seed', '3'])
+              '--mi_calculation_only', '--skip_strand_correction'] + list(extra))
     mi = pd.read_table(prefix + '.mi.txt')
     removed = pd.read_table(prefix + '.removed.txt')
     strand = pd.read_table(prefix + '.strand.txt')
     assert list(strand.columns) == ['read_name', 'original_read_strand', 'corrected_read_strand'] and len(strand) == 0
-    assert list(mi.columns) == ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi', 'p_perm']
+    assert list(mi.columns)[:7] == ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
     assert list(removed.columns) == ['chromosome', 'strand', 'pos', 'removed']
-    # the same numbers as the region-level drop-in on the duck-typed fakes (CLI defaults: min_allele_ratio 0.05,
-    # min_total_depth 2, min_common 6), footprint by footprint
-    eng = lgmi.default_engine()
-    frames = []
-    for contig, (reads, genome, snps) in regions.items():
-        lo, hi = min(r.reference_start for r in reads), max(r.reference_end for r in reads)
-        frames.append(region.region_mismatch_analysis(contig, lo, hi, FakeSam(reads), FakeGenome(genome), snp_positions=snps,
-                                                      min_allele_ratio=0.05, min_total_depth=2, min_common_reads=6, engine=eng))
-    exp_mi = pd.concat([f[1] for f in frames])
-    exp_removed = pd.concat([f[2] for f in frames])
-    assert len(mi) == len(exp_mi) and len(mi) > 10
-    assert mi.iloc[:, :6].values.tolist() == exp_mi.iloc[:, :6].values.tolist()
-    assert np.allclose(mi['mi'].values, exp_mi['mi'].values, atol=1e-12)
-    # the BAM pile-up (like pysam's) also has columns inside introns (reference skips), which the duck-typed
-    # fake does not emit.  Through the reference's look-up quirks every such column becomes an empty site reported
-    # as 'too few usable reads after filters', and a site dropped by the window filter next to an intron is
-    # re-created by a later look-up and re-reported with that reason.  So: every site the fake run removes is removed
-    # here too (same reason, or the empty-site reason), and every other reason seen here is the fake run's.
-    empty = 'too few usable reads after filters'
-    got = {(c, st, p): r for c, st, p, r in removed.values.tolist()}
-    exp = {(c, st, p): r for c, st, p, r in exp_removed.values.tolist()}
-    for k, r in exp.items():
-        assert got.get(k) in (r, empty), (k, r, got.get(k))
-    for k, r in got.items():
-        if r != empty:
-            assert exp.get(k) == r
-    introns = {(c, p) for c in regions for a, b in ((300, 380), (620, 700)) for p in range(a, b)}
-    assert {(c, p) for (c, _s, p) in set(got) - set(exp)} <= introns
+    exp_mi = [r for c in gold for r in c['pair_mi']['data']]
+    exp_removed = [r for c in gold for r in c['removed']['data']]
+    assert [c['contig'] for c in gold] == ['chrA', 'chrB'] and len(exp_mi) > 50
+    assert mi.iloc[:, :6].values.tolist() == [r[:6] for r in exp_mi]
+    assert np.allclose(mi['mi'].values, [r[6] for r in exp_mi], atol=1e-6, rtol=0)
+    assert removed.values.tolist() == exp_removed
+    return mi
+
+
+def test_cli_host_side_matches_the_reference(tmp_path, monkeypatch):
+    """CPU: everything but the MI kernels (BAM/BAI/FASTA/VCF reading, footprints, filters, typing, table assembly,
+    output files); the MI block is the CPU oracle and the engine a stub — test-only, the product has no CPU path"""
+    import lgmi.engine
+    from lgmi import region
+    from oracle import mi_oracle
+
+    def oracle_blocks(regions, mc=5, n_shuffles=0, seed=0, engine=None):
+        out = []
+        for mm, chrom in regions:
+            kept, means = mi_oracle.region_mi(mm, mc)
+            out.append(([[chrom, s] + r for s in '+-' for r in kept[s]], {s: dict(means[s]) for s in '+-'}, None))
+        return out
+
+    class NoEngine:
+        def __init__(self, device=None):
+            pass
+
+        def close(self):
+            pass
+    monkeypatch.setattr(region, 'regions_pair_mi', oracle_blocks)
+    monkeypatch.setattr(lgmi.engine, 'Engine', NoEngine)
+    run_cli_and_compare(tmp_path)
+
+
+@pytest.mark.gpu
+def test_cli_mi_calculation_only(tmp_path):
+    mi = run_cli_and_compare(tmp_path, ['--n_shuffles', '50', '--seed', '3'])
+    assert list(mi.columns)[7:] == ['p_perm']
+    assert ((mi['p_perm'] >= 1 / 51) & (mi['p_perm'] <= 1)).all()
