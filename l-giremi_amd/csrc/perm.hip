@@ -26,6 +26,8 @@
 // One shortcut: le_exp() lets the hardware's f32 exp decide the HRUA acceptances that are not
 // within 1e-4 of the boundary (same decisions as det_exp as long as the hardware value is
 // within 1e-4 of it — measured 2e-7, pinned by a device-side sweep in the GPU tests).
+#include <algorithm>
+
 #include "lgmi_internal.h"
 #include "philox.h"
 
@@ -296,9 +298,12 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
     double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
     uint32_t* __restrict__ gen_list = pa.gen_list; unsigned int* __restrict__ gen_count = pa.gen_count;
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((uint64_t)blockIdx.x * blockDim.x >= n_rows) return;      // wave-uniform: the grid is sized by an upper bound
     const uint32_t lane = threadIdx.x & 63u;
+    // persistent one-wave workgroups: a fixed grid strides over the 64-row chunks (the row count is only known on
+    // the device, and 7 million one-wave workgroups per launch were a cost of their own)
+    const uint64_t n_chunks = (n_rows + 63ull) / 64ull;
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // wave-uniform trip count: the grid drains
+    const uint64_t r = chunk * 64ull + lane;
     // ---- phase A (one lane per row): classify, set up the hypergeometric, find the bounds
     int kind = 0;   // 0 nothing, 1 degenerate, 2 two-by-two, 3 queued for k_perm_general
     HG22 h = {1u, 0u, 0u, 0u, 0u, 0.0};
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
         }
         out_exceed[r] = LGMI_EXCEED_EXACT;
         out_p[r] = p;
-        return;
+        kind = 0;                                           // done with this row
     }
     if (kind == 2) {
         const unsigned long long sm = s_acc[w][lane];
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 #endif
     }
     // ---- phase C (one lane per row): the shuffles
-    if (kind == 0 || kind == 3) return;
+    if (kind == 1 || kind == 2) {
     uint32_t exceed;
     if (kind == 1) {
         exceed = n_shuffles;
@@ -449,6 +454,9 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     }
     out_exceed[r] = exceed;
     out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+    }
+    __syncthreads();                                        // s_pre / s_acc are reused by the next chunk
+    }   // chunk loop
 }
 
 // ---------------------------------------------------------------- general tables
@@ -981,7 +989,8 @@ void launch_selftest_le_exp(hipStream_t st, uint64_t n, const double* x2, const 
 void launch_perm_fast(hipStream_t st, const PermArgs& a)
 {
     if (!a.max_rows) return;
-    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)((a.max_rows + 63) / 64)), dim3(64), 0, st, a);
+    const uint64_t chunks = (a.max_rows + 63) / 64;
+    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)std::min<uint64_t>(chunks, 256ull * 32ull)), dim3(64), 0, st, a);
 }
 
 void launch_perm_general(hipStream_t st, const PermArgs& a)

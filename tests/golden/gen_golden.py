@@ -252,6 +252,42 @@ def time_reference(out_path):
         json.dump(res, f, indent=1)
 
 
+LARGE_CONFIGS = [('cfg2 10k x 50k', 50_000), ('cfg3 22 x (9,091 x 45,455)', 45_455), ('north-star 50k x 200k', 200_000),
+                 ('cfg5 depth x 4 (181,820 reads per chromosome)', 181_820)]
+
+
+def _time_block(args):
+    """worker of time_reference_large (also run through multiprocessing.Pool): one dense 64-site block = 2,016 pairs"""
+    seed, n_reads = args
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mm = random_block(rng, 64, n_reads, 2, 0.9)
+    t0 = time.perf_counter()
+    rows = _orig_call(mm, 6)
+    return time.perf_counter() - t0, len(rows)
+
+
+def time_reference_large(out_path):
+    """a fixed-seed ~2,000-pair subsample (one dense block of 64 sites = 2,016 pairs at the
+    config's read depth, 10 % dropout) of every larger config, single process and multiprocessing.Pool(8) over 8
+    such blocks — the reference's own parallelism (script/giremi.py:375-380).  Appends to the timing JSON."""
+    import multiprocessing as mp
+    with open(out_path) as f:
+        res = json.load(f)
+    res['subsamples'] = []
+    for k, (name, n_reads) in enumerate(LARGE_CONFIGS):
+        dt, n_rows = _time_block((1000 + k, n_reads))
+        with mp.Pool(8) as pool:
+            t0 = time.perf_counter()
+            outs = pool.map(_time_block, [(2000 + 10 * k + j, n_reads) for j in range(8)])
+            wall8 = time.perf_counter() - t0
+        res['subsamples'].append({'config': name, 'n_reads': n_reads, 'pairs_per_block': 2016,
+                                  'single_process': {'wall_s': dt, 'pairs_per_s': 2016 / dt, 'pairs_emitted': n_rows},
+                                  'pool8_over_8_blocks': {'wall_s': wall8, 'pairs_per_s': 8 * 2016 / wall8,
+                                                          'per_block_wall_s': [o[0] for o in outs]}})
+        with open(out_path, 'w') as f:
+            json.dump(res, f, indent=1)
+
+
 def _orig_call(mm, mc):
     ref_mi.mutual_info_score = _orig_mis
     try:
@@ -415,6 +451,9 @@ def main():
     import scipy
     meta = {'reference': 'gxiaolab/L-GIREMI v0.2.4 imported by file path',
             'sklearn': sklearn.__version__, 'numpy': np.__version__, 'scipy': scipy.__version__}
+    if '--time-large' in sys.argv:      # added in round 2
+        time_reference_large(os.path.join(HERE, 'reference_timing.json'))
+        return
     if '--only-cli' in sys.argv:        # added in round 2: leaves the round-1 fixtures byte-for-byte as they are
         with open(os.path.join(HERE, 'cli.json'), 'w') as f:
             json.dump({'meta': meta, 'cases': cli_cases()}, f)

@@ -26,6 +26,21 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names, 'ctypes binding and header disagree'
 
 
+def test_io_library_exports_every_declared_symbol():
+    """liblgmi_io.so (host-only BAM reader) against include/lgmi_io.h and the ctypes table in lgmi/io.py"""
+    from lgmi import io
+    text = open(os.path.join(ROOT, 'include', 'lgmi_io.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    names = sorted(set(re.findall(r'\b(lgio_[a-z0-9_]+)\s*\(', text)))
+    lib = C.CDLL(io.IO_LIB_PATH)
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(lib, name), 'liblgmi_io.so does not export %s' % name
+    assert sorted(io.IO_SYMBOLS) == names
+    assert io.load_io().lgio_abi_version() == 1
+    assert C.sizeof(io._Reads) == 152 and C.sizeof(io._Pileup) == 48 + 152
+
+
 def test_abi_version_and_struct_sizes():
     lib = _lib.load()
     assert lib.lgmi_abi_version() == _lib.ABI_VERSION
