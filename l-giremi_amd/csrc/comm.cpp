@@ -230,12 +230,18 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
         if (!e) e = pool_alloc(ctx, (void**)&gnp, tsn * 4);
         if (!e) e = pool_alloc(ctx, (void**)&gsum, tsn * 8);
         if (e) my_status = 1;
+    } else if (same_batch) {
+        // ncclReduce only writes recvbuff on the root, but every rank hands RCCL a valid device pointer
+        const size_t tsn = (size_t)std::max<uint64_t>(v.n_sites, 1);
+        int e = pool_alloc(ctx, (void**)&gnp, tsn * 4);
+        if (!e) e = pool_alloc(ctx, (void**)&gsum, tsn * 8);
+        if (e) my_status = 1;
     }
     std::vector<uint64_t> status(world);
     rc = lgmi_comm_allgather_u64v(ctx, &my_status, 1, status.data());
     if (rc) { release_all(); return rc; }
     for (int r = 0; r < world; ++r)
-        if (status[r]) { release_all(); return set_error(LGMI_E_OOM, "lgmi_comm_gather: the root could not allocate the gathered result"); }
+        if (status[r]) { release_all(); return set_error(LGMI_E_OOM, "lgmi_comm_gather: a rank could not allocate its buffers"); }
 
     // different batches: sites no rank reports (gaps between the ranks' site ranges) read NaN / 0 pairs; queued on
     // the stream before the receives that fill the ranks' own ranges
@@ -291,7 +297,9 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
 #undef NC
     if (nr != ncclSuccess) { (void)hipStreamSynchronize(st); release_all(); return nccl_fail(nr, "lgmi_comm_gather"); }
     if (rank != root) {
-        HIPCHK2(hipStreamSynchronize(st));
+        const hipError_t es = hipStreamSynchronize(st);
+        release_all();
+        if (es != hipSuccess) return set_error(LGMI_E_HIP, hipGetErrorString(es));
         return LGMI_OK;
     }
     // ---- 4. root: its own rows, the site bases, the per-site means
