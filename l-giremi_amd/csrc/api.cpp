@@ -122,7 +122,6 @@ struct lgmi_ctx {
     Pool pool;
     long long* d_G = nullptr;   // round(n ln n * 2^28): permutation statistic (perm.hip)
     double* d_LF = nullptr;     // ln n!
-    double* d_LN = nullptr;     // ln n (emit.hip: the MI's logarithms are look-ups, their arguments are read counts)
     uint32_t tables_len = 0;
     void* comm = nullptr;       // ncclComm_t (comm.cpp)
     int rank = 0, world = 1;
@@ -218,7 +217,6 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_G) (void)hipFree(ctx->d_G);
     if (ctx->d_LF) (void)hipFree(ctx->d_LF);
-    if (ctx->d_LN) (void)hipFree(ctx->d_LN);
     ctx->pool.destroy();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -610,20 +608,16 @@ static int ensure_perm_tables(lgmi_ctx* ctx, uint32_t max_n) {
     if (ctx->tables_len > max_n) return LGMI_OK;
     if (ctx->d_G) { (void)hipFree(ctx->d_G); ctx->d_G = nullptr; }
     if (ctx->d_LF) { (void)hipFree(ctx->d_LF); ctx->d_LF = nullptr; }
-    if (ctx->d_LN) { (void)hipFree(ctx->d_LN); ctx->d_LN = nullptr; }
     ctx->tables_len = 0;
     std::vector<long long> g((size_t)max_n + 1);
-    std::vector<double> lf((size_t)max_n + 1), ln((size_t)max_n + 1);
+    std::vector<double> lf((size_t)max_n + 1);
     g[0] = 0;
-    ln[0] = 0.0;                                     // never read: a cell that is 0 contributes no term
-    for (uint32_t n = 1; n <= max_n; ++n) { ln[n] = std::log((double)n); g[n] = llrint((double)n * ln[n] * 268435456.0); }
+    for (uint32_t n = 1; n <= max_n; ++n) g[n] = llrint((double)n * std::log((double)n) * 268435456.0);
     for (uint32_t n = 0; n <= max_n; ++n) lf[n] = lgamma((double)n + 1.0);
     HIPCHK(hipMalloc((void**)&ctx->d_G, g.size() * sizeof(long long)));
     HIPCHK(hipMalloc((void**)&ctx->d_LF, lf.size() * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&ctx->d_LN, ln.size() * sizeof(double)));
     HIPCHK(hipMemcpy(ctx->d_G, g.data(), g.size() * sizeof(long long), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_LF, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->d_LN, ln.data(), ln.size() * sizeof(double), hipMemcpyHostToDevice));
     ctx->tables_len = max_n + 1;
     return LGMI_OK;
 }
@@ -656,8 +650,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     int rc;
 
     // the log-factorial table also serves the binomial draw of the 2 x 2 path: LF[0 .. n_shuffles]
-    // (and ln n for the MI itself: every run)
-    if ((rc = ensure_perm_tables(ctx, std::max(db->max_reads, prm->n_shuffles)))) return rc;   // first use only
+    if (want_p && (rc = ensure_perm_tables(ctx, std::max(db->max_reads, prm->n_shuffles)))) return rc;   // first use only
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     const auto t_plan0 = std::chrono::steady_clock::now();
     Plan pl;
@@ -750,7 +743,6 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     ea.plans = d_plans; ea.smap = d_smap; ea.xlist = d_xlist; ea.cols = db->d.d_cols;
     ea.type = db->d.d_type; ea.tri = db->d.d_tri;
     ea.slots = d_slots;
-    ea.LN = ctx->d_LN;
     ea.n_items = (uint32_t)n_items; ea.items = d_items;
     ea.row_cnt = d_rowcnt; ea.row_start = d_rowstart;
     ea.site_sum = d_sum; ea.site_cnt = d_cnt; ea.err_flag = d_err; ea.word_pairs = d_wordpairs;

@@ -12,14 +12,9 @@
 
 namespace lgmi {
 
-// MI of a 3 x 3 table, sklearn.metrics.mutual_info_score's formula term by term (_supervised.py:903-923).  Every
-// logarithm it takes is of a read count (cell, margin, total) or of a product of two margins, so the logs are
-// look-ups in a host-built table of ln n (libm, correctly rounded to < 1 ulp) and log(R C) = ln R + ln C: 9 scattered
-// 8-byte loads per row instead of ~900 VALU instructions of f64 log (k_emit<2> was VALU-bound on them, PMC:
-// 0.71 issue).  Differences from sklearn's own rounding stay at the 1e-16 level (tolerance of the path: 1e-6).
-__device__ __forceinline__ double mi_from_table(const uint32_t t[9], const double* __restrict__ LN) {
-    // Classes absent among the common reads do not exist (np.unique); a single surviving row or column
-    // returns exactly 0.0 (:909).
+__device__ __forceinline__ double mi_from_table(const uint32_t t[9]) {
+    // _supervised.py:903-923.  Classes absent among the common reads do not exist
+    // (np.unique); a single surviving row or column returns exactly 0.0 (:909).
     uint32_t R[3], C[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -30,10 +25,7 @@ __device__ __forceinline__ double mi_from_table(const uint32_t t[9], const doubl
     const int nr = (R[0] != 0) + (R[1] != 0) + (R[2] != 0);
     const int nc = (C[0] != 0) + (C[1] != 0) + (C[2] != 0);
     if (nr <= 1 || nc <= 1) return 0.0;
-    const double dn = (double)n, log_n = LN[n];
-    double lr[3], lc[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { lr[a] = R[a] ? LN[R[a]] : 0.0; lc[a] = C[a] ? LN[C[a]] : 0.0; }
+    const double dn = (double)n, log_n = log(dn);
     double sum = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -42,7 +34,8 @@ __device__ __forceinline__ double mi_from_table(const uint32_t t[9], const doubl
             const uint32_t nab = t[3 * a + b];
             if (nab) {
                 const double frac = (double)nab / dn;
-                double term = frac * (LN[nab] - log_n) + frac * (-(lr[a] + lc[b]) + log_n + log_n);
+                const double outer = (double)((uint64_t)R[a] * (uint64_t)C[b]);
+                double term = frac * (log((double)nab) - log_n) + frac * (-log(outer) + log_n + log_n);
                 if (fabs(term) < 2.220446049250313e-16) term = 0.0;
                 sum += term;
             }
@@ -158,7 +151,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
                         T[6] = t02; T[7] = t12; T[8] = n22;
                     }
                 }
-                const double mi = (n_common == 0) ? 0.0 : mi_from_table(T, a.LN);
+                const double mi = (n_common == 0) ? 0.0 : mi_from_table(T);
                 a.out_i[r] = i;
                 a.out_j[r] = j;
                 a.out_mi[r] = mi;

@@ -121,7 +121,6 @@ struct EmitArgs {
     const Col* cols;
     const uint8_t* type;
     const uint8_t* tri;
-    const double* LN;         // ln n for n = 0 .. the largest read count of the batch (host-built, libm)
     const uint4* slots;       // one (N, R, C, A) per slot: common reads, class-2 reads of x, of y, of both
     // work items of the two emit passes: a site row is cut into segments of EMIT_SEG partners so that the long
     // rows of x sites (up to the whole block) spread over many waves; items are in (site, segment) order
