@@ -712,7 +712,10 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
             if (nr == 3) hr_base(rc2, R1, hb);
             uint32_t s_id = lane, call = 0u, exceed = 0u, x0 = 0u;
             uint32_t good = 0u, sample = 0u, m = 0u, mn = 0u, mx = 0u;
-            double d6 = 0.0, d8 = 0.0, d10 = 0.0, d11 = 0.0;
+            // d10 (the log-weight at the mode) is kept as its four table values and summed where it is used, in the
+            // order the specification adds them: the set-up's look-ups are then still in flight when the candidate's
+            // look-ups are issued, and one wait covers both (a trip had three dependent rounds of global loads)
+            double d6 = 0.0, d8 = 0.0, d10a = 0.0, d10b = 0.0, d10c = 0.0, d10d = 0.0, d11 = 0.0;
             int phase = s_id < n_shuffles ? 0 : 3;       // 0 begin, 1 HRUA candidates, 3 finished
             for (;;) {
                 // one Philox call per trip and lane.  A lane that starts a shuffle (call 0) draws its first result
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                     d6 = (double)m * hb.d4 + 0.5;
                     const double d7 = d7max;                     // the row's hat width (no square root per shuffle)
                     const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
-                    d10 = LF[d9] + LF[mn - d9] + LF[m - d9] + LF[mx - m + d9];
+                    d10a = LF[d9]; d10b = LF[mn - d9]; d10c = LF[m - d9]; d10d = LF[mx - m + d9];
                     d8 = HRUA_D1 * d7 + HRUA_D2;
                     const double cap = (double)((m < mn ? m : mn) + 1u);
                     const double lim = floor(d6 + 16.0 * d7);
@@ -752,7 +755,8 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                     const double w = d6 + d8 * (y - 0.5) / x;
                     if (!(w < 0.0 || w >= d11)) {
                         const uint32_t zc = (uint32_t)floor(w);
-                        const double tt = d10 - (LF[zc] + LF[mn - zc] + LF[m - zc] + LF[mx - m + zc]);
+                        const double lz = LF[zc] + LF[mn - zc] + LF[m - zc] + LF[mx - m + zc];
+                        const double tt = (d10a + d10b + d10c + d10d) - lz;
                         bool acc = (x * (4.0 - x) - 3.0 <= tt);
                         if (!acc && !(x * (x - tt) >= 1.0)) acc = le_exp(x * x, tt);   // 2 ln x <= tt
                         if (acc) {
