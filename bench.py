@@ -113,7 +113,9 @@ def main():
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-to-host', action='store_true')
-    ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the row gather (kernel-only scaling)')
+    ap.add_argument('--no-gather', action='store_true',
+                    help='N > 1: skip the RCCL communicator and the row gather (kernel-only scaling; also lets several '
+                         'ranks share one GPU with LGMI_BENCH_DEVICE=0 to rehearse the launch, which RCCL refuses)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -141,7 +143,7 @@ def main():
         db = eng.upload(banded_chromosome(wl['n_sites'], wl['n_reads'], seed=seed))
     else:
         db = eng.synth_dense(lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed, n_blocks=n_blocks))
-    if world > 1:
+    if world > 1 and not args.no_gather:
         eng.comm_init_group(group)                             # RCCL communicator inside liblgmi (csrc/comm.cpp)
     shard = (rank, world) if (strong and world > 1) else None
     n_sites_rank = wl['n_sites'] * n_blocks
