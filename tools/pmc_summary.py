@@ -17,10 +17,10 @@ import sys
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, '**', '*' + suffix), recursive=True))
+    hits = sorted(glob.glob(os.path.join(d, '**', '*' + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
         sys.exit('no *%s under %s' % (suffix, d))
-    return hits[0]
+    return hits[-1]                 # the newest run when a directory holds several
 
 
 def counters(d):
