@@ -143,8 +143,32 @@ def main():
         db = eng.upload(banded_chromosome(wl['n_sites'], wl['n_reads'], seed=seed))
     else:
         db = eng.synth_dense(lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed, n_blocks=n_blocks))
-    if world > 1 and not args.no_gather:
-        eng.comm_init_group(group)                             # RCCL communicator inside liblgmi (csrc/comm.cpp)
+    gather_state = {'on': world > 1 and not args.no_gather, 'note': None}
+    hung = []
+    if gather_state['on']:
+        # RCCL communicator inside liblgmi (csrc/comm.cpp).  The 128-byte id travels over the sockets here; the
+        # collective ncclCommInitRank runs in a thread so that a rank that cannot bring RCCL up (or never returns)
+        # costs the job its gather, not its measurement: every rank learns the outcome over the sockets and the
+        # run goes on kernel-only, saying so in the JSON line.
+        import threading
+        from lgmi.dist import exchange_unique_id
+        uid = exchange_unique_id(group, eng.comm_unique_id if rank == 0 else None)
+        box = {}
+
+        def bring_up():
+            try:
+                eng.comm_init(uid, rank, world)
+                box['ok'] = True
+            except Exception as e:                              # noqa: BLE001
+                box['err'] = repr(e)
+        th = threading.Thread(target=bring_up, daemon=True)
+        th.start()
+        th.join(float(os.environ.get('LGMI_COMM_INIT_TIMEOUT', '240')))
+        if th.is_alive():
+            hung.append(th)
+        states = group.allgather(box.get('err') or ('ok' if box.get('ok') else 'timeout'))
+        if any(st != 'ok' for st in states):
+            gather_state.update(on=False, note='RCCL communicator not available (%s): rows were NOT gathered' % states)
     shard = (rank, world) if (strong and world > 1) else None
     n_sites_rank = wl['n_sites'] * n_blocks
 
@@ -157,7 +181,7 @@ def main():
     def step():
         dr = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
         info = dr.info()
-        if world > 1 and not args.no_gather:                   # the final gather: rows HBM -> rank 0's HBM over xGMI
+        if gather_state['on']:                                 # the final gather: rows HBM -> rank 0's HBM over xGMI
             t0 = time.perf_counter()
             g, begins = eng.comm_gather(dr, root=0, site_base=0 if strong else rank * n_sites_rank, same_batch=strong)
             info['ms_gather'] = 1e3 * (time.perf_counter() - t0)
@@ -211,7 +235,9 @@ def main():
                                        ('tile shards of one batch x%d, RCCL row gather to rank 0' % world if strong else
                                         'one chromosome per rank x%d, RCCL row gather to rank 0' % world)),
                        'timed_region': 'resident batch -> result rows resident in HBM'
-                                       + (' of rank 0 (gather included)' if world > 1 and not args.no_gather else '')},
+                                       + (' of rank 0 (gather included)' if gather_state['on'] else ''),
+                       'gather': ('liblgmi RCCL (lgmi_comm_gather)' if gather_state['on'] else
+                                  (gather_state['note'] or ('skipped (--no-gather)' if world > 1 else 'n/a')))},
             'stage_ms': {k: sum(i.get(k, 0.0) for i in infos) / len(infos)
                          for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
                                    'ms_perm_general', 'ms_mean', 'ms_gather')},
@@ -295,7 +321,9 @@ def main():
     eng.close()
     group.close()
     if out is not None:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if hung:                                                   # a thread still inside ncclCommInitRank: do not wait for it
+        os._exit(0)
 
 
 if __name__ == '__main__':

@@ -112,6 +112,23 @@ def test_fewer_than_two_alleles_raises_indexerror(engine):
     assert lgmi.mismatch_pair_mutual_info(mm, 5, engine=engine) == []   # never ranked: no pair passes :19
 
 
+def test_region_block_raises_for_a_bad_site_in_a_pair_without_het_side(engine):
+    """the reference ranks the alleles of every qualifying pair before its het filter (mutual_information.py:25-32,
+    mismatch.py:392-396): a site with < 2 alleles in `depth` raises IndexError even when its only partner with enough
+    common reads is not a het_snp"""
+    import lgmi
+    reads = ['r%d' % k for k in range(8)]
+    mm = {'+': {10: {'type': 'mismatch', 'depth': {'A': 8}, 'nt': {'A': reads}},
+                20: {'type': 'mismatch', 'depth': {'A': 5, 'C': 3}, 'nt': {'A': reads[:5], 'C': reads[5:]}},
+                30: {'type': 'het_snp', 'depth': {'G': 2, 'T': 2}, 'nt': {'G': ['x1', 'x2'], 'T': ['x3', 'x4']}}},
+          '-': {}}
+    with pytest.raises(IndexError):
+        lgmi.region_pair_mi(mm, 'chrS', 5, engine=engine)
+    mm['+'][10]['nt'] = {'A': reads[:3]}                       # now no pair of site 10 has 5 common reads
+    records, _mean, _p = lgmi.region_pair_mi(mm, 'chrS', 5, engine=engine)
+    assert records == []
+
+
 def test_empty_and_single_site(engine):
     import lgmi
     assert lgmi.mismatch_pair_mutual_info({}, 5, engine=engine) == []
