@@ -126,6 +126,13 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
         args.gpus = world
 
+    # stdout carries ONE JSON line.  Libraries loaded below write banners to file descriptor 1 (RCCL prints its version
+    # block there when a communicator comes up): keep a private copy of the real stdout for the JSON line and point
+    # descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import lgmi
     from lgmi.dist import group_from_env
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -321,7 +328,7 @@ def main():
     eng.close()
     group.close()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if hung:                                                   # a thread still inside ncclCommInitRank: do not wait for it
         os._exit(0)
 
