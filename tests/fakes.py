@@ -81,15 +81,17 @@ class FakeGenome:
         return self.seq[max(start, 0):end]
 
 
-def simulate_region(seed, n_reads=60, length=900, n_snps=6, n_edits=8, err=0.004, lower_case_ref=False):
+def simulate_region(seed, n_reads=60, length=900, n_snps=6, n_edits=8, err=0.004, lower_case_ref=False, scale=1):
     """one gene with three exons; reads start anywhere, all spliced; two haplotypes differing at n_snps
     positions; n_edits A>G editing sites hit with a site-specific probability; uniform sequencing errors.
+    scale > 1 stretches the gene (length and exon coordinates times scale) for cfg1-sized cases.
     Returns (reads, genome string, snp positions, [start, end])."""
     rng = np.random.default_rng(seed)
+    length = length * scale
     seq = ''.join(rng.choice(list(BASES), length))
     # a homopolymer stretch and a fixed exon structure
     seq = seq[:200] + 'AAAAAAA' + seq[207:]
-    exons = [(20, 300), (380, 620), (700, 880)]
+    exons = [(20 * scale, 300 * scale), (380 * scale, 620 * scale), (700 * scale, 880 * scale)]
     exonic = [p for a, b in exons for p in range(a + 12, b - 12)]
     snp_pos = sorted(int(p) for p in rng.choice(exonic, n_snps, replace=False))
     snp_alt = {p: rng.choice([b for b in BASES if b != seq[p]]) for p in snp_pos}

@@ -376,6 +376,28 @@ CLI_KWARGS = dict(keep_non_spliced_read=False, min_dist_from_splice=4, min_allel
                   mode='cs', read_strand_dict=None)
 
 
+# BASELINE.json configs[0]: "Synthetic 1-chrom BAM, 500 sites x 2k reads, --mi_calculation_only": one stretched gene,
+# 2,000 spliced reads, 110 SNP positions and up to 420 editing sites
+CFG1_REGION = ('chrC', dict(seed=300, n_reads=2000, n_snps=110, n_edits=420, err=0.002, scale=4))
+
+
+def cli_cfg1_case():
+    """the reference on the cfg1-sized footprint (same construction as cli_cases); the site table is left out"""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from fakes import FakeGenome, FakeSamSkips, simulate_region
+    ref_mm = load_ref_mismatch()
+    contig, sim_kw = CFG1_REGION
+    reads, genome, snps, _ = simulate_region(**sim_kw)
+    lo, hi = min(r.reference_start for r in reads), max(r.reference_end for r in reads)
+    snp_in = sorted(p for p in snps if lo <= p < hi)
+    t0 = time.perf_counter()
+    dfs = ref_mm.region_mismatch_analysis(contig, lo, hi, FakeSamSkips(reads), FakeGenome(genome),
+                                          simple_repeat_intervals=[], snp_positions=snp_in, **CLI_KWARGS)
+    dt = time.perf_counter() - t0
+    return {'contig': contig, 'sim': sim_kw, 'footprint': [lo, hi], 'pair_mi': frame_json(dfs[1]),
+            'removed': frame_json(dfs[2]), 'n_sites': int(len(dfs[0])), 'reference_wall_s': dt}
+
+
 def cli_cases():
     """what the reference's footprint_bulk_calculation (script/giremi.py:20-93) computes for the CLI test's two
     footprints: region_mismatch_analysis with the CLI's defaults, on a pysam-like view of the same reads (pile-up
@@ -453,6 +475,10 @@ def main():
             'sklearn': sklearn.__version__, 'numpy': np.__version__, 'scipy': scipy.__version__}
     if '--time-large' in sys.argv:      # added in round 2
         time_reference_large(os.path.join(HERE, 'reference_timing.json'))
+        return
+    if '--only-cli-cfg1' in sys.argv:   # added in round 2 (several minutes: the reference examines ~1e5 pairs at depth 2,000)
+        with open(os.path.join(HERE, 'cli_cfg1.json'), 'w') as f:
+            json.dump({'meta': meta, 'case': cli_cfg1_case()}, f)
         return
     if '--only-cli' in sys.argv:        # added in round 2: leaves the round-1 fixtures byte-for-byte as they are
         with open(os.path.join(HERE, 'cli.json'), 'w') as f:

@@ -152,3 +152,80 @@ def test_cli_mi_calculation_only(tmp_path):
     mi = run_cli_and_compare(tmp_path, ['--n_shuffles', '50', '--seed', '3'])
     assert list(mi.columns)[7:] == ['p_perm']
     assert ((mi['p_perm'] >= 1 / 51) & (mi['p_perm'] <= 1)).all()
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[0]: 500 sites x 2k reads through the CLI
+def cfg1_inputs(tmp_path):
+    from conftest import load_golden
+    gold = load_golden('cli_cfg1.json')['case']
+    reads, genome, snps, _ = simulate_region(**gold['sim'])
+    bam, fa, vcf = write_inputs(tmp_path, {gold['contig']: (reads, genome, snps)})
+    return gold, bam, fa, vcf
+
+
+def check_cfg1(prefix, gold):
+    mi = pd.read_table(prefix + '.mi.txt')
+    removed = pd.read_table(prefix + '.removed.txt')
+    exp_mi, exp_removed = gold['pair_mi']['data'], gold['removed']['data']
+    assert len(exp_mi) > 5000 and gold['n_sites'] > 300
+    assert mi.iloc[:, :6].values.tolist() == [r[:6] for r in exp_mi]
+    assert np.allclose(mi['mi'].values, [r[6] for r in exp_mi], atol=1e-6, rtol=0)
+    assert removed.values.tolist() == exp_removed
+    return mi
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', 'cli_cfg1.json')),
+                    reason='tests/golden/cli_cfg1.json not generated')
+def test_cli_cfg1_host_side_matches_the_reference(tmp_path, monkeypatch):
+    """the cfg1-sized footprint (2,000 reads, several hundred candidate sites) through the BAM reader, the filters and
+    the vectorised packer; MI block = the C oracle on the packed blocks (test-only stub, the product has no CPU path)"""
+    import lgmi.engine
+    from lgmi import region
+    from lgmi.pack import pack_blocks
+    from oracle import c_oracle
+
+    def oracle_blocks(regions, mc=5, n_shuffles=0, seed=0, engine=None):
+        out = []
+        for mm, chrom in regions:
+            records, means = [], {'+': {}, '-': {}}
+            for strand in '+-':
+                blk = mm.get(strand, {})
+                if len(blk) < 2:
+                    continue
+                pb = pack_blocks([blk])
+                res = c_oracle.run(pb, min_common=mc, het_only=True)
+                pos, names = pb.site_pos.tolist(), pb.type_names
+                records.extend([chrom, strand, pos[i], names[i], pos[j], names[j], m]
+                               for i, j, m in zip(res['row_i'].tolist(), res['row_j'].tolist(), res['row_mi'].tolist()))
+                for s_ in np.nonzero(res['site_n_pairs'])[0].tolist():
+                    means[strand][pos[s_]] = float(res['site_mean_mi'][s_])
+            out.append((records, means, None))
+        return out
+
+    class NoEngine:
+        def __init__(self, device=None):
+            pass
+
+        def close(self):
+            pass
+    monkeypatch.setattr(region, 'regions_pair_mi', oracle_blocks)
+    monkeypatch.setattr(lgmi.engine, 'Engine', NoEngine)
+    gold, bam, fa, vcf = cfg1_inputs(tmp_path)
+    from lgmi import cli
+    prefix = str(tmp_path / 'cfg1')
+    cli.main(['-b', bam, '-c', gold['contig'], '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
+              '--mi_calculation_only', '--skip_strand_correction'])
+    check_cfg1(prefix, gold)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', 'cli_cfg1.json')),
+                    reason='tests/golden/cli_cfg1.json not generated')
+def test_cli_cfg1_mi_calculation_only(tmp_path):
+    from lgmi import cli
+    gold, bam, fa, vcf = cfg1_inputs(tmp_path)
+    prefix = str(tmp_path / 'cfg1')
+    cli.main(['-b', bam, '-c', gold['contig'], '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
+              '--mi_calculation_only', '--skip_strand_correction', '--n_shuffles', '100', '--seed', '5'])
+    mi = check_cfg1(prefix, gold)
+    assert ((mi['p_perm'] >= 1 / 101) & (mi['p_perm'] <= 1)).all()
