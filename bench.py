@@ -113,6 +113,9 @@ def main():
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-to-host', action='store_true')
+    ap.add_argument('--force-gather', action='store_true',
+                    help='N = 1: bring the RCCL communicator up with one rank and run the gather and its verification '
+                         'anyway (rehearses the N > 1 code path on a one-GPU box)')
     ap.add_argument('--no-gather', action='store_true',
                     help='N > 1: skip the RCCL communicator and the row gather (kernel-only scaling; also lets several '
                          'ranks share one GPU with LGMI_BENCH_DEVICE=0 to rehearse the launch, which RCCL refuses)')
@@ -150,7 +153,7 @@ def main():
         db = eng.upload(banded_chromosome(wl['n_sites'], wl['n_reads'], seed=seed))
     else:
         db = eng.synth_dense(lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed, n_blocks=n_blocks))
-    gather_state = {'on': world > 1 and not args.no_gather, 'note': None}
+    gather_state = {'on': (world > 1 or args.force_gather) and not args.no_gather, 'note': None}
     hung = []
     if gather_state['on']:
         # RCCL communicator inside liblgmi (csrc/comm.cpp).  The 128-byte id travels over the sockets here; the
@@ -209,6 +212,26 @@ def main():
     per_rank = group.gather({k: sum(i[k] for i in infos) / len(infos) for k in
                              ('ms_total', 'ms_count', 'ms_emit', 'ms_perm', 'n_examined', 'n_rows', 'n_tile_pairs')})
 
+    # N > 1, strong scaling: one more (untimed) pass whose gathered result rank 0 compares, array by array, with the
+    # unsharded run of the same chromosome on its own GPU — the multi-GPU path checks itself wherever it runs
+    verify = None
+    if gather_state['on'] and strong and not os.environ.get('LGMI_BENCH_NO_VERIFY'):
+        import numpy as np
+        dr = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
+        g, begins = eng.comm_gather(dr, root=0, same_batch=True)
+        dr.free()
+        if g is not None:
+            got = g.fetch()
+            g.free()
+            dr0 = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+            ref = dr0.fetch()
+            dr0.free()
+            fields = ['row_i', 'row_j', 'row_mi', 'site_n_pairs', 'site_mean_mi'] + (['row_p', 'row_exceed'] if n_shuffles else [])
+            bad = [f for f in fields if not np.array_equal(getattr(got, f), getattr(ref, f), equal_nan=(f in ('site_mean_mi', 'row_p')))]
+            verify = {'gathered_rows': int(got.n_rows), 'unsharded_rows': int(ref.n_rows), 'rank_row_begin': begins,
+                      'fields_compared': fields, 'fields_differing': bad, 'equal_to_unsharded': not bad}
+            del got, ref
+
     info = infos[-1]
     ms_count = sum(i['ms_count'] for i in infos) / len(infos)
     out = None
@@ -249,8 +272,9 @@ def main():
                          for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
                                    'ms_perm_general', 'ms_mean', 'ms_gather')},
         }
-        if world > 1:
+        if world > 1 or args.force_gather:
             out['per_rank'] = per_rank
+            out['verify'] = verify if verify is not None else 'not run (no gather, or weak scaling)'
         out['rates'] = {'emitted_pairs_per_s': rows_job * args.steps / elapsed}
         if n_shuffles:
             # the permutation stage, priced on what it really draws: a 2 x 2 row costs ONE binomial

@@ -377,8 +377,8 @@ CLI_KWARGS = dict(keep_non_spliced_read=False, min_dist_from_splice=4, min_allel
 
 
 # BASELINE.json configs[0]: "Synthetic 1-chrom BAM, 500 sites x 2k reads, --mi_calculation_only": one stretched gene,
-# 2,000 spliced reads, 110 SNP positions and up to 420 editing sites
-CFG1_REGION = ('chrC', dict(seed=300, n_reads=2000, n_snps=110, n_edits=420, err=0.002, scale=4))
+# (10.8 kb), 2,000 spliced reads (half per strand), 50 SNP positions and 420 editing sites: ~350 sites per strand block
+CFG1_REGION = ('chrC', dict(seed=300, n_reads=2000, n_snps=50, n_edits=420, err=0.0001, scale=12))
 
 
 def cli_cfg1_case():
