@@ -151,7 +151,7 @@ def test_cli_host_side_matches_the_reference(tmp_path, monkeypatch):
 def test_cli_mi_calculation_only(tmp_path):
     mi = run_cli_and_compare(tmp_path, ['--n_shuffles', '50', '--seed', '3'])
     assert list(mi.columns)[7:] == ['p_perm']
-    assert ((mi['p_perm'] >= 1 / 51) & (mi['p_perm'] <= 1)).all()
+    assert ((mi['p_perm'] >= 1 / 51 - 1e-12) & (mi['p_perm'] <= 1)).all()
 
 
 # ---------------------------------------------------------------- BASELINE.json configs[0]: 500 sites x 2k reads through the CLI
@@ -228,4 +228,4 @@ def test_cli_cfg1_mi_calculation_only(tmp_path):
     cli.main(['-b', bam, '-c', gold['contig'], '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
               '--mi_calculation_only', '--skip_strand_correction', '--n_shuffles', '100', '--seed', '5'])
     mi = check_cfg1(prefix, gold)
-    assert ((mi['p_perm'] >= 1 / 101) & (mi['p_perm'] <= 1)).all()
+    assert ((mi['p_perm'] >= 1 / 101 - 1e-12) & (mi['p_perm'] <= 1)).all()          # (read back from text)
