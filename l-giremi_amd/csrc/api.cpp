@@ -157,6 +157,8 @@ struct lgmi_dresult {
     unsigned long long* d_sum = nullptr;   // per-site sum of MI in 2^-40 fixed point (what d_mean was made from)
     bool has_p = false, has_counts = false;
     bool sharded = false;                  // per-site figures cover this shard's rows only
+    uint32_t n_shuffles = 0;
+    bool p_from_exceed = false;            // every row_p is (1 + row_exceed) / (n_shuffles + 1): the gather need not carry it
 };
 
 struct HostResult : ResultOwner {  // owner_ of a host lgmi_result: pinned buffers that go back to the context's cache
@@ -238,6 +240,7 @@ void dresult_view(const lgmi_dresult* r, DResultView* v) {
     v->p = r->has_p ? r->d_p : nullptr; v->exceed = r->has_p ? r->d_exceed : nullptr;
     v->counts = r->has_counts ? r->d_counts : nullptr;
     v->mean = r->d_mean; v->npairs = r->d_npairs; v->sum = r->d_sum;
+    v->n_shuffles = r->n_shuffles; v->p_from_exceed = r->p_from_exceed;
     v->info = r->info;
 }
 // a resident result made by the gather (comm.cpp): arrays come from the context's pool
@@ -250,6 +253,7 @@ lgmi_dresult* dresult_new_gathered(lgmi_ctx* c, const DResultView& v) {
     r->d_mean = const_cast<double*>(v.mean); r->d_npairs = const_cast<uint32_t*>(v.npairs);
     r->d_sum = const_cast<unsigned long long*>(v.sum);
     r->has_p = v.p != nullptr; r->has_counts = v.counts != nullptr;
+    r->n_shuffles = v.n_shuffles; r->p_from_exceed = v.p_from_exceed;
     r->info = v.info;
     return r;
 }
@@ -674,6 +678,8 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     res->has_p = want_p;
     res->has_counts = want_counts;
     res->sharded = sh_world > 1;
+    res->n_shuffles = prm->n_shuffles;
+    res->p_from_exceed = prm->n_shuffles > 0 && !prm->exact_2x2;
     // scratch (returned to the pool at the end of the call) and the result
     std::vector<void*> scratch;
     struct Guard {

@@ -150,11 +150,17 @@ __global__ void k_mean_from_sums(uint32_t n, const unsigned long long* __restric
     const uint32_t c = cnt[s];
     mean[s] = c ? ((double)sum[s] / MEAN_SCALE) / (double)c : __longlong_as_double(0x7ff8000000000000ll);
 }
+// p of a Monte-Carlo row is a function of its exceed count: the gather moves 4 bytes instead of 12 and the root
+// recomputes p with the expression the permutation kernels use (bit-equal)
+__global__ void k_p_from_exceed(double* __restrict__ p, const uint32_t* __restrict__ exceed, uint64_t n, uint32_t n_shuffles) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) p[k] = (1.0 + (double)exceed[k]) / ((double)n_shuffles + 1.0);
+}
 __global__ void k_fill_nan(double* __restrict__ mean, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ sum, uint64_t n) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) { mean[k] = __longlong_as_double(0x7ff8000000000000ll); cnt[k] = 0u; sum[k] = 0ull; }
 }
-enum { M_ROWS = 0, M_FLAGS, M_BASE, M_SITES, M_EXAMINED, M_GENERAL, M_N };
+enum { M_ROWS = 0, M_FLAGS, M_BASE, M_SITES, M_EXAMINED, M_GENERAL, M_SHUFFLES, M_N };
 }  // namespace
 
 extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out);
@@ -179,7 +185,8 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
     // ---- 1. everybody learns everybody's sizes and flags
     uint64_t my_meta[M_N];
     my_meta[M_ROWS] = v.n_rows;
-    my_meta[M_FLAGS] = (v.p ? 1u : 0u) | (v.counts ? 2u : 0u) | (o.same_batch ? 4u : 0u);
+    my_meta[M_FLAGS] = (v.p ? 1u : 0u) | (v.counts ? 2u : 0u) | (o.same_batch ? 4u : 0u) | (v.p && v.p_from_exceed ? 8u : 0u);
+    my_meta[M_SHUFFLES] = v.n_shuffles;
     my_meta[M_BASE] = o.site_base;
     my_meta[M_SITES] = v.n_sites;
     my_meta[M_EXAMINED] = v.info.n_examined;
@@ -191,7 +198,7 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
     uint64_t total = 0, total_sites = 0, examined = 0, general = 0;
     bool consistent = true;
     for (int r = 0; r < world; ++r) {
-        if (M(r, M_FLAGS) != M(0, M_FLAGS)) consistent = false;
+        if (M(r, M_FLAGS) != M(0, M_FLAGS) || M(r, M_SHUFFLES) != M(0, M_SHUFFLES)) consistent = false;
         if (o.same_batch && (M(r, M_BASE) != 0 || M(r, M_SITES) != M(0, M_SITES))) consistent = false;
         if (M(r, M_BASE) + M(r, M_SITES) >= 0xFFFFFFF0ull) consistent = false;
         total += M(r, M_ROWS);
@@ -208,6 +215,8 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
         return set_error(LGMI_E_ARG, "lgmi_comm_gather: ranks disagree (p / counts / same_batch flags, or same_batch with "
                                      "different site counts or a non-zero site_base)");
     const bool has_p = M(0, M_FLAGS) & 1u, has_counts = M(0, M_FLAGS) & 2u, same_batch = M(0, M_FLAGS) & 4u;
+    const bool derive_p = M(0, M_FLAGS) & 8u;          // p travels as its exceed count
+    const uint32_t n_shuffles = (uint32_t)M(0, M_SHUFFLES);
 
     // ---- 2. the root allocates; the outcome is agreed on before anything is posted
     uint32_t *gi = nullptr, *gj = nullptr, *gexc = nullptr, *gcnt = nullptr, *gnp = nullptr;
@@ -258,7 +267,7 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
             NC(g.Send(v.i, n, ncclUint32, root, comm, st));
             NC(g.Send(v.j, n, ncclUint32, root, comm, st));
             NC(g.Send(v.mi, n, ncclFloat64, root, comm, st));
-            if (has_p) { NC(g.Send(v.p, n, ncclFloat64, root, comm, st)); NC(g.Send(v.exceed, n, ncclUint32, root, comm, st)); }
+            if (has_p) { if (!derive_p) NC(g.Send(v.p, n, ncclFloat64, root, comm, st)); NC(g.Send(v.exceed, n, ncclUint32, root, comm, st)); }
             if (has_counts) NC(g.Send(v.counts, n * 9, ncclUint32, root, comm, st));
         }
         if (!same_batch && v.n_sites) {
@@ -274,7 +283,7 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
                     NC(g.Recv(gi + off, c, ncclUint32, r, comm, st));
                     NC(g.Recv(gj + off, c, ncclUint32, r, comm, st));
                     NC(g.Recv(gmi + off, c, ncclFloat64, r, comm, st));
-                    if (has_p) { NC(g.Recv(gp + off, c, ncclFloat64, r, comm, st)); NC(g.Recv(gexc + off, c, ncclUint32, r, comm, st)); }
+                    if (has_p) { if (!derive_p) NC(g.Recv(gp + off, c, ncclFloat64, r, comm, st)); NC(g.Recv(gexc + off, c, ncclUint32, r, comm, st)); }
                     if (has_counts) NC(g.Recv(gcnt + 9 * off, c * 9, ncclUint32, r, comm, st));
                 }
                 if (!same_batch && sn) {
@@ -311,8 +320,10 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
     };
     d2d(gi + off, v.i, n * 4); d2d(gj + off, v.j, n * 4); d2d(gmi + off, v.mi, n * 8);
-    if (has_p) { d2d(gp + off, v.p, n * 8); d2d(gexc + off, v.exceed, n * 4); }
+    if (has_p) { if (!derive_p) d2d(gp + off, v.p, n * 8); d2d(gexc + off, v.exceed, n * 4); }
     if (has_counts) d2d(gcnt + 9 * off, v.counts, n * 36);
+    if (has_p && derive_p && total)                        // every row, the root's own included
+        hipLaunchKernelGGL(k_p_from_exceed, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, gp, gexc, total, n_shuffles);
     if (same_batch && v.n_sites)
         hipLaunchKernelGGL(k_mean_from_sums, dim3((uint32_t)((v.n_sites + 255) / 256)), dim3(256), 0, st,
                            (uint32_t)v.n_sites, gsum, gnp, gmean);
@@ -330,6 +341,7 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
     gv.n_rows = total; gv.n_sites = total_sites;
     gv.i = gi; gv.j = gj; gv.mi = gmi; gv.p = gp; gv.exceed = gexc; gv.counts = gcnt;
     gv.mean = gmean; gv.npairs = gnp; gv.sum = gsum;
+    gv.n_shuffles = n_shuffles; gv.p_from_exceed = derive_p;
     gv.info = v.info;                       // stage times stay the root's own
     gv.info.n_rows = total; gv.info.n_examined = examined; gv.info.n_general_rows = general;
     *out = dresult_new_gathered(ctx, gv);

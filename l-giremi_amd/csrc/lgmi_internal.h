@@ -71,6 +71,8 @@ struct DResultView {
     const uint32_t* i = nullptr; const uint32_t* j = nullptr; const double* mi = nullptr;
     const double* p = nullptr; const uint32_t* exceed = nullptr; const uint32_t* counts = nullptr;
     const double* mean = nullptr; const uint32_t* npairs = nullptr; const unsigned long long* sum = nullptr;
+    uint32_t n_shuffles = 0;      // with p_from_exceed: row_p == (1 + row_exceed) / (n_shuffles + 1) for every row
+    bool p_from_exceed = false;
     lgmi_run_info info = {};
 };
 
