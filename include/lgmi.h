@@ -239,7 +239,9 @@ int  lgmi_ecdf(lgmi_ctx* ctx, uint64_t n_ref, const double* ref, uint64_t n_quer
 /* ---- sharding plan, host only (no GPU touched): what lgmi_run_device() would do for (shard_rank, shard_world).
  * Lets a launcher balance / inspect shards and lets CPU-only tests check that every row of a shard is fed by
  * one of the shard's count tiles.  A work item is (site i, segment g): the partners number
- * [g * LGMI_EMIT_SEG, (g+1) * LGMI_EMIT_SEG) of site i's row, rows being in reference order. */
+ * [g * LGMI_EMIT_SEG, (g+1) * LGMI_EMIT_SEG) of site i's row, rows being in reference order.  Rows of x sites (every
+ * site, or the het_snp sites when het_only) are cut into such segments; the row of any other site (its partners are
+ * the later x sites) is one item, segment 0. */
 #define LGMI_EMIT_SEG 8192u
 typedef struct lgmi_shard_plan {
     uint64_t n_items_total;      /* work items of the whole batch                                  */

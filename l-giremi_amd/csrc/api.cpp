@@ -694,6 +694,8 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if ((rc = salloc((void**)&d_plans, pl.plans.size() * sizeof(BlockPlan)))) return rc;
     if ((rc = salloc((void**)&d_xlist, pl.xlist.size() * 4))) return rc;
     if ((rc = salloc((void**)&d_items, std::max<size_t>(n_items, 1) * sizeof(uint2)))) return rc;
+    uint2* d_units = nullptr;
+    if ((rc = salloc((void**)&d_units, std::max<size_t>(pl.units.size(), 1) * sizeof(uint2)))) return rc;
     if ((rc = salloc((void**)&d_ylist, pl.ylist.size() * 4))) return rc;
     if ((rc = salloc((void**)&d_smap, pl.smap.size() * sizeof(SiteMap)))) return rc;
     if ((rc = salloc((void**)&d_tiles, pl.tiles.size() * sizeof(Tile)))) return rc;
@@ -720,6 +722,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(h2d(d_plans, pl.plans.data(), pl.plans.size() * sizeof(BlockPlan)));
     HIPCHK(h2d(d_xlist, pl.xlist.data(), pl.xlist.size() * 4));
     HIPCHK(h2d(d_items, pl.items.data() + pl.item_begin, n_items * sizeof(uint2)));
+    HIPCHK(h2d(d_units, pl.units.data(), pl.units.size() * sizeof(uint2)));
     HIPCHK(h2d(d_ylist, pl.ylist.data(), pl.ylist.size() * 4));
     HIPCHK(h2d(d_smap, pl.smap.data(), pl.smap.size() * sizeof(SiteMap)));
     HIPCHK(h2d(d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)));
@@ -750,6 +753,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     ea.type = db->d.d_type; ea.tri = db->d.d_tri;
     ea.slots = d_slots;
     ea.n_items = (uint32_t)n_items; ea.items = d_items;
+    ea.n_units = (uint32_t)pl.units.size(); ea.units = d_units;
     ea.row_cnt = d_rowcnt; ea.row_start = d_rowstart;
     ea.site_sum = d_sum; ea.site_cnt = d_cnt; ea.err_flag = d_err; ea.word_pairs = d_wordpairs;
     launch_emit_count(st, ea);

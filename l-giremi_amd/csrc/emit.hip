@@ -44,13 +44,11 @@ __device__ __forceinline__ double mi_from_table(const uint32_t t[9]) {
     return sum > 0.0 ? sum : 0.0;
 }
 
+// one work item = up to EMIT_SEG consecutive partners of one site row, 64 per trip (x sites: their partners j > i
+// are consecutive sites, so the slots of a trip are consecutive columns of one slot-matrix row)
 template <int PASS>
-__global__ __launch_bounds__(256) void k_emit(EmitArgs a)
+__device__ __forceinline__ void emit_item(const EmitArgs& a, uint32_t item, uint32_t lane, uint32_t* __restrict__ cst)
 {
-    __shared__ uint32_t cstage[4][64 * 9];          // pass 2: one wave's 3 x 3 tables, row-major, before the coalesced store
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t item = blockIdx.x * 4u + wv;
-    if (item >= a.n_items) return;
     const uint32_t i = a.items[item].x, seg = a.items[item].y;
     const SiteMap mi_ = a.smap[i];
     const BlockPlan bp = a.plans[mi_.block];
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
                 a.out_mi[r] = mi;
                 if (a.out_counts) {     // staged through LDS below: 9 dwords per row at a 36-byte stride are partial-line stores
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) cstage[wv][9u * prefix + k] = T[k];
+                    for (int k = 0; k < 9; ++k) cst[9u * prefix + k] = T[k];
                 }
                 const unsigned long long fx = (unsigned long long)__double2ll_rn(mi * MEAN_SCALE);
                 my_sum += fx;
@@ -176,7 +174,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const uint32_t idx = 64u * k + lane;
-                    if (idx < n_dw) dst[idx] = cstage[wv][idx];
+                    if (idx < n_dw) dst[idx] = cst[idx];
                 }
                 __builtin_amdgcn_wave_barrier();     // the next trip's stores stay behind these loads
             }
@@ -201,13 +199,178 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a)
     }
 }
 
+// A quad = up to four sites that are NOT x sites and whose slot-matrix columns are the four slots of one 64-byte
+// line (consecutive, aligned y columns).  Their partners are the x sites after them: a COLUMN walk of the row-major slot
+// matrix.  One site per wave read one 16-byte slot per cache line; here lane = (site of the quad, x rank inside the trip),
+// so the four slots of a line are read by four neighbouring lanes and every fetched line is used whole.  Rows of a site
+// still come out in increasing partner order (lanes of a site are ordered by x rank) at that site's own row offset.
+template <int PASS>
+__device__ __forceinline__ void emit_quad(const EmitArgs& a, uint32_t first_item, uint32_t n_it, uint32_t lane,
+                                          uint32_t* __restrict__ cst)
+{
+    const uint32_t sa = lane & 3u, t = lane >> 2;
+    const bool has_site = sa < n_it;
+    const uint32_t item = first_item + (has_site ? sa : 0u);
+    const uint32_t i = a.items[item].x;
+    const SiteMap mi_ = a.smap[i];
+    const BlockPlan bp = a.plans[mi_.block];                 // one block per unit (the planner never mixes blocks)
+    const uint32_t q0 = mi_.xnext;                           // the first x rank after site i
+    const Col ci = a.cols[i];
+    const uint32_t i_w0 = ci.w0, i_w1 = ci.w0 + ci.nw;
+    const bool tri_i = a.tri[i] != 0;
+    uint32_t rmin = has_site ? q0 : 0xFFFFFFFFu;             // the quad's first x rank: every group of four lanes holds all sites
+    rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, 1));
+    rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, 2));
+    const unsigned long long site_mask = 0x1111111111111111ull << sa;
+    uint64_t base_row = 0;
+    if (PASS == 2 && has_site) base_row = a.row_start[item];
+    uint32_t running = 0;                                    // rows of this lane's site so far (equal in all its lanes)
+    unsigned long long wsum = 0ull, my_sum = 0ull;
+
+    for (uint32_t rb = rmin; rb < bp.nxs; rb += 16u) {       // wave-uniform bounds
+        const uint32_t r = rb + t;
+        bool valid = false;
+        uint32_t j = 0, n_common = 0;
+        uint64_t slot = 0;
+        uint4 sl = make_uint4(0u, 0u, 0u, 0u);
+        SiteMap mj = mi_;
+        if (has_site && r >= q0 && r < bp.nxs) {
+            j = a.xlist[bp.xl_off + r];                      // real x sites are the first nxs rows of the x list: xrow(j) == r
+            const Col cj = a.cols[j];
+            const uint32_t lo = max(i_w0, cj.w0), hi = min(i_w1, cj.w0 + cj.nw);
+            mj = a.smap[j];
+            if (PASS == 1 && lo < hi) wsum += hi - lo;
+            if (lo < hi) {
+                slot = bp.slot_base + (uint64_t)r * bp.ny_pad + mi_.ycol;
+                sl = a.slots[slot];
+                n_common = sl.x;
+            }
+            valid = (n_common >= a.min_common);
+        }
+        const unsigned long long ball = __ballot(valid);
+        const unsigned long long mine = ball & site_mask;
+        const uint32_t cnt_mine = (uint32_t)__popcll(mine);
+        if (PASS == 2) {
+            unsigned long long fx = 0ull;
+            if (valid) {
+                const uint32_t prefix = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+                const uint64_t ro = base_row + running + prefix;
+                uint32_t T[9];
+                if (n_common == 0) {  // only reachable with min_common == 0
+                    *a.err_flag = 1;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) T[k] = 0;
+                } else {
+                    // x = row site = j, y = col site = i (see emit_item for the derivation of the nine cells)
+                    const bool tri_x = a.tri[j] != 0, tri_y = tri_i;
+                    const uint32_t N = n_common, r2 = sl.y, c2 = sl.z, n22 = sl.w;
+                    uint32_t R1 = N - r2, C1 = N - c2, t12 = c2 - n22, t21 = r2 - n22;
+                    if (tri_x) {
+                        const uint4 sp = a.slots[bp.slot_base + (uint64_t)mj.prow * bp.ny_pad + mi_.ycol];
+                        R1 = sp.y;
+                        t12 = sp.w;
+                    }
+                    if (tri_y) {
+                        const uint4 sp = a.slots[bp.slot_base + (uint64_t)r * bp.ny_pad + mi_.pcol];
+                        C1 = sp.z;
+                        t21 = sp.w;
+                    }
+                    uint32_t t11;
+                    if (tri_x && tri_y) t11 = a.slots[bp.slot_base + (uint64_t)mj.prow * bp.ny_pad + mi_.pcol].w;
+                    else if (tri_y) t11 = C1 - t21;
+                    else t11 = R1 - t12;
+                    const uint32_t R0 = N - r2 - R1;
+                    const uint32_t t20 = r2 - n22 - t21, t10 = R1 - t12 - t11;
+                    const uint32_t t02 = c2 - n22 - t12, t01 = C1 - t21 - t11;
+                    const uint32_t t00 = R0 - t01 - t02;
+                    // rows are (i, j) ordered and x is j: the transpose
+                    T[0] = t00; T[1] = t10; T[2] = t20;
+                    T[3] = t01; T[4] = t11; T[5] = t21;
+                    T[6] = t02; T[7] = t12; T[8] = n22;
+                }
+                const double mi = (n_common == 0) ? 0.0 : mi_from_table(T);
+                a.out_i[ro] = i;
+                a.out_j[ro] = j;
+                a.out_mi[ro] = mi;
+                if (a.out_counts) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) cst[144u * sa + 9u * prefix + k] = T[k];
+                }
+                fx = (unsigned long long)__double2ll_rn(mi * MEAN_SCALE);
+                my_sum += fx;
+            }
+            {
+                // the partner's side of the mean: the four lanes of an x rank hold the same partner j — one atomic for
+                // the four (same-address atomics of one wave serialise), integer sums so the total is the same
+                unsigned long long f4 = fx;
+                uint32_t c4 = valid ? 1u : 0u;
+                f4 += __shfl_xor(f4, 1); c4 += (uint32_t)__shfl_xor((int)c4, 1);
+                f4 += __shfl_xor(f4, 2); c4 += (uint32_t)__shfl_xor((int)c4, 2);
+                if (sa == 0u && c4) {
+                    const uint32_t jq = a.xlist[bp.xl_off + r];
+                    atomicAdd(&a.site_sum[jq], f4);
+                    atomicAdd(&a.site_cnt[jq], c4);
+                }
+            }
+            if (a.out_counts) {
+                // each site's tables of this trip are consecutive rows of that site: four contiguous runs
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned long long row_here = base_row + running;      // of this lane's site
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t n_dw = 9u * (uint32_t)__popcll(ball & (0x1111111111111111ull << s));
+                    const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)row_here, s);
+                    const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(row_here >> 32), s);
+                    uint32_t* dst = a.out_counts + 9ull * (((unsigned long long)hi32 << 32) | lo32);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t idx = 64u * k + lane;
+                        if (idx < n_dw) dst[idx] = cst[144u * s + idx];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        running += cnt_mine;
+    }
+    if (PASS == 1) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+        if (t == 0u && has_site) a.row_cnt[item] = running;
+        if (lane == 0 && wsum) atomicAdd(a.word_pairs, wsum);
+    } else {
+        // the i side of the mean: sum over the lanes of a site (xor 4, 8, 16, 32 keeps the site)
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) my_sum += __shfl_xor(my_sum, o);
+        if (t == 0u && has_site && running) {
+            atomicAdd(&a.site_sum[i], my_sum);
+            atomicAdd(&a.site_cnt[i], running);
+        }
+    }
+}
+
+// one wave per work unit: an x site's item, or a quad of other sites' items (units are built on the host, plan.cpp)
+template <int PASS>
+__global__ __launch_bounds__(256) void k_emit(EmitArgs a)
+{
+    __shared__ uint32_t cstage[4][64 * 9];          // pass 2: one wave's 3 x 3 tables, row-major, before the coalesced store
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t u = blockIdx.x * 4u + wv;
+    if (u >= a.n_units) return;
+    const uint2 unit = a.units[u];                  // (first item, items in the unit | kind << 16)
+    if (unit.y >> 16) emit_quad<PASS>(a, unit.x, unit.y & 0xFFFFu, lane, cstage[wv]);
+    else emit_item<PASS>(a, unit.x, lane, cstage[wv]);
+}
+
 void launch_emit_count(hipStream_t st, const EmitArgs& a) {
-    if (!a.n_items) return;
-    hipLaunchKernelGGL(k_emit<1>, dim3((a.n_items + 3) / 4), dim3(256), 0, st, a);
+    if (!a.n_units) return;
+    hipLaunchKernelGGL(k_emit<1>, dim3((a.n_units + 3) / 4), dim3(256), 0, st, a);
 }
 void launch_emit_write(hipStream_t st, const EmitArgs& a) {
-    if (!a.n_items) return;
-    hipLaunchKernelGGL(k_emit<2>, dim3((a.n_items + 3) / 4), dim3(256), 0, st, a);
+    if (!a.n_units) return;
+    hipLaunchKernelGGL(k_emit<2>, dim3((a.n_units + 3) / 4), dim3(256), 0, st, a);
 }
 
 // exclusive scan of n u32 counts into n+1 u64 offsets; one workgroup, each thread

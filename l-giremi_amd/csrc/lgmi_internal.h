@@ -128,6 +128,8 @@ struct EmitArgs {
     // rows of x sites (up to the whole block) spread over many waves; items are in (site, segment) order
     uint32_t n_items;
     const uint2* items;       // [n_items] (site, segment)
+    uint32_t n_units;         // one wave per unit: an x site's item, or up to four other sites sharing a line of slots
+    const uint2* units;       // [n_units] (first item, n items | kind << 16); kind 1 = quad
     uint32_t* row_cnt;        // [n_items]   pass 1 out
     const uint64_t* row_start;// [n_items+1] pass 2 in
     uint32_t* out_i; uint32_t* out_j; double* out_mi; uint32_t* out_counts; // pass 2 out

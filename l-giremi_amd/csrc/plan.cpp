@@ -76,11 +76,15 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         // examined pairs: pairs a wave of the emit kernel will look at
         const uint64_t W = std::max<uint64_t>(1, ((uint64_t)in.block_n_reads[b] + 63u) / 64u);
         for (uint32_t s = sb; s < se; ++s) {
-            const uint32_t ncand = (pl.smap[s].xrow != NONE) ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
+            const bool is_x = pl.smap[s].xrow != NONE;
+            const uint32_t ncand = is_x ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
             pl.n_examined_total += ncand;
-            for (uint32_t g = 0; g * EMIT_SEG < ncand; ++g) {
+            // an x site's row is cut into segments of EMIT_SEG partners; another site's row (at most nxs partners: a
+            // column walk of the slot matrix, done four sites at a time, emit.hip: emit_quad) is one item
+            const uint32_t seg_len = is_x ? EMIT_SEG : 0xFFFFFFFFu;
+            for (uint32_t g = 0; (uint64_t)g * seg_len < ncand; ++g) {
                 pl.items.push_back(make_uint2(s, g));
-                const uint32_t n_in_seg = std::min<uint32_t>(EMIT_SEG, ncand - g * EMIT_SEG);
+                const uint32_t n_in_seg = std::min<uint32_t>(seg_len, ncand - g * (is_x ? EMIT_SEG : 0u));
                 item_ncand.push_back(n_in_seg);
                 item_cost.push_back((uint64_t)n_in_seg * W);
                 item_block.push_back((uint32_t)b);
@@ -104,6 +108,20 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         pl.item_end = (shard_rank + 1u == shard_world) ? n_items : k;
     }
     for (uint64_t k = pl.item_begin; k < pl.item_end; ++k) pl.n_examined += item_ncand[k];
+    // emit work units over the shard's items (indices relative to item_begin): an x site's item alone, or up to four
+    // consecutive items of other sites whose slot-matrix columns share one aligned group of four (one 64-byte line)
+    for (uint64_t k = pl.item_begin; k < pl.item_end;) {
+        const SiteMap& m = pl.smap[pl.items[k].x];
+        if (m.xrow != NONE) { pl.units.push_back(make_uint2((uint32_t)(k - pl.item_begin), 1u)); ++k; continue; }
+        uint32_t n = 1;
+        while (n < 4u && k + n < pl.item_end) {
+            const SiteMap& m2 = pl.smap[pl.items[k + n].x];
+            if (m2.xrow != NONE || m2.block != m.block || (m2.ycol >> 2) != (m.ycol >> 2) || m2.ycol != m.ycol + n) break;
+            ++n;
+        }
+        pl.units.push_back(make_uint2((uint32_t)(k - pl.item_begin), n | (1u << 16)));
+        k += n;
+    }
 
     // ---- pass 2: count tiles, block by block; a sharded run keeps the tiles its items read from
     std::vector<uint32_t> xmin, xmax, ymin, ymax, xbefore, tribefore, trix_before;
@@ -155,8 +173,8 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                         if (mi.prow != NONE) need.mark(mi.prow, mi.prow + 1u, c0[part], c1[part]);
                     }
                 } else {
-                    const uint32_t ncand = nxs - mi.xnext;
-                    const uint32_t xa = mi.xnext + g * EMIT_SEG, xb = mi.xnext + std::min(ncand, (g + 1u) * EMIT_SEG);
+                    (void)g;                                     // (always 0: one item per such site)
+                    const uint32_t xa = mi.xnext, xb = nxs;
                     const uint32_t pa = nxs + trix_before[xa], pb = nxs + trix_before[xb];
                     need.mark(xa, xb, mi.ycol, mi.ycol + 1u);
                     need.mark(pa, pb, mi.ycol, mi.ycol + 1u);

@@ -35,6 +35,7 @@ struct Plan {
     uint32_t op_max_steps = 0;
     std::vector<uint2> items;       // emit work items of the WHOLE batch: (site, segment of EMIT_SEG partners), in row order
     uint64_t item_begin = 0, item_end = 0;   // this shard's items
+    std::vector<uint2> units;       // emit work units of this shard: (first item - item_begin, n items | kind << 16)
     uint64_t total_slots = 0, n_examined = 0, n_examined_total = 0, bytes_in = 0;
 };
 

@@ -19,7 +19,7 @@ def item_of_rows(pb, plan, row_i, row_j):
     i_is_x = xrow[i] != NONE
     q = np.where(i_is_x, j - i - 1, xrow[j] - xnext[i])
     assert (q >= 0).all()
-    seg = q // EMIT_SEG
+    seg = np.where(i_is_x, q // EMIT_SEG, 0)            # only x-site rows are cut into segments
     key = {(int(s), int(g)): k for k, (s, g) in enumerate(zip(plan['item_site'], plan['item_seg']))}
     return np.array([key[(int(a), int(b))] for a, b in zip(i, seg)], np.int64)
 
