@@ -372,11 +372,23 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
         } else {
             kind = 3;
 #if !(LGMI_PABL & 16)
-            if (n_shuffles) gen_list[atomicAdd(gen_count, 1u)] = (uint32_t)r;
-            else { out_exceed[r] = LGMI_EXCEED_EXACT; out_p[r] = __longlong_as_double(0x7ff8000000000000ll); }   // exact_2x2 only: no estimate
+            if (!n_shuffles) { out_exceed[r] = LGMI_EXCEED_EXACT; out_p[r] = __longlong_as_double(0x7ff8000000000000ll); }   // exact_2x2 only: no estimate
 #endif
         }
     }
+#if !(LGMI_PABL & 16)
+    if (n_shuffles) {
+        // queue the larger tables for k_perm_general: one atomic per wave, not one per row (millions of atomics on one
+        // address serialise in the L2); the order inside the queue is free
+        const unsigned long long qb = __ballot(kind == 3);
+        if (qb) {
+            uint32_t base = 0u;
+            if (lane == 0u) base = atomicAdd(gen_count, (unsigned int)__popcll(qb));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (kind == 3) gen_list[base + (uint32_t)__popcll(qb & ((1ull << lane) - 1ull))] = (uint32_t)r;
+        }
+    }
+#endif
     // ---- phase B: exact mass of the "as or more extreme" set, or of its complement when that is the short side.
     //      Each row lists up to two ranges of k; the ranges are cut into units of 64 values and the units of the
     //      wave's 64 rows are dealt to the lanes 64 at a time, so every lane has the same amount of work whatever
