@@ -141,6 +141,10 @@ def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     group = group_from_env()                                   # plain sockets; a no-op object at N = 1
     device = int(os.environ.get('LGMI_BENCH_DEVICE', local_rank))
+    import ctypes
+    n_dev = ctypes.c_int(0)
+    if lgmi._lib.load().lgmi_device_count(ctypes.byref(n_dev)) == 0 and n_dev.value > 0:
+        device %= n_dev.value                                  # a launcher that narrows the visible devices per rank
 
     eng = lgmi.Engine(device)
     wl = WORKLOADS[args.workload]
