@@ -321,6 +321,23 @@ def test_hardware_exp_stays_inside_the_guard(engine):
     np.testing.assert_array_equal(fast, det)
 
 
+def test_row_arrays_sized_exactly_or_by_their_bound(engine, monkeypatch):
+    """lgmi_run_device sizes the row arrays by the examined-pair bound when that fits (no host wait between the two emit
+    passes) and by one read-back of the row count otherwise (LGMI_EXACT_ROW_ALLOC forces it): same results either way,
+    on a banded batch where far fewer rows are emitted than examined"""
+    from lgmi.synth import banded_chromosome
+    from oracle import c_oracle
+    pb = banded_chromosome(3000, 12000, seed=5)
+    ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=20, seed=8)
+    a = engine.run(pb, min_common=6, het_only=True, n_shuffles=20, seed=8, emit_counts=True)
+    monkeypatch.setenv('LGMI_EXACT_ROW_ALLOC', '1')
+    b = engine.run(pb, min_common=6, het_only=True, n_shuffles=20, seed=8, emit_counts=True)
+    assert a.n_rows < 0.5 * a.info['n_examined']
+    for res in (a, b):
+        assert_same_as_oracle(res, ora)
+        assert_perm_same(res, ora, 20)
+
+
 def test_permutation_seed_changes_draws_not_counts(engine):
     pb = random_batch(4242, n_blocks=1, P=(30, 30), R=(300, 300))
     a = engine.run(pb, min_common=5, n_shuffles=500, seed=1, emit_counts=True)
