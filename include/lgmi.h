@@ -110,7 +110,7 @@ typedef struct lgmi_params {
     uint8_t  reserved0;    /* must be 0 */
     /* tile-level sharding of ONE batch over several GPUs (the reference's analogue is the chunked
      * Pool.map of script/giremi.py:367-394): the result rows, in reference order, are cut into shard_world
-     * contiguous, cost-balanced ranges; this call computes range shard_rank only (count tiles that feed it,
+     * contiguous, cost-balanced ranges (cost model: csrc/plan.cpp); this call computes range shard_rank only (count tiles that feed it,
      * its rows, their p-values, its share of the per-site sums).  Concatenating the shards' rows in rank
      * order gives exactly the unsharded rows.  0/0 or x/1 = unsharded. */
     uint16_t shard_rank;
@@ -264,8 +264,10 @@ typedef struct lgmi_shard_plan {
     const uint32_t* site_xnext;  /* [n_sites] number of x sites of the block at or before the site */
     void* owner_;
 } lgmi_shard_plan;
-int  lgmi_plan_shard(const lgmi_batch* batch, int het_only, uint32_t shard_rank, uint32_t shard_world,
-                     lgmi_shard_plan* out);
+/* n_shuffles is the lgmi_params value the run will use: it only prices the work items (a pair with a tri-allelic
+ * site costs n_shuffles table draws), i.e. it moves the shard boundaries, never the rows */
+int  lgmi_plan_shard(const lgmi_batch* batch, int het_only, uint32_t n_shuffles, uint32_t shard_rank,
+                     uint32_t shard_world, lgmi_shard_plan* out);
 void lgmi_shard_plan_free(lgmi_shard_plan* plan);
 
 /* device self-test of the one place where the permutation kernels use the hardware's f32 exp (perm.hip: le_exp):

@@ -542,8 +542,8 @@ extern "C" void lgmi_shard_plan_free(lgmi_shard_plan* p) {
     memset(p, 0, sizeof *p);
 }
 
-extern "C" int lgmi_plan_shard(const lgmi_batch* b, int het_only, uint32_t shard_rank, uint32_t shard_world,
-                               lgmi_shard_plan* out) {
+extern "C" int lgmi_plan_shard(const lgmi_batch* b, int het_only, uint32_t n_shuffles, uint32_t shard_rank,
+                               uint32_t shard_world, lgmi_shard_plan* out) {
     if (!out) return fail(LGMI_E_ARG, "out is NULL");
     memset(out, 0, sizeof *out);
     int rc = validate_batch(b);
@@ -578,8 +578,8 @@ extern "C" int lgmi_plan_shard(const lgmi_batch* b, int het_only, uint32_t shard
     int ck; uint32_t xg;
     plan_env(&ck, &xg);
     Plan whole, mine;
-    build_plan(in, het_only != 0, 0, 1, ck, xg, whole);
-    build_plan(in, het_only != 0, shard_rank, shard_world, ck, xg, mine);
+    build_plan(in, het_only != 0, 0, 1, ck, xg, n_shuffles, whole);
+    build_plan(in, het_only != 0, shard_rank, shard_world, ck, xg, n_shuffles, mine);
     ShardPlanOwner* o = new ShardPlanOwner();
     for (const uint2& it : mine.items) { o->item_site.push_back(it.x); o->item_seg.push_back(it.y); }
     for (int kind = 0; kind < 2; ++kind)
@@ -661,7 +661,7 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     {
         int ck; uint32_t xg;
         plan_env(&ck, &xg);
-        build_plan(plan_input(db), prm->het_only != 0, sh_rank, sh_world, ck, xg, pl);
+        build_plan(plan_input(db), prm->het_only != 0, sh_rank, sh_world, ck, xg, prm->n_shuffles, pl);
     }
     const float ms_plan_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
     const size_t n_items = (size_t)(pl.item_end - pl.item_begin);

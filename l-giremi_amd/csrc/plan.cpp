@@ -30,8 +30,14 @@ struct NeedMap {                       // which (x tile, y tile) of a block this
 
 }  // namespace
 
+// Cost of a pair in units of one pair-word of the count kernel, from the north-star stage times: count
+// 97 ms for 4.5e8 pairs x 3,125 words; emit + the 2 x 2 permutation path 85 ms for 4.5e8 pairs (22 ms without
+// p-values); 303 ms for 1.74e10 table draws of the pairs whose table is larger than 2 x 2 — approximated here by
+// "one of the two sites has a third class" (the tri flag).
+static const uint64_t COST_PAIR = 2750, COST_PAIR_NO_P = 700, COST_DRAW = 250;
+
 void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_t shard_world, int count_kernel,
-                uint32_t xg_override, Plan& pl)
+                uint32_t xg_override, uint32_t n_shuffles, Plan& pl)
 {
     if (shard_world == 0) { shard_world = 1; shard_rank = 0; }
     const bool sharded = shard_world > 1;
@@ -75,6 +81,18 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         pl.plans[b] = bp;
         // examined pairs: pairs a wave of the emit kernel will look at
         const uint64_t W = std::max<uint64_t>(1, ((uint64_t)in.block_n_reads[b] + 63u) / 64u);
+        const uint64_t pair_cost = W + (n_shuffles ? COST_PAIR : COST_PAIR_NO_P);
+        // tri sites among the first k sites of the block / among the first k x sites: how many of an item's partners
+        // bring the Monte-Carlo path with them
+        std::vector<uint32_t> tri_pre(P + 1, 0), trix_pre(nxs + 1, 0);
+        if (sharded && n_shuffles) {
+            uint32_t xr = 0;
+            for (uint32_t k = 0; k < P; ++k) {
+                const bool t = in.tri[sb + k] != 0;
+                tri_pre[k + 1] = tri_pre[k] + (t ? 1u : 0u);
+                if (pl.smap[sb + k].xrow != NONE) { trix_pre[xr + 1] = trix_pre[xr] + (t ? 1u : 0u); ++xr; }
+            }
+        }
         for (uint32_t s = sb; s < se; ++s) {
             const bool is_x = pl.smap[s].xrow != NONE;
             const uint32_t ncand = is_x ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
@@ -84,9 +102,16 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
             const uint32_t seg_len = is_x ? EMIT_SEG : 0xFFFFFFFFu;
             for (uint32_t g = 0; (uint64_t)g * seg_len < ncand; ++g) {
                 pl.items.push_back(make_uint2(s, g));
-                const uint32_t n_in_seg = std::min<uint32_t>(seg_len, ncand - g * (is_x ? EMIT_SEG : 0u));
+                const uint32_t q_a = is_x ? g * EMIT_SEG : 0u;
+                const uint32_t n_in_seg = std::min<uint32_t>(seg_len, ncand - q_a);
+                uint64_t n_general = 0;
+                if (sharded && n_shuffles) {
+                    if (in.tri[s]) n_general = n_in_seg;
+                    else if (is_x) n_general = tri_pre[s + 1 + q_a + n_in_seg - sb] - tri_pre[s + 1 + q_a - sb];
+                    else n_general = trix_pre[nxs] - trix_pre[pl.smap[s].xnext];
+                }
                 item_ncand.push_back(n_in_seg);
-                item_cost.push_back((uint64_t)n_in_seg * W);
+                item_cost.push_back((uint64_t)n_in_seg * pair_cost + n_general * n_shuffles * COST_DRAW);
                 item_block.push_back((uint32_t)b);
             }
         }

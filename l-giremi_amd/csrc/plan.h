@@ -41,7 +41,9 @@ struct Plan {
 
 // count_kernel: 0 auto, 1 VALU popcount only, 2 matrix cores only, 3 matrix cores with int8 operands only;
 // xg_override: 0 = default group of x-tile rows that sweep the y tiles together
+// n_shuffles only prices the work items (a pair with a tri-allelic site costs n_shuffles table draws): it moves the
+// shard boundaries, never the rows
 void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_t shard_world, int count_kernel,
-                uint32_t xg_override, Plan& pl);
+                uint32_t xg_override, uint32_t n_shuffles, Plan& pl);
 
 }  // namespace lgmi

@@ -103,7 +103,7 @@ SYMBOLS = {
     'lgmi_result_free': (None, [C.POINTER(Result)]),
     'lgmi_site_mean': (C.c_int, [VP, C.c_uint64, u32p, u32p, f64p, C.c_uint64, f64p, u32p]),
     'lgmi_ecdf': (C.c_int, [VP, C.c_uint64, f64p, C.c_uint64, f64p, f64p]),
-    'lgmi_plan_shard': (C.c_int, [C.POINTER(Batch), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(ShardPlan)]),
+    'lgmi_plan_shard': (C.c_int, [C.POINTER(Batch), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShardPlan)]),
     'lgmi_shard_plan_free': (None, [C.POINTER(ShardPlan)]),
     'lgmi_ctx_synchronize': (C.c_int, [VP]),
     'lgmi_selftest_le_exp': (C.c_int, [VP, C.c_uint64, f64p, f64p, u8p, u8p, f64p, f64p]),

@@ -60,12 +60,12 @@ def make_params(min_common=5, n_shuffles=0, seed=0, het_only=True, emit_counts=F
                        1 if het_only else 0, 1 if emit_counts else 0, 1 if exact_2x2 else 0, 0, rank, world)
 
 
-def plan_shard(batch: PackedBatch, het_only=True, shard=(0, 1)) -> dict:
+def plan_shard(batch: PackedBatch, het_only=True, shard=(0, 1), n_shuffles=0) -> dict:
     """The planner's view of one shard, computed on the host (no GPU): item range, examined pairs, count tiles
     and the slot-matrix coordinates of every site (include/lgmi.h: lgmi_plan_shard)."""
     lib = _lib.load()
     st, sp = batch.as_struct(), _lib.ShardPlan()
-    _lib.check(lib.lgmi_plan_shard(C.byref(st), 1 if het_only else 0, int(shard[0]), int(shard[1]), C.byref(sp)))
+    _lib.check(lib.lgmi_plan_shard(C.byref(st), 1 if het_only else 0, int(n_shuffles), int(shard[0]), int(shard[1]), C.byref(sp)))
     try:
         def a(ptr, n):
             return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n and ptr else np.zeros(0, np.uint32)
