@@ -298,22 +298,25 @@ class BamReader:
             names = [pool[noff[k]:noff[k + 1]].decode() for k in range(nr)]
         finally:
             self._lib.lgio_pileup_free(C.byref(pl))
+        # columns are views: the caller looks at the names / bases of the few columns that are candidate sites
+        # (mismatch.py:160-190) and only at the position of all the others
         for c in range(nc):
-            a, b = int(off[c]), int(off[c + 1])
-            yield PileupColumn(int(pos[c]), [names[r] for r in ridx[a:b]],
-                               [chr(x) if x else '' for x in base[a:b]])
+            yield PileupColumn(int(pos[c]), names, ridx, base, int(off[c]), int(off[c + 1]))
 
 
 class PileupColumn:
-    def __init__(self, pos, names, bases):
-        self.pos, self._names, self._bases = pos, names, bases
-        self.reference_pos = pos
+    __slots__ = ('pos', 'reference_pos', '_names', '_ridx', '_base', '_a', '_b')
+
+    def __init__(self, pos, names, ridx=None, base=None, a=0, b=0):
+        self.pos = self.reference_pos = pos
+        self._names, self._ridx, self._base, self._a, self._b = names, ridx, base, a, b
 
     def get_query_names(self):
-        return list(self._names)
+        names = self._names
+        return [names[r] for r in self._ridx[self._a:self._b].tolist()]
 
     def get_query_sequences(self):
-        return list(self._bases)
+        return [chr(x) if x else '' for x in self._base[self._a:self._b]]
 
 
 def _bgzf_block(payload: bytes) -> bytes:

@@ -133,7 +133,8 @@ def get_region_mismatches_with_filters(chromosome, start_pos, end_pos, sam, geno
         if len(sites) == 0:
             continue
         # ---- 2. reads that carry the reference base, from the pile-up (:160-190)
-        known = sorted(sites.keys())
+        known = set(sites.keys())                        # (the reference tests membership in a sorted LIST, :159-167:
+        #                                                  the same answer in time linear in the number of sites per column)
         for column in sam.pileup(contig=chromosome, start=start_pos, stop=end_pos):
             pos = column.pos
             ref = sites[pos]['ref']                      # creates an empty site for a new position
