@@ -16,6 +16,7 @@ of the reference (src/giremi/cs.py:110-363) is not part of this path.
 from __future__ import annotations
 
 import re
+from bisect import bisect_left
 from collections import defaultdict
 from typing import List, Optional, Sequence, Tuple
 
@@ -151,7 +152,8 @@ def get_region_mismatches_with_filters(chromosome, start_pos, end_pos, sam, geno
         half = round(mismatch_window_size / 2)
         snapshot = sorted(sites.keys())
         for pos in snapshot:
-            around = [q for q in snapshot if q != pos and pos - half <= q < pos + half]
+            # the snapshot is sorted: the window is a slice (the reference filters the whole list for every site, :211-220)
+            around = [q for q in snapshot[bisect_left(snapshot, pos - half):bisect_left(snapshot, pos + half)] if q != pos]
             if not around:
                 continue
             for q in around:
