@@ -38,7 +38,8 @@ def parse_args(argv=None):
     p.add_argument('-c', '--chromosomes', nargs='*', type=str,
                    default=['chr%s' % c for c in list(range(1, 23)) + ['X', 'Y']], help='chromosomes to be analyzed')
     p.add_argument('-o', '--output_prefix', type=str, default='out', help='prefix of output file')
-    p.add_argument('-t', '--thread', type=int, default=1, help='accepted for compatibility (the MI step runs on the GPU)')
+    p.add_argument('-t', '--thread', type=int, default=1,
+                   help='processes for the host-side site extraction (the MI step itself runs on the GPU, in one batch)')
     p.add_argument('--annotation_gtf', type=str, default=None)
     p.add_argument('--genome_fasta', type=str, default=None)
     p.add_argument('--homopoly_length', type=int, default=5)
@@ -100,6 +101,16 @@ def get_footprints(sam, chromosomes, min_read_count=2):
     return out
 
 
+class _Reopen:
+    """picklable: a pool worker opens its own handles on the alignment and genome files"""
+
+    def __init__(self, bam, fasta):
+        self.bam, self.fasta = bam, fasta
+
+    def __call__(self):
+        return open_alignment(self.bam), open_fasta(self.fasta)
+
+
 def read_repeats(path):
     """chrom -> [[start, end]] sorted by start (src/giremi/fileio.py:4-21)"""
     table = defaultdict(list)
@@ -142,10 +153,15 @@ def main(argv=None):
         reps = [[a, b] for a, b in repeats.get(chrom, []) if a > end or b < start]
         jobs.append({'chromosome': chrom, 'start': start, 'end': end, 'snp_positions': snps,
                      'simple_repeat_intervals': reps, 'read_strand_dict': None})
-    engine = Engine(args.device)
+    made = []
+
+    def make_engine():                      # after the worker pool is gone: a HIP context does not survive fork()
+        made.append(Engine(args.device))
+        return made[0]
     df_sites, df_mi, df_removed = regions_mismatch_analysis(
         jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
-        engine=engine, concat=True, keep_non_spliced_read=args.keep_non_spliced_read,
+        engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta),
+        keep_non_spliced_read=args.keep_non_spliced_read,
         min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
         min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
         homopoly_length=args.homopoly_length, min_het_snp_ratio=args.min_het_snp_ratio,
@@ -156,7 +172,8 @@ def main(argv=None):
     strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
     df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
     df_removed.to_csv(args.output_prefix + '.removed.txt', sep='\t', index=False)
-    engine.close()
+    for e in made:
+        e.close()
     logging.info('All done!')
     return df_sites, df_mi, df_removed
 

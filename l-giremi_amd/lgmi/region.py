@@ -238,22 +238,51 @@ def region_mismatch_analysis(chromosome, start_pos, end_pos, sam, genome,
     return _frames(chromosome, sites, gone, records, mean_mi, pvals)
 
 
+def _extract_chunk(job, sam=None, genome=None):
+    """site extraction + filters for a list of footprints -> [(chromosome, sites, gone)] (pool worker and serial path)"""
+    reopen, footprints, filter_kwargs = job
+    if reopen is not None:
+        sam, genome = reopen()
+    out = []
+    for fp in footprints:
+        sites, gone = get_region_mismatches_with_filters(
+            chromosome=fp['chromosome'], start_pos=fp['start'], end_pos=fp['end'], sam=sam, genome=genome,
+            snp_positions=fp.get('snp_positions', []), simple_repeat_intervals=fp.get('simple_repeat_intervals', []),
+            read_strand_dict=fp.get('read_strand_dict'), **filter_kwargs)
+        if reopen is not None:              # results cross a process boundary: plain dicts (the site factory does not pickle)
+            sites = {strand: dict(d) for strand, d in sites.items()}
+            gone = {strand: dict(d) for strand, d in gone.items()}
+        out.append((fp['chromosome'], sites, gone))
+    return out
+
+
 def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
-                              concat=False, **filter_kwargs):
+                              concat=False, threads=1, reopen=None, **filter_kwargs):
     """``region_mismatch_analysis`` over many footprints with ONE GPU batch for all their MI blocks — the shape the
     reference's per-chunk loop (src/giremi/script/giremi.py:32-88) takes when the MI step is a device call.
 
     ``footprints``: iterable of dicts with ``chromosome``, ``start``, ``end`` and optionally the per-footprint inputs
     ``snp_positions``, ``simple_repeat_intervals``, ``read_strand_dict``; ``filter_kwargs`` are the common filter
     parameters of ``region_mismatch_analysis``.  Returns a list of (df_sites, df_pairs, df_removed) in footprint order,
-    or with ``concat=True`` the three frames concatenated the way script/giremi.py:79-88 concatenates them."""
-    staged = []
-    for fp in footprints:
-        sites, gone = get_region_mismatches_with_filters(
-            chromosome=fp['chromosome'], start_pos=fp['start'], end_pos=fp['end'], sam=sam, genome=genome,
-            snp_positions=fp.get('snp_positions', []), simple_repeat_intervals=fp.get('simple_repeat_intervals', []),
-            read_strand_dict=fp.get('read_strand_dict'), **filter_kwargs)
-        staged.append((fp['chromosome'], sites, gone))
+    or with ``concat=True`` the three frames concatenated the way script/giremi.py:79-88 concatenates them.
+    ``threads`` > 1 with ``reopen`` (a picklable callable returning fresh ``(sam, genome)`` objects) runs the host-side
+    extraction in a process pool; ``engine`` may then be a callable that creates the engine AFTER the pool has finished."""
+    footprints = list(footprints)
+    staged = None
+    if threads and threads > 1 and len(footprints) > 1 and reopen is not None:
+        # host-side site extraction is per footprint and shares nothing: the reference maps it over a process pool
+        # (script/giremi.py:367-380, -t); so does this, with the MI step kept OUT of the workers — they return site
+        # dictionaries, the parent packs every footprint's blocks into one GPU batch.  Workers reopen the files
+        # (`reopen()` -> (sam, genome)); the pool must be done before the parent creates its HIP context (fork).
+        import multiprocessing as mp
+        chunk = max(1, -(-len(footprints) // (4 * threads)))
+        jobs = [(reopen, footprints[k:k + chunk], filter_kwargs) for k in range(0, len(footprints), chunk)]
+        with mp.get_context('fork').Pool(threads) as pool:
+            staged = [x for part in pool.map(_extract_chunk, jobs) for x in part]
+    if staged is None:
+        staged = _extract_chunk((None, footprints, filter_kwargs), sam, genome)
+    if callable(engine) and not hasattr(engine, 'run'):
+        engine = engine()
     blocks = regions_pair_mi([(sites, chrom) for chrom, sites, _gone in staged], min_common_reads,
                              n_shuffles=n_shuffles, seed=seed, engine=engine)
     frames = [_frames(chrom, sites, gone, *blk) for (chrom, sites, gone), blk in zip(staged, blocks)]

@@ -145,6 +145,8 @@ def test_cli_host_side_matches_the_reference(tmp_path, monkeypatch):
     monkeypatch.setattr(region, 'regions_pair_mi', oracle_blocks)
     monkeypatch.setattr(lgmi.engine, 'Engine', NoEngine)
     run_cli_and_compare(tmp_path)
+    # -t 2: the site extraction of the two footprints in a process pool (the reference's -t), same files out
+    run_cli_and_compare(tmp_path, ['-t', '2'])
 
 
 @pytest.mark.gpu

@@ -194,3 +194,23 @@ def test_multi_block_full_size_properties(engine, name, n_blocks, n_sites, n_rea
     pick = np.concatenate([sample, rng.choice(general, min(100 if n_shuffles > 1000 else 300, len(general)), replace=False)])
     _, e_spec = c_oracle.perm_rows(res.row_i[pick], res.row_j[pick], res.row_counts[pick], n_shuffles, 13)
     np.testing.assert_array_equal(res.row_exceed[pick], e_spec)
+
+
+def test_north_star_banded_full_size_against_the_oracle(engine):
+    """the long-read-like regime at the north-star's size (50k sites x 200k reads in 25 blocks, every site sees ~70
+    reads): small enough per pair for the C oracle to do ALL of it — rows, tables, MI, per-site means and the
+    1000-shuffle permutation counts, bit for bit"""
+    from lgmi.synth import banded_chromosome
+    from oracle import c_oracle
+    pb = banded_chromosome(50_000, 200_000, seed=20250808)
+    res = engine.run(pb, min_common=6, het_only=True, n_shuffles=1000, seed=3, emit_counts=True)
+    ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=1000, seed=3)
+    assert res.n_rows == len(ora['row_i']) > 500_000 and res.info['n_examined'] == ora['n_examined']
+    np.testing.assert_array_equal(res.row_i, ora['row_i'])
+    np.testing.assert_array_equal(res.row_j, ora['row_j'])
+    np.testing.assert_array_equal(res.row_counts, ora['row_counts'])
+    np.testing.assert_array_equal(res.row_exceed, ora['row_exceed'])
+    assert np.max(np.abs(res.row_mi - ora['row_mi'])) <= 1e-6
+    np.testing.assert_array_equal(res.site_n_pairs, ora['site_n_pairs'])
+    m = ora['site_n_pairs'] > 0
+    assert np.max(np.abs(res.site_mean_mi[m] - ora['site_mean_mi'][m])) <= 1e-6
