@@ -159,30 +159,6 @@ def main():
         db = eng.synth_dense(lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed, n_blocks=n_blocks))
     gather_state = {'on': (world > 1 or args.force_gather) and not args.no_gather, 'note': None}
     hung = []
-    if gather_state['on']:
-        # RCCL communicator inside liblgmi (csrc/comm.cpp).  The 128-byte id travels over the sockets here; the
-        # collective ncclCommInitRank runs in a thread so that a rank that cannot bring RCCL up (or never returns)
-        # costs the job its gather, not its measurement: every rank learns the outcome over the sockets and the
-        # run goes on kernel-only, saying so in the JSON line.
-        import threading
-        from lgmi.dist import exchange_unique_id
-        uid = exchange_unique_id(group, eng.comm_unique_id if rank == 0 else None)
-        box = {}
-
-        def bring_up():
-            try:
-                eng.comm_init(uid, rank, world)
-                box['ok'] = True
-            except Exception as e:                              # noqa: BLE001
-                box['err'] = repr(e)
-        th = threading.Thread(target=bring_up, daemon=True)
-        th.start()
-        th.join(float(os.environ.get('LGMI_COMM_INIT_TIMEOUT', '240')))
-        if th.is_alive():
-            hung.append(th)
-        states = group.allgather(box.get('err') or ('ok' if box.get('ok') else 'timeout'))
-        if any(st != 'ok' for st in states):
-            gather_state.update(on=False, note='RCCL communicator not available (%s): rows were NOT gathered' % states)
     shard = (rank, world) if (strong and world > 1) else None
     n_sites_rank = wl['n_sites'] * n_blocks
 
@@ -206,150 +182,215 @@ def main():
         dr.free()
         return info
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    infos = [step() for _ in range(args.steps)]
-    sync()
-    elapsed = group.allreduce_max(time.perf_counter() - t0)
-    per_rank = group.gather({k: sum(i[k] for i in infos) / len(infos) for k in
-                             ('ms_total', 'ms_count', 'ms_emit', 'ms_perm', 'n_examined', 'n_rows', 'n_tile_pairs')})
+    def measure():
+        """W untimed + K timed steps between barriers; -> (infos, max-over-ranks seconds, per-rank stage means)"""
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        infos_ = [step() for _ in range(args.steps)]
+        sync()
+        elapsed_ = group.allreduce_max(time.perf_counter() - t0)
+        per_rank_ = group.gather({k: sum(i[k] for i in infos_) / len(infos_) for k in
+                                  ('ms_total', 'ms_count', 'ms_emit', 'ms_perm', 'n_examined', 'n_rows', 'n_tile_pairs')})
+        return infos_, elapsed_, per_rank_
 
-    # N > 1, strong scaling: one more (untimed) pass whose gathered result rank 0 compares, array by array, with the
-    # unsharded run of the same chromosome on its own GPU — the multi-GPU path checks itself wherever it runs
-    verify = None
-    if gather_state['on'] and strong and not os.environ.get('LGMI_BENCH_NO_VERIFY'):
+    def run_verify():
+        """N > 1, strong scaling: one more (untimed) pass whose gathered result rank 0 compares, array by array, with the
+        unsharded run of the same chromosome on its own GPU — the multi-GPU path checks itself wherever it runs"""
         import numpy as np
         dr = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
         g, begins = eng.comm_gather(dr, root=0, same_batch=True)
         dr.free()
-        if g is not None:
-            got = g.fetch()
-            g.free()
-            dr0 = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
-            ref = dr0.fetch()
-            dr0.free()
-            fields = ['row_i', 'row_j', 'row_mi', 'site_n_pairs', 'site_mean_mi'] + (['row_p', 'row_exceed'] if n_shuffles else [])
-            bad = [f for f in fields if not np.array_equal(getattr(got, f), getattr(ref, f), equal_nan=(f in ('site_mean_mi', 'row_p')))]
-            verify = {'gathered_rows': int(got.n_rows), 'unsharded_rows': int(ref.n_rows), 'rank_row_begin': begins,
-                      'fields_compared': fields, 'fields_differing': bad, 'equal_to_unsharded': not bad}
-            del got, ref
+        if g is None:
+            return None
+        got = g.fetch()
+        g.free()
+        dr0 = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+        ref = dr0.fetch()
+        dr0.free()
+        fields = ['row_i', 'row_j', 'row_mi', 'site_n_pairs', 'site_mean_mi'] + (['row_p', 'row_exceed'] if n_shuffles else [])
+        bad = [f for f in fields if not np.array_equal(getattr(got, f), getattr(ref, f), equal_nan=(f in ('site_mean_mi', 'row_p')))]
+        return {'gathered_rows': int(got.n_rows), 'unsharded_rows': int(ref.n_rows), 'rank_row_begin': begins,
+                'fields_compared': fields, 'fields_differing': bad, 'equal_to_unsharded': not bad}
 
-    info = infos[-1]
-    ms_count = sum(i['ms_count'] for i in infos) / len(infos)
+    def make_out(infos, elapsed, per_rank, verify):
+        """the JSON line (rank 0 only); host_to_host and cpu_baseline are added by the caller"""
+        info = infos[-1]
+        ms_count = sum(i['ms_count'] for i in infos) / len(infos)
+        if True:
+            examined_job = info['n_examined_total'] if strong else sum(int(p['n_examined']) for p in per_rank)
+            rows_job = sum(info.get('world_rows', [info['n_rows']]))
+            general_job = info['n_general_rows']                    # this rank's; scaled below for the job-wide rate
+            # dominant kernel: k_count.  Algorithmic HBM bytes per launch (SURVEY §8d(1), DESIGN.md §4):
+            # every column's planes once (16 B per 64-read word) + site metadata + the 4 count planes
+            # of every computed slot (16 B).
+            mfma = info.get('n_mfma_tiles', 0) > 0
+            alg_bytes = info['bytes_in'] + 16 * info['n_tile_pairs']
+            word_ops = 4 * info['word_pairs']                      # SURVEY §8d(3): 4 mandatory AND+POPC per pair-word
+            secs = ms_count * 1e-3
+            out = {
+                'metric': 'MI site-pairs/sec (incl. permutation p)' if n_shuffles else 'MI site-pairs/sec',
+                'value': examined_job * args.steps / elapsed,
+                'unit': 'site-pairs/s',
+                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': 1e3 * elapsed / args.steps,
+                'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+                'dtype': {2: 'u64 bit planes -> fp4 (e2m1) MFMA operands, f32 counts (exact < 2^24), f64 MI',
+                          1: 'u64 bit planes -> int8 MFMA operands, i32 counts, f64 MI'}.get(
+                              info.get('mfma_dtype', 0), 'u64 bit planes (AND + popcount), u32 counts, f64 MI'),
+                'data': 'synthetic',
+                'config': {'workload': args.workload, 'n_sites': wl['n_sites'], 'n_reads': wl['n_reads'],
+                           'n_blocks': n_blocks, 'regime': wl.get('regime', 'dense'), 'het_every': 5,
+                           'min_common': args.min_common, 'n_shuffles': n_shuffles,
+                           'examined_pairs_job': examined_job, 'emitted_pairs_job': rows_job,
+                           'parallelism': ('1 gpu' if world == 1 else
+                                           ('tile shards of one batch x%d, RCCL row gather to rank 0' % world if strong else
+                                            'one chromosome per rank x%d, RCCL row gather to rank 0' % world)),
+                           'timed_region': 'resident batch -> result rows resident in HBM'
+                                           + (' of rank 0 (gather included)' if gather_state['on'] else ''),
+                           'gather': ('liblgmi RCCL (lgmi_comm_gather)' if gather_state['on'] else
+                                      (gather_state['note'] or ('skipped (--no-gather)' if world > 1 else 'n/a')))},
+                'stage_ms': {k: sum(i.get(k, 0.0) for i in infos) / len(infos)
+                             for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
+                                       'ms_perm_general', 'ms_mean', 'ms_gather')},
+            }
+            if world > 1 or args.force_gather:
+                out['per_rank'] = per_rank
+                out['verify'] = verify if verify is not None else 'not run (no gather, or weak scaling)'
+            out['rates'] = {'emitted_pairs_per_s': rows_job * args.steps / elapsed}
+            if n_shuffles:
+                # the permutation stage, priced on what it really draws (DESIGN.md §5): a 2 x 2 row costs ONE binomial
+                # variate against its exact tail mass; only the larger tables draw n_shuffles tables each.  VALU issue
+                # and lane occupancy come from the committed SQ counter pass of this workload.
+                sq = committed_profile('pmc_sq_perm').get(args.workload, {})
+                ms_gen = sum(i['ms_perm_general'] for i in infos) / len(infos)
+                ms_fast = sum(i['ms_perm_fast'] for i in infos) / len(infos)
+                draws = general_job * n_shuffles
+                pr = {'general_rows': general_job, 'two_by_two_rows': info['n_rows'] - general_job,
+                      'table_draws': draws, 'ms_general': ms_gen, 'ms_fast': ms_fast,
+                      'table_draws_per_s': draws / (ms_gen * 1e-3) if ms_gen > 0 else None,
+                      'two_by_two_rows_per_s': (info['n_rows'] - general_job) / (ms_fast * 1e-3) if ms_fast > 0 else None,
+                      'bound': 'valu_issue', 'unit': 'wave64 VALU instructions/s',
+                      'peak': VALU_WAVE_INSTR_PEAK, 'counters': sq.get('_file') or committed_profile('pmc_sq_perm').get('_file')}
+                for k in ('k_perm_general', 'k_perm_fast'):
+                    c = sq.get(k)
+                    if c and c.get('valu_insts') and c.get('ms'):
+                        pr[k] = {'valu_issue_frac': c['valu_insts'] / (c['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
+                                 'active_lane_frac': c.get('active_lanes', 0) / 64.0,
+                                 'valu_insts_per_table_draw' if k == 'k_perm_general' else 'valu_insts_per_row':
+                                     c['valu_insts'] * 64.0 / (c.get('units') or 1)}
+                out['perm_roofline'] = pr
+            traffic = committed_profile('pmc_k_count').get(args.workload + ('_mfma' if mfma else ''), {}).get('hbm_bytes')
+            hbm = {'kernel': 'count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes, 'achieved': alg_bytes / secs / 1e9,
+                   'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
+                   'traffic': traffic,
+                   'note': 'bytes per launch; the count kernel is compute-bound, not HBM-bound.  traffic = L2-miss bytes '
+                           '(FETCH_SIZE x2 + WRITE_SIZE, newest profiles/rNN_pmc_k_count.json)'}
+            valu = {'kernel': 'k_count', 'bound': 'valu_popcount', 'achieved': word_ops / secs / 1e12,
+                    'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12, 'unit': 'T word-ops/s (64-bit AND+POPC)',
+                    'frac': word_ops / secs / (VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS)}
+            if mfma:
+                # matrix-core count kernels: the four counts of a pair-word are 4 x 64 multiply-accumulates = 512 ops
+                ops = 512.0 * info['word_pairs']
+                fp4 = info.get('mfma_dtype', 1) == 2
+                peak = MFMA_FP4_PEAK_TOPS if fp4 else MFMA_I8_PEAK_TOPS
+                out['roofline'] = {'kernel': 'k_count_mfma_fp4' if fp4 else 'k_count_mfma', 'bound': 'mfma',
+                                   'achieved': ops / secs / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                                   'op_kind': ('fp4 (e2m1)' if fp4 else 'int8') + ' multiply-add ops (tera-ops/s), dense MFMA peak',
+                                   'frac': ops / secs / 1e12 / peak, 'traffic': traffic,
+                                   'algorithmic_ops': ops, 'ms_kernel': ms_count,
+                                   'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2) of this '
+                                           'rank\'s shard; '
+                                           + ('v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands and unit scales, exact in f32 below 2^24 reads; '
+                                              if fp4 else 'v_mfma_i32_32x32x32_i8; ')
+                                           + 'weighted-bit operands made from the bit planes in registers (AND / shift-AND per operand dword)'}
+                out['hbm_roofline'] = hbm
+            else:
+                out['roofline'] = hbm
+                out['valu_roofline'] = valu
+            if world == 1 and not args.no_host_to_host:
+                # SURVEY §8d's other wall time: packed batch in HOST memory -> result rows in HOST memory (upload + layout
+                # prep + kernels + fetch), through lgmi_run.  Never `value`.
+                pb = db.download()
+                t1 = time.perf_counter()
+                eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+                dt_first = time.perf_counter() - t1                # pays the pinning of the result buffers (cached after)
+                t1 = time.perf_counter()
+                hi = eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+                dt = time.perf_counter() - t1
+                out['host_to_host'] = {'ms': 1e3 * dt, 'ms_first_call': 1e3 * dt_first, 'site_pairs_per_s': hi['n_examined'] / dt,
+                                       'h2d_bytes': int(pb.planes.nbytes + 25 * len(pb.site_pos)),
+                                       'd2h_bytes': int(hi['bytes_out'] + 12 * len(pb.site_pos)),
+                                       'kernels_ms': hi['ms_total'],
+                                       'note': 'one lgmi_run call from pageable host memory: validation + H2D + layout prep '
+                                               '+ kernels + D2H of (i, j, mi, p, exceed) per row into pinned buffers the '
+                                               'context caches (the first call pins them)'}
+                del pb
+            if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
+                out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)
+            return out
+
+    multi = gather_state['on']
     out = None
-    if rank == 0:
-        examined_job = info['n_examined_total'] if strong else sum(int(p['n_examined']) for p in per_rank)
-        rows_job = sum(info.get('world_rows', [info['n_rows']]))
-        general_job = info['n_general_rows']                    # this rank's; scaled below for the job-wide rate
-        # dominant kernel: k_count.  Algorithmic HBM bytes per launch:
-        # every column's planes once (16 B per 64-read word) + site metadata + the 4 count planes
-        # of every computed slot (16 B).
-        mfma = info.get('n_mfma_tiles', 0) > 0
-        alg_bytes = info['bytes_in'] + 16 * info['n_tile_pairs']
-        word_ops = 4 * info['word_pairs']                      # 4 mandatory AND+POPC per pair-word
-        secs = ms_count * 1e-3
-        out = {
-            'metric': 'MI site-pairs/sec (incl. permutation p)' if n_shuffles else 'MI site-pairs/sec',
-            'value': examined_job * args.steps / elapsed,
-            'unit': 'site-pairs/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-            'dtype': {2: 'u64 bit planes -> fp4 (e2m1) MFMA operands, f32 counts (exact < 2^24), f64 MI',
-                      1: 'u64 bit planes -> int8 MFMA operands, i32 counts, f64 MI'}.get(
-                          info.get('mfma_dtype', 0), 'u64 bit planes (AND + popcount), u32 counts, f64 MI'),
-            'data': 'synthetic',
-            'config': {'workload': args.workload, 'n_sites': wl['n_sites'], 'n_reads': wl['n_reads'],
-                       'n_blocks': n_blocks, 'regime': wl.get('regime', 'dense'), 'het_every': 5,
-                       'min_common': args.min_common, 'n_shuffles': n_shuffles,
-                       'examined_pairs_job': examined_job, 'emitted_pairs_job': rows_job,
-                       'parallelism': ('1 gpu' if world == 1 else
-                                       ('tile shards of one batch x%d, RCCL row gather to rank 0' % world if strong else
-                                        'one chromosome per rank x%d, RCCL row gather to rank 0' % world)),
-                       'timed_region': 'resident batch -> result rows resident in HBM'
-                                       + (' of rank 0 (gather included)' if gather_state['on'] else ''),
-                       'gather': ('liblgmi RCCL (lgmi_comm_gather)' if gather_state['on'] else
-                                  (gather_state['note'] or ('skipped (--no-gather)' if world > 1 else 'n/a')))},
-            'stage_ms': {k: sum(i.get(k, 0.0) for i in infos) / len(infos)
-                         for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
-                                   'ms_perm_general', 'ms_mean', 'ms_gather')},
-        }
-        if world > 1 or args.force_gather:
-            out['per_rank'] = per_rank
-            out['verify'] = verify if verify is not None else 'not run (no gather, or weak scaling)'
-        out['rates'] = {'emitted_pairs_per_s': rows_job * args.steps / elapsed}
-        if n_shuffles:
-            # the permutation stage, priced on what it really draws: a 2 x 2 row costs ONE binomial
-            # variate against its exact tail mass; only the larger tables draw n_shuffles tables each.  VALU issue
-            # and lane occupancy come from the committed SQ counter pass of this workload.
-            sq = committed_profile('pmc_sq_perm').get(args.workload, {})
-            ms_gen = sum(i['ms_perm_general'] for i in infos) / len(infos)
-            ms_fast = sum(i['ms_perm_fast'] for i in infos) / len(infos)
-            draws = general_job * n_shuffles
-            pr = {'general_rows': general_job, 'two_by_two_rows': info['n_rows'] - general_job,
-                  'table_draws': draws, 'ms_general': ms_gen, 'ms_fast': ms_fast,
-                  'table_draws_per_s': draws / (ms_gen * 1e-3) if ms_gen > 0 else None,
-                  'two_by_two_rows_per_s': (info['n_rows'] - general_job) / (ms_fast * 1e-3) if ms_fast > 0 else None,
-                  'bound': 'valu_issue', 'unit': 'wave64 VALU instructions/s',
-                  'peak': VALU_WAVE_INSTR_PEAK, 'counters': sq.get('_file') or committed_profile('pmc_sq_perm').get('_file')}
-            for k in ('k_perm_general', 'k_perm_fast'):
-                c = sq.get(k)
-                if c and c.get('valu_insts') and c.get('ms'):
-                    pr[k] = {'valu_issue_frac': c['valu_insts'] / (c['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
-                             'active_lane_frac': c.get('active_lanes', 0) / 64.0,
-                             'valu_insts_per_table_draw' if k == 'k_perm_general' else 'valu_insts_per_row':
-                                 c['valu_insts'] * 64.0 / (c.get('units') or 1)}
-            out['perm_roofline'] = pr
-        traffic = committed_profile('pmc_k_count').get(args.workload + ('_mfma' if mfma else ''), {}).get('hbm_bytes')
-        hbm = {'kernel': 'count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes, 'achieved': alg_bytes / secs / 1e9,
-               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
-               'traffic': traffic,
-               'note': 'bytes per launch; the count kernel is compute-bound, not HBM-bound.  traffic = L2-miss bytes '
-                       '(FETCH_SIZE x2 + WRITE_SIZE, newest profiles/rNN_pmc_k_count.json)'}
-        valu = {'kernel': 'k_count', 'bound': 'valu_popcount', 'achieved': word_ops / secs / 1e12,
-                'peak': VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS / 1e12, 'unit': 'T word-ops/s (64-bit AND+POPC)',
-                'frac': word_ops / secs / (VALU_LANE_OPS_PEAK / WORD_OP_LANE_OPS)}
-        if mfma:
-            # matrix-core count kernels: the four counts of a pair-word are 4 x 64 multiply-accumulates = 512 ops
-            ops = 512.0 * info['word_pairs']
-            fp4 = info.get('mfma_dtype', 1) == 2
-            peak = MFMA_FP4_PEAK_TOPS if fp4 else MFMA_I8_PEAK_TOPS
-            out['roofline'] = {'kernel': 'k_count_mfma_fp4' if fp4 else 'k_count_mfma', 'bound': 'mfma',
-                               'achieved': ops / secs / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
-                               'op_kind': ('fp4 (e2m1)' if fp4 else 'int8') + ' multiply-add ops (tera-ops/s), dense MFMA peak',
-                               'frac': ops / secs / 1e12 / peak, 'traffic': traffic,
-                               'algorithmic_ops': ops, 'ms_kernel': ms_count,
-                               'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2) of this '
-                                       'rank\'s shard; '
-                                       + ('v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands and unit scales, exact in f32 below 2^24 reads; '
-                                          if fp4 else 'v_mfma_i32_32x32x32_i8; ')
-                                       + 'weighted-bit operands made from the bit planes in registers (AND / shift-AND per operand dword)'}
-            out['hbm_roofline'] = hbm
+    if not multi:
+        infos, elapsed, per_rank = measure()
+        if rank == 0:
+            out = make_out(infos, elapsed, per_rank, None)
+    else:
+        # (1) kernel-only measurement first: it involves no RCCL call, so it always completes and is what rank 0 prints
+        #     if the communicator cannot be brought up or the gathered measurement does not finish
+        gather_state['on'] = False
+        infos_k, elapsed_k, per_rank_k = measure()
+        fallback = None
+        if rank == 0:
+            gather_state['note'] = 'kernel-only: the RCCL gather was not measured'
+            fallback = make_out(infos_k, elapsed_k, per_rank_k, None)
+        # (2) RCCL communicator inside liblgmi (csrc/comm.cpp).  The 128-byte id travels over the sockets; the collective
+        #     ncclCommInitRank runs in a watched thread: a rank that cannot bring RCCL up (or never returns) costs the job
+        #     its gather, not its measurement
+        import threading
+        from lgmi.dist import exchange_unique_id
+        uid = exchange_unique_id(group, eng.comm_unique_id if rank == 0 else None)
+        box = {}
+
+        def bring_up():
+            try:
+                eng.comm_init(uid, rank, world)
+                box['ok'] = True
+            except Exception as e:                              # noqa: BLE001
+                box['err'] = repr(e)
+        th = threading.Thread(target=bring_up, daemon=True)
+        th.start()
+        th.join(float(os.environ.get('LGMI_COMM_INIT_TIMEOUT', '240')))
+        if th.is_alive():
+            hung.append(th)
+        states = group.allgather(box.get('err') or ('ok' if box.get('ok') else 'timeout'))
+        if any(st != 'ok' for st in states):
+            if rank == 0:
+                fallback['config']['gather'] = 'RCCL communicator not available (%s): rows were NOT gathered' % states
+                out = fallback
         else:
-            out['roofline'] = hbm
-            out['valu_roofline'] = valu
-        if world == 1 and not args.no_host_to_host:
-            # SURVEY §8d's other wall time: packed batch in HOST memory -> result rows in HOST memory (upload + layout
-            # prep + kernels + fetch), through lgmi_run.  Never `value`.
-            pb = db.download()
-            t1 = time.perf_counter()
-            eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
-            dt_first = time.perf_counter() - t1                # pays the pinning of the result buffers (cached after)
-            t1 = time.perf_counter()
-            hi = eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
-            dt = time.perf_counter() - t1
-            out['host_to_host'] = {'ms': 1e3 * dt, 'ms_first_call': 1e3 * dt_first, 'site_pairs_per_s': hi['n_examined'] / dt,
-                                   'h2d_bytes': int(pb.planes.nbytes + 25 * len(pb.site_pos)),
-                                   'd2h_bytes': int(hi['bytes_out'] + 12 * len(pb.site_pos)),
-                                   'kernels_ms': hi['ms_total'],
-                                   'note': 'one lgmi_run call from pageable host memory: validation + H2D + layout prep '
-                                           '+ kernels + D2H of (i, j, mi, p, exceed) per row into pinned buffers the '
-                                           'context caches (the first call pins them)'}
-            del pb
-        if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
-            out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)
+            # (3) the measurement proper, gather inside the timed region, under a watchdog: if it does not finish, every
+            #     rank leaves and rank 0 prints the kernel-only line saying so
+            limit = float(os.environ.get('LGMI_GATHER_TIMEOUT', '600'))
+
+            def give_up():
+                if rank == 0:
+                    fallback['config']['gather'] = 'the RCCL gather did not finish within %.0f s: rows were NOT gathered' % limit
+                    os.write(json_fd, (json.dumps(fallback) + '\n').encode())
+                os._exit(0 if rank == 0 else 3)
+            dog = threading.Timer(limit, give_up)
+            dog.daemon = True
+            dog.start()
+            gather_state.update(on=True, note=None)
+            infos, elapsed, per_rank = measure()
+            verify = run_verify() if (strong and not os.environ.get('LGMI_BENCH_NO_VERIFY')) else None
+            dog.cancel()
+            if rank == 0:
+                out = make_out(infos, elapsed, per_rank, verify)
+                out['kernel_only'] = {'value': fallback['value'], 'ms_per_step': fallback['ms_per_step'],
+                                      'note': 'the same steps without the gather (measured first)'}
     db.free()
     if world > 1:
         group.barrier()
