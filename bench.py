@@ -169,11 +169,30 @@ def main():
             eng.synchronize()
 
     def step():
-        dr = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
+        kw = dict(min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
+        base = 0 if strong else rank * n_sites_rank
+        if gather_state['on'] and gather_state.get('overlap'):
+            # rows first; their transfer to rank 0 (communication stream) runs under the permutation kernels
+            dr = eng.run_device(db, rows_only=True, **kw)
+            t0 = time.perf_counter()
+            flight = eng.comm_gather_begin(dr, root=0, site_base=base, same_batch=strong)
+            t1 = time.perf_counter()
+            dr.permute()
+            t2 = time.perf_counter()
+            g, begins = flight.finish()
+            info = dr.info()
+            info['ms_gather'] = 1e3 * ((t1 - t0) + (time.perf_counter() - t2))      # host time in the two halves
+            info['world_rows'] = [begins[k + 1] - begins[k] for k in range(world)]
+            if g is not None:
+                info['gathered_rows'] = g.info()['n_rows']
+                g.free()
+            dr.free()
+            return info
+        dr = eng.run_device(db, **kw)
         info = dr.info()
         if gather_state['on']:                                 # the final gather: rows HBM -> rank 0's HBM over xGMI
             t0 = time.perf_counter()
-            g, begins = eng.comm_gather(dr, root=0, site_base=0 if strong else rank * n_sites_rank, same_batch=strong)
+            g, begins = eng.comm_gather(dr, root=0, site_base=base, same_batch=strong)
             info['ms_gather'] = 1e3 * (time.perf_counter() - t0)
             info['world_rows'] = [begins[k + 1] - begins[k] for k in range(world)]
             if g is not None:
@@ -199,8 +218,15 @@ def main():
         """N > 1, strong scaling: one more (untimed) pass whose gathered result rank 0 compares, array by array, with the
         unsharded run of the same chromosome on its own GPU — the multi-GPU path checks itself wherever it runs"""
         import numpy as np
-        dr = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
-        g, begins = eng.comm_gather(dr, root=0, same_batch=True)
+        if gather_state.get('overlap'):
+            dr = eng.run_device(db, rows_only=True, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True,
+                                shard=shard)
+            flight = eng.comm_gather_begin(dr, root=0, same_batch=True)
+            dr.permute()
+            g, begins = flight.finish()
+        else:
+            dr = eng.run_device(db, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, shard=shard)
+            g, begins = eng.comm_gather(dr, root=0, same_batch=True)
         dr.free()
         if g is None:
             return None
@@ -387,10 +413,49 @@ def main():
             infos, elapsed, per_rank = measure()
             verify = run_verify() if (strong and not os.environ.get('LGMI_BENCH_NO_VERIFY')) else None
             dog.cancel()
+            simple = None
             if rank == 0:
-                out = make_out(infos, elapsed, per_rank, verify)
-                out['kernel_only'] = {'value': fallback['value'], 'ms_per_step': fallback['ms_per_step'],
-                                      'note': 'the same steps without the gather (measured first)'}
+                simple = make_out(infos, elapsed, per_rank, verify)
+                simple['kernel_only'] = {'value': fallback['value'], 'ms_per_step': fallback['ms_per_step'],
+                                         'note': 'the same steps without the gather (measured first)'}
+                simple['config']['gather'] += ' after the permutation stage'
+                out = simple
+            # (4) the same with the rows travelling UNDER the permutation stage (run split in two, gather in two halves).
+            #     Its own watchdog: if it does not finish, rank 0 prints the line of (3).  It becomes the reported line only
+            #     when it finishes, verifies against the unsharded run and is faster.
+            if n_shuffles and not os.environ.get('LGMI_BENCH_NO_OVERLAP'):
+                def keep_simple():
+                    if rank == 0:
+                        simple['overlapped_gather'] = 'did not finish within %.0f s' % limit
+                        os.write(json_fd, (json.dumps(simple) + '\n').encode())
+                    os._exit(0 if rank == 0 else 3)
+                dog = threading.Timer(limit, keep_simple)
+                dog.daemon = True
+                dog.start()
+                gather_state['overlap'] = True
+                try:
+                    infos2, elapsed2, per_rank2 = measure()
+                    verify2 = run_verify() if (strong and not os.environ.get('LGMI_BENCH_NO_VERIFY')) else None
+                    failed = None
+                except Exception as e:                              # noqa: BLE001  (an error on one rank is an error on all: agreed below)
+                    failed = repr(e)
+                dog.cancel()
+                states2 = group.allgather(failed)
+                if rank == 0:
+                    if any(states2):
+                        simple['overlapped_gather'] = 'failed: %s' % [st for st in states2 if st]
+                    else:
+                        over = make_out(infos2, elapsed2, per_rank2, verify2)
+                        over['config']['gather'] += ' under the permutation stage (lgmi_run_device_rows, lgmi_comm_gather_begin, lgmi_dresult_permute, lgmi_comm_gather_finish)'
+                        ok2 = verify2 is None or verify2.get('equal_to_unsharded')
+                        summary = {'value': over['value'], 'ms_per_step': over['ms_per_step'], 'verify': verify2}
+                        if ok2 and over['value'] > simple['value']:
+                            over['kernel_only'] = simple['kernel_only']
+                            over['gather_after_permutation'] = {'value': simple['value'], 'ms_per_step': simple['ms_per_step'],
+                                                                'verify': simple.get('verify')}
+                            out = over
+                        else:
+                            simple['overlapped_gather'] = summary
     db.free()
     if world > 1:
         group.barrier()

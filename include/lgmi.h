@@ -210,6 +210,12 @@ void lgmi_dbatch_free(lgmi_dbatch* db);
 /* the hot path on a resident batch; rows stay in HBM */
 int  lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm,
                      lgmi_dresult** out);
+/* the same in two calls: lgmi_run_device_rows() stops when the rows (i, j, mi, tables, per-site means) are final,
+ * lgmi_dresult_permute() runs the permutation stage on them (row_p / row_exceed are undefined in between).  A
+ * multi-GPU host starts gathering the rows between the two (lgmi_comm_gather_begin) so that the transfer runs
+ * under the permutation kernels. */
+int  lgmi_run_device_rows(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out);
+int  lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* dr);
 int  lgmi_dresult_info(const lgmi_dresult* dr, lgmi_run_info* out);
 /* raw device pointers of a resident result (for RCCL / zero-copy consumers) */
 int  lgmi_dresult_device_ptrs(const lgmi_dresult* dr, lgmi_result* out_device_view);
@@ -308,6 +314,16 @@ typedef struct lgmi_gather_opts {
 } lgmi_gather_opts;
 int  lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int root, const lgmi_gather_opts* opts_or_null,
                       lgmi_dresult** out, uint64_t* rank_row_begin_or_null);
+/* The same gather in two halves, on a communication stream of its own: _begin exchanges the sizes, allocates on the
+ * root and posts the transfer of (row_i, row_j, row_mi [, row_counts]) — it returns while that transfer is in flight,
+ * so a result made by lgmi_run_device_rows() can run lgmi_dresult_permute() meanwhile; _finish posts what the
+ * permutation stage produced (row_exceed [, row_p]), the per-site reduction, waits for everything and builds the
+ * gathered result.  lgmi_comm_gather() is _begin followed by _finish.  `mine` must stay alive until _finish returns;
+ * _finish always releases the handle. */
+typedef struct lgmi_gather lgmi_gather;
+int  lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, int root, const lgmi_gather_opts* opts_or_null,
+                            lgmi_gather** handle);
+int  lgmi_comm_gather_finish(lgmi_gather* handle, lgmi_dresult** out, uint64_t* rank_row_begin_or_null);
 /* lgmi_comm_gather() with default options followed by a fetch on the root: `out` is a host-resident
  * concatenation there, n_rows = 0 elsewhere */
 int  lgmi_comm_gather_rows(lgmi_ctx* ctx, const lgmi_dresult* mine, int root,

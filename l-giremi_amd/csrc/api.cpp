@@ -124,6 +124,7 @@ struct lgmi_ctx {
     double* d_LF = nullptr;     // ln n!
     uint32_t tables_len = 0;
     void* comm = nullptr;       // ncclComm_t (comm.cpp)
+    hipStream_t comm_stream = nullptr;   // the gather runs here, beside the kernels of `stream`
     int rank = 0, world = 1;
     size_t mem_total = 0;       // device memory, for the "allocate rows by their upper bound" decision
     std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
@@ -159,6 +160,11 @@ struct lgmi_dresult {
     bool sharded = false;                  // per-site figures cover this shard's rows only
     uint32_t n_shuffles = 0;
     bool p_from_exceed = false;            // every row_p is (1 + row_exceed) / (n_shuffles + 1): the gather need not carry it
+    // split run (lgmi_run_device_rows + lgmi_dresult_permute): the permutation stage is still to come
+    bool perm_pending = false;
+    uint64_t* d_nrows = nullptr;           // the row count on the device, for the permutation kernels' grids
+    uint64_t cap_rows = 0;
+    lgmi_params prm = {};
 };
 
 struct HostResult : ResultOwner {  // owner_ of a host lgmi_result: pinned buffers that go back to the context's cache
@@ -221,6 +227,7 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     if (ctx->d_LF) (void)hipFree(ctx->d_LF);
     ctx->pool.destroy();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -228,6 +235,10 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
 // accessors for comm.cpp (keeps lgmi_ctx private to this file)
 namespace lgmi {
 hipStream_t ctx_stream(lgmi_ctx* c) { return c->stream; }
+hipStream_t ctx_comm_stream(lgmi_ctx* c) {               // created on first use
+    if (!c->comm_stream && hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess) c->comm_stream = nullptr;
+    return c->comm_stream ? c->comm_stream : c->stream;
+}
 int ctx_device(lgmi_ctx* c) { return c->device; }
 void** ctx_comm_slot(lgmi_ctx* c) { return &c->comm; }
 int* ctx_rank_slot(lgmi_ctx* c) { return &c->rank; }
@@ -631,11 +642,11 @@ extern "C" void lgmi_dresult_free(lgmi_dresult* r) {
     Pool& p = r->ctx->pool;
     p.release(r->d_i); p.release(r->d_j); p.release(r->d_mi); p.release(r->d_p);
     p.release(r->d_exceed); p.release(r->d_counts); p.release(r->d_mean); p.release(r->d_npairs);
-    p.release(r->d_sum);
+    p.release(r->d_sum); p.release(r->d_nrows);
     delete r;
 }
 
-extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out) {
+static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out, bool defer_perm) {
     if (!ctx || !db || !prm || !out) return fail(LGMI_E_ARG, "NULL argument");
     *out = nullptr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
@@ -785,7 +796,14 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     HIPCHK(hipEventRecord(ctx->ev[6], st));
-    if (want_p && cap_rows) {
+    if (defer_perm && want_p) {
+        // split run: the rows are final here; the permutation stage runs later on this result (lgmi_dresult_permute)
+        if ((rc = pool.alloc((void**)&res->d_nrows, 8))) return rc;
+        HIPCHK(hipMemcpyAsync(res->d_nrows, d_rowstart + n_items, 8, hipMemcpyDeviceToDevice, st));
+        res->perm_pending = true;
+        res->cap_rows = cap_rows;
+        res->prm = *prm;
+    } else if (want_p && cap_rows) {
         uint32_t* d_genlist;
         if ((rc = salloc((void**)&d_genlist, (size_t)cap_rows * 4))) return rc;
         PermArgs pa{};
@@ -837,9 +855,60 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&inf.ms_mean, ctx->ev[4], ctx->ev[5]));
     HIPCHK(hipEventElapsedTime(&inf.ms_total, ctx->ev[0], ctx->ev[5]));
-    if (!want_counts && res->d_counts) { pool.release(res->d_counts); res->d_counts = nullptr; }
+    if (!want_counts && res->d_counts && !res->perm_pending) { pool.release(res->d_counts); res->d_counts = nullptr; }
     guard.r = nullptr;
     *out = res;
+    return LGMI_OK;
+}
+
+extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out) {
+    return run_device_impl(ctx, db, prm, out, false);
+}
+
+// ---- split run: rows first, permutation stage later (a multi-GPU host gathers (i, j, mi) while the stage runs)
+extern "C" int lgmi_run_device_rows(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out) {
+    return run_device_impl(ctx, db, prm, out, true);
+}
+
+extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
+    if (!ctx || !res) return fail(LGMI_E_ARG, "NULL argument");
+    if (res->ctx != ctx) return fail(LGMI_E_ARG, "result belongs to another context");
+    if (!res->perm_pending) return LGMI_OK;              // nothing was deferred (no p requested, or already done)
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    Pool& pool = ctx->pool;
+    int rc = LGMI_OK;
+    uint32_t* d_genlist = nullptr; unsigned int* d_gencount = nullptr;
+    struct Guard { Pool& p; uint32_t** a; unsigned int** b; ~Guard() { p.release(*a); p.release(*b); } } guard{pool, &d_genlist, &d_gencount};
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    HIPCHK(hipEventRecord(ctx->ev[6], st));
+    unsigned int n_general = 0;
+    if (res->cap_rows) {
+        if ((rc = pool.alloc((void**)&d_genlist, (size_t)res->cap_rows * 4))) return rc;
+        if ((rc = pool.alloc((void**)&d_gencount, 4))) return rc;
+        HIPCHK(hipMemsetAsync(d_gencount, 0, 4, st));
+        PermArgs pa{};
+        pa.n_rows_dev = res->d_nrows; pa.max_rows = res->cap_rows;
+        pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
+        pa.n_shuffles = res->prm.n_shuffles; pa.seed = res->prm.seed; pa.exact_2x2 = res->prm.exact_2x2;
+        pa.out_p = res->d_p; pa.out_exceed = res->d_exceed; pa.gen_list = d_genlist; pa.gen_count = d_gencount;
+        launch_perm_fast(st, pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev[6], st));
+        launch_perm_general(st, pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&n_general, d_gencount, 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    HIPCHK(hipStreamSynchronize(st));
+    lgmi_run_info& inf = res->info;
+    inf.n_general_rows = n_general;
+    HIPCHK(hipEventElapsedTime(&inf.ms_perm, ctx->ev[3], ctx->ev[4]));
+    HIPCHK(hipEventElapsedTime(&inf.ms_perm_fast, ctx->ev[3], ctx->ev[6]));
+    HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));
+    inf.ms_total += inf.ms_perm;
+    res->perm_pending = false;
+    if (!res->has_counts && res->d_counts) { pool.release(res->d_counts); res->d_counts = nullptr; }
     return LGMI_OK;
 }
 

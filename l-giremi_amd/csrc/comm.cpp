@@ -18,6 +18,7 @@
 struct lgmi_dresult;
 namespace lgmi {
 hipStream_t ctx_stream(lgmi_ctx* c);
+hipStream_t ctx_comm_stream(lgmi_ctx* c);
 int ctx_device(lgmi_ctx* c);
 void** ctx_comm_slot(lgmi_ctx* c);
 int* ctx_rank_slot(lgmi_ctx* c);
@@ -118,8 +119,8 @@ extern "C" int lgmi_comm_allgather_u64v(lgmi_ctx* ctx, const uint64_t* mine, uin
     ncclComm_t comm = (ncclComm_t)*ctx_comm_slot(ctx);
     if (!comm) return set_error(LGMI_E_STATE, "lgmi_comm_init has not been called");
     const int world = *ctx_world_slot(ctx);
-    hipStream_t st = ctx_stream(ctx);
     HIPCHK2(hipSetDevice(ctx_device(ctx)));
+    hipStream_t st = ctx_comm_stream(ctx);
     uint64_t* d = nullptr;
     int rc = pool_alloc(ctx, (void**)&d, sizeof(uint64_t) * n * (size_t)(world + 1));
     if (rc) return rc;
@@ -166,10 +167,30 @@ enum { M_ROWS = 0, M_FLAGS, M_BASE, M_SITES, M_EXAMINED, M_GENERAL, M_SHUFFLES, 
 extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out);
 extern "C" void lgmi_dresult_free(lgmi_dresult* r);
 
-extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int root, const lgmi_gather_opts* opts,
-                                lgmi_dresult** out, uint64_t* rank_row_begin) {
-    if (!ctx || !mine || !out) return set_error(LGMI_E_ARG, "NULL argument");
-    *out = nullptr;
+// the state of a gather between its two halves
+struct lgmi_gather {
+    lgmi_ctx* ctx = nullptr;
+    const lgmi_dresult* mine = nullptr;
+    int root = 0, world = 1, rank = 0;
+    std::vector<uint64_t> meta;
+    uint64_t total = 0, total_sites = 0, examined = 0;
+    bool has_p = false, has_counts = false, same_batch = false, derive_p = false;
+    uint32_t n_shuffles = 0;
+    uint32_t *gi = nullptr, *gj = nullptr, *gexc = nullptr, *gcnt = nullptr, *gnp = nullptr;
+    double *gmi = nullptr, *gp = nullptr, *gmean = nullptr;
+    unsigned long long* gsum = nullptr;
+    uint64_t M(int r, int k) const { return meta[(size_t)r * M_N + k]; }
+    void release_all() {
+        pool_release(ctx, gi); pool_release(ctx, gj); pool_release(ctx, gmi); pool_release(ctx, gp); pool_release(ctx, gexc);
+        pool_release(ctx, gcnt); pool_release(ctx, gmean); pool_release(ctx, gnp); pool_release(ctx, gsum);
+        gi = gj = gexc = gcnt = gnp = nullptr; gmi = gp = gmean = nullptr; gsum = nullptr;
+    }
+};
+
+extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, int root, const lgmi_gather_opts* opts,
+                                      lgmi_gather** handle) {
+    if (!ctx || !mine || !handle) return set_error(LGMI_E_ARG, "NULL argument");
+    *handle = nullptr;
     ncclComm_t comm = (ncclComm_t)*ctx_comm_slot(ctx);
     if (!comm) return set_error(LGMI_E_STATE, "lgmi_comm_init has not been called");
     const int world = *ctx_world_slot(ctx), rank = *ctx_rank_slot(ctx);
@@ -177,8 +198,8 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
     lgmi_gather_opts o = {};
     if (opts) o = *opts;
     if (o.reserved[0] || o.reserved[1] || o.reserved[2] || o.same_batch > 1) return set_error(LGMI_E_ARG, "bad gather options");
-    hipStream_t st = ctx_stream(ctx);
     HIPCHK2(hipSetDevice(ctx_device(ctx)));
+    hipStream_t st = ctx_comm_stream(ctx);      // the rows of `mine` are final: its producer synchronised its stream
     DResultView v;
     dresult_view(mine, &v);
 
@@ -186,78 +207,69 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
     uint64_t my_meta[M_N];
     my_meta[M_ROWS] = v.n_rows;
     my_meta[M_FLAGS] = (v.p ? 1u : 0u) | (v.counts ? 2u : 0u) | (o.same_batch ? 4u : 0u) | (v.p && v.p_from_exceed ? 8u : 0u);
-    my_meta[M_SHUFFLES] = v.n_shuffles;
     my_meta[M_BASE] = o.site_base;
     my_meta[M_SITES] = v.n_sites;
     my_meta[M_EXAMINED] = v.info.n_examined;
-    my_meta[M_GENERAL] = v.info.n_general_rows;
-    std::vector<uint64_t> meta((size_t)world * M_N);
-    int rc = lgmi_comm_allgather_u64v(ctx, my_meta, M_N, meta.data());
+    my_meta[M_GENERAL] = 0;
+    my_meta[M_SHUFFLES] = v.n_shuffles;
+    lgmi_gather* h = new lgmi_gather();
+    struct Drop { lgmi_gather* p; ~Drop() { if (p) { p->release_all(); delete p; } } } drop{h};
+    h->ctx = ctx; h->mine = mine; h->root = root; h->world = world; h->rank = rank;
+    h->meta.resize((size_t)world * M_N);
+    int rc = lgmi_comm_allgather_u64v(ctx, my_meta, M_N, h->meta.data());
     if (rc) return rc;
-    auto M = [&](int r, int k) { return meta[(size_t)r * M_N + k]; };
-    uint64_t total = 0, total_sites = 0, examined = 0, general = 0;
     bool consistent = true;
     for (int r = 0; r < world; ++r) {
-        if (M(r, M_FLAGS) != M(0, M_FLAGS) || M(r, M_SHUFFLES) != M(0, M_SHUFFLES)) consistent = false;
-        if (o.same_batch && (M(r, M_BASE) != 0 || M(r, M_SITES) != M(0, M_SITES))) consistent = false;
-        if (M(r, M_BASE) + M(r, M_SITES) >= 0xFFFFFFF0ull) consistent = false;
-        total += M(r, M_ROWS);
-        total_sites = std::max<uint64_t>(total_sites, M(r, M_BASE) + M(r, M_SITES));
-        examined += M(r, M_EXAMINED);
-        general += M(r, M_GENERAL);
-    }
-    if (rank_row_begin) {
-        rank_row_begin[0] = 0;
-        for (int r = 0; r < world; ++r) rank_row_begin[r + 1] = rank_row_begin[r] + M(r, M_ROWS);
+        if (h->M(r, M_FLAGS) != h->M(0, M_FLAGS) || h->M(r, M_SHUFFLES) != h->M(0, M_SHUFFLES)) consistent = false;
+        if (o.same_batch && (h->M(r, M_BASE) != 0 || h->M(r, M_SITES) != h->M(0, M_SITES))) consistent = false;
+        if (h->M(r, M_BASE) + h->M(r, M_SITES) >= 0xFFFFFFF0ull) consistent = false;
+        h->total += h->M(r, M_ROWS);
+        h->total_sites = std::max<uint64_t>(h->total_sites, h->M(r, M_BASE) + h->M(r, M_SITES));
+        h->examined += h->M(r, M_EXAMINED);
     }
     // every rank holds the same meta table, so every rank takes this exit together
     if (!consistent)
-        return set_error(LGMI_E_ARG, "lgmi_comm_gather: ranks disagree (p / counts / same_batch flags, or same_batch with "
-                                     "different site counts or a non-zero site_base)");
-    const bool has_p = M(0, M_FLAGS) & 1u, has_counts = M(0, M_FLAGS) & 2u, same_batch = M(0, M_FLAGS) & 4u;
-    const bool derive_p = M(0, M_FLAGS) & 8u;          // p travels as its exceed count
-    const uint32_t n_shuffles = (uint32_t)M(0, M_SHUFFLES);
+        return set_error(LGMI_E_ARG, "lgmi_comm_gather: ranks disagree (p / counts / same_batch flags, shuffles, or same_batch "
+                                     "with different site counts or a non-zero site_base)");
+    h->has_p = h->M(0, M_FLAGS) & 1u; h->has_counts = h->M(0, M_FLAGS) & 2u; h->same_batch = h->M(0, M_FLAGS) & 4u;
+    h->derive_p = h->M(0, M_FLAGS) & 8u;               // p travels as its exceed count
+    h->n_shuffles = (uint32_t)h->M(0, M_SHUFFLES);
+    const uint64_t total = h->total, total_sites = h->total_sites;
 
     // ---- 2. the root allocates; the outcome is agreed on before anything is posted
-    uint32_t *gi = nullptr, *gj = nullptr, *gexc = nullptr, *gcnt = nullptr, *gnp = nullptr;
-    double *gmi = nullptr, *gp = nullptr, *gmean = nullptr;
-    unsigned long long* gsum = nullptr;
-    auto release_all = [&]() {
-        pool_release(ctx, gi); pool_release(ctx, gj); pool_release(ctx, gmi); pool_release(ctx, gp); pool_release(ctx, gexc);
-        pool_release(ctx, gcnt); pool_release(ctx, gmean); pool_release(ctx, gnp); pool_release(ctx, gsum);
-    };
     uint64_t my_status = 0;
     if (rank == root) {
         const size_t tn = (size_t)std::max<uint64_t>(total, 1), tsn = (size_t)std::max<uint64_t>(total_sites, 1);
-        int e = pool_alloc(ctx, (void**)&gi, tn * 4);
-        if (!e) e = pool_alloc(ctx, (void**)&gj, tn * 4);
-        if (!e) e = pool_alloc(ctx, (void**)&gmi, tn * 8);
-        if (!e && has_p) e = pool_alloc(ctx, (void**)&gp, tn * 8);
-        if (!e && has_p) e = pool_alloc(ctx, (void**)&gexc, tn * 4);
-        if (!e && has_counts) e = pool_alloc(ctx, (void**)&gcnt, tn * 36);
-        if (!e) e = pool_alloc(ctx, (void**)&gmean, tsn * 8);
-        if (!e) e = pool_alloc(ctx, (void**)&gnp, tsn * 4);
-        if (!e) e = pool_alloc(ctx, (void**)&gsum, tsn * 8);
+        int e = pool_alloc(ctx, (void**)&h->gi, tn * 4);
+        if (!e) e = pool_alloc(ctx, (void**)&h->gj, tn * 4);
+        if (!e) e = pool_alloc(ctx, (void**)&h->gmi, tn * 8);
+        if (!e && h->has_p) e = pool_alloc(ctx, (void**)&h->gp, tn * 8);
+        if (!e && h->has_p) e = pool_alloc(ctx, (void**)&h->gexc, tn * 4);
+        if (!e && h->has_counts) e = pool_alloc(ctx, (void**)&h->gcnt, tn * 36);
+        if (!e) e = pool_alloc(ctx, (void**)&h->gmean, tsn * 8);
+        if (!e) e = pool_alloc(ctx, (void**)&h->gnp, tsn * 4);
+        if (!e) e = pool_alloc(ctx, (void**)&h->gsum, tsn * 8);
         if (e) my_status = 1;
-    } else if (same_batch) {
+    } else if (h->same_batch) {
         // ncclReduce only writes recvbuff on the root, but every rank hands RCCL a valid device pointer
         const size_t tsn = (size_t)std::max<uint64_t>(v.n_sites, 1);
-        int e = pool_alloc(ctx, (void**)&gnp, tsn * 4);
-        if (!e) e = pool_alloc(ctx, (void**)&gsum, tsn * 8);
+        int e = pool_alloc(ctx, (void**)&h->gnp, tsn * 4);
+        if (!e) e = pool_alloc(ctx, (void**)&h->gsum, tsn * 8);
         if (e) my_status = 1;
     }
     std::vector<uint64_t> status(world);
     rc = lgmi_comm_allgather_u64v(ctx, &my_status, 1, status.data());
-    if (rc) { release_all(); return rc; }
+    if (rc) return rc;
     for (int r = 0; r < world; ++r)
-        if (status[r]) { release_all(); return set_error(LGMI_E_OOM, "lgmi_comm_gather: a rank could not allocate its buffers"); }
+        if (status[r]) return set_error(LGMI_E_OOM, "lgmi_comm_gather: a rank could not allocate its buffers");
 
     // different batches: sites no rank reports (gaps between the ranks' site ranges) read NaN / 0 pairs; queued on
     // the stream before the receives that fill the ranks' own ranges
-    if (rank == root && !same_batch && total_sites)
-        hipLaunchKernelGGL(k_fill_nan, dim3((uint32_t)((total_sites + 255) / 256)), dim3(256), 0, st, gmean, gnp, gsum, total_sites);
+    if (rank == root && !h->same_batch && total_sites)
+        hipLaunchKernelGGL(k_fill_nan, dim3((uint32_t)((total_sites + 255) / 256)), dim3(256), 0, st, h->gmean, h->gnp, h->gsum, total_sites);
 
-    // ---- 3. rows: one hop each over the xGMI mesh, straight into their place on the root
+    // ---- 3. what is final already — (i, j, mi) and the tables — one hop each over the xGMI mesh, straight into place on
+    //         the root.  Not waited for: the caller may run the permutation stage on its main stream meanwhile.
     ncclResult_t nr = ncclSuccess;
 #define NC(expr) do { if (nr == ncclSuccess) nr = (expr); } while (0)
     NC(g.GroupStart());
@@ -267,29 +279,17 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
             NC(g.Send(v.i, n, ncclUint32, root, comm, st));
             NC(g.Send(v.j, n, ncclUint32, root, comm, st));
             NC(g.Send(v.mi, n, ncclFloat64, root, comm, st));
-            if (has_p) { if (!derive_p) NC(g.Send(v.p, n, ncclFloat64, root, comm, st)); NC(g.Send(v.exceed, n, ncclUint32, root, comm, st)); }
-            if (has_counts) NC(g.Send(v.counts, n * 9, ncclUint32, root, comm, st));
-        }
-        if (!same_batch && v.n_sites) {
-            NC(g.Send(v.mean, v.n_sites, ncclFloat64, root, comm, st));
-            NC(g.Send(v.npairs, v.n_sites, ncclUint32, root, comm, st));
+            if (h->has_counts) NC(g.Send(v.counts, n * 9, ncclUint32, root, comm, st));
         }
     } else {
         uint64_t off = 0;
         for (int r = 0; r < world; ++r) {
-            const uint64_t c = M(r, M_ROWS), sb = M(r, M_BASE), sn = M(r, M_SITES);
-            if (r != root) {
-                if (c) {
-                    NC(g.Recv(gi + off, c, ncclUint32, r, comm, st));
-                    NC(g.Recv(gj + off, c, ncclUint32, r, comm, st));
-                    NC(g.Recv(gmi + off, c, ncclFloat64, r, comm, st));
-                    if (has_p) { if (!derive_p) NC(g.Recv(gp + off, c, ncclFloat64, r, comm, st)); NC(g.Recv(gexc + off, c, ncclUint32, r, comm, st)); }
-                    if (has_counts) NC(g.Recv(gcnt + 9 * off, c * 9, ncclUint32, r, comm, st));
-                }
-                if (!same_batch && sn) {
-                    NC(g.Recv(gmean + sb, sn, ncclFloat64, r, comm, st));
-                    NC(g.Recv(gnp + sb, sn, ncclUint32, r, comm, st));
-                }
+            const uint64_t c = h->M(r, M_ROWS);
+            if (r != root && c) {
+                NC(g.Recv(h->gi + off, c, ncclUint32, r, comm, st));
+                NC(g.Recv(h->gj + off, c, ncclUint32, r, comm, st));
+                NC(g.Recv(h->gmi + off, c, ncclFloat64, r, comm, st));
+                if (h->has_counts) NC(g.Recv(h->gcnt + 9 * off, c * 9, ncclUint32, r, comm, st));
             }
             off += c;
         }
@@ -298,54 +298,140 @@ extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int roo
         const ncclResult_t ge = g.GroupEnd();
         if (nr == ncclSuccess) nr = ge;
     }
-    // same batch: the shards' per-site integer sums and counts add up on the root (exact, any order)
-    if (nr == ncclSuccess && same_batch && v.n_sites) {
-        NC(g.Reduce(v.sum, gsum, v.n_sites, ncclUint64, ncclSum, root, comm, st));
-        NC(g.Reduce(v.npairs, gnp, v.n_sites, ncclUint32, ncclSum, root, comm, st));
+    if (nr != ncclSuccess) { (void)hipStreamSynchronize(st); return nccl_fail(nr, "lgmi_comm_gather_begin"); }
+    if (rank == root) {             // the root's own rows
+        hipError_t e = hipSuccess;
+        uint64_t off = 0;
+        for (int r = 0; r < root; ++r) off += h->M(r, M_ROWS);
+        const uint64_t n = v.n_rows;
+        auto d2d = [&](void* dst, const void* src, size_t bytes) {
+            if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+        };
+        d2d(h->gi + off, v.i, n * 4); d2d(h->gj + off, v.j, n * 4); d2d(h->gmi + off, v.mi, n * 8);
+        if (h->has_counts) d2d(h->gcnt + 9 * off, v.counts, n * 36);
+        if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_error(LGMI_E_HIP, hipGetErrorString(e)); }
     }
 #undef NC
-    if (nr != ncclSuccess) { (void)hipStreamSynchronize(st); release_all(); return nccl_fail(nr, "lgmi_comm_gather"); }
+    drop.p = nullptr;
+    *handle = h;
+    return LGMI_OK;
+}
+
+extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint64_t* rank_row_begin) {
+    if (!h || !out) { if (h) { h->release_all(); delete h; } return set_error(LGMI_E_ARG, "NULL argument"); }
+    *out = nullptr;
+    struct Drop { lgmi_gather* p; bool keep; ~Drop() { if (!keep) p->release_all(); delete p; } } drop{h, false};
+    lgmi_ctx* ctx = h->ctx;
+    ncclComm_t comm = (ncclComm_t)*ctx_comm_slot(ctx);
+    if (!comm) return set_error(LGMI_E_STATE, "the communicator is gone");
+    const int world = h->world, rank = h->rank, root = h->root;
+    if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return set_error(LGMI_E_HIP, "hipSetDevice");
+    hipStream_t st = ctx_comm_stream(ctx);
+    DResultView v;
+    dresult_view(h->mine, &v);      // (the permutation stage, if it ran in between, was synchronised by its caller)
+    if (rank_row_begin) {
+        rank_row_begin[0] = 0;
+        for (int r = 0; r < world; ++r) rank_row_begin[r + 1] = rank_row_begin[r] + h->M(r, M_ROWS);
+    }
+    // the larger-than-2x2 row counts are only known now
+    uint64_t my_general = v.info.n_general_rows;
+    std::vector<uint64_t> gen(world);
+    int rc = lgmi_comm_allgather_u64v(ctx, &my_general, 1, gen.data());
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    uint64_t general = 0;
+    for (int r = 0; r < world; ++r) general += gen[r];
+
+    // ---- 4. what the permutation stage made, then the per-site figures
+    ncclResult_t nr = ncclSuccess;
+#define NC(expr) do { if (nr == ncclSuccess) nr = (expr); } while (0)
+    NC(g.GroupStart());
+    if (rank != root) {
+        const uint64_t n = v.n_rows;
+        if (n && h->has_p) {
+            if (!h->derive_p) NC(g.Send(v.p, n, ncclFloat64, root, comm, st));
+            NC(g.Send(v.exceed, n, ncclUint32, root, comm, st));
+        }
+        if (!h->same_batch && v.n_sites) {
+            NC(g.Send(v.mean, v.n_sites, ncclFloat64, root, comm, st));
+            NC(g.Send(v.npairs, v.n_sites, ncclUint32, root, comm, st));
+        }
+    } else {
+        uint64_t off = 0;
+        for (int r = 0; r < world; ++r) {
+            const uint64_t c = h->M(r, M_ROWS), sb = h->M(r, M_BASE), sn = h->M(r, M_SITES);
+            if (r != root) {
+                if (c && h->has_p) {
+                    if (!h->derive_p) NC(g.Recv(h->gp + off, c, ncclFloat64, r, comm, st));
+                    NC(g.Recv(h->gexc + off, c, ncclUint32, r, comm, st));
+                }
+                if (!h->same_batch && sn) {
+                    NC(g.Recv(h->gmean + sb, sn, ncclFloat64, r, comm, st));
+                    NC(g.Recv(h->gnp + sb, sn, ncclUint32, r, comm, st));
+                }
+            }
+            off += c;
+        }
+    }
+    {
+        const ncclResult_t ge = g.GroupEnd();
+        if (nr == ncclSuccess) nr = ge;
+    }
+    // same batch: the shards' per-site integer sums and counts add up on the root (exact, any order)
+    if (nr == ncclSuccess && h->same_batch && v.n_sites) {
+        NC(g.Reduce(v.sum, h->gsum, v.n_sites, ncclUint64, ncclSum, root, comm, st));
+        NC(g.Reduce(v.npairs, h->gnp, v.n_sites, ncclUint32, ncclSum, root, comm, st));
+    }
+#undef NC
+    if (nr != ncclSuccess) { (void)hipStreamSynchronize(st); return nccl_fail(nr, "lgmi_comm_gather_finish"); }
     if (rank != root) {
         const hipError_t es = hipStreamSynchronize(st);
-        release_all();
         if (es != hipSuccess) return set_error(LGMI_E_HIP, hipGetErrorString(es));
         return LGMI_OK;
     }
-    // ---- 4. root: its own rows, the site bases, the per-site means
+    // ---- 5. root: its own p / exceed, the site bases, the per-site means
     hipError_t e = hipSuccess;
     uint64_t off = 0;
-    for (int r = 0; r < root; ++r) off += M(r, M_ROWS);
-    const uint64_t n = v.n_rows;
+    for (int r = 0; r < root; ++r) off += h->M(r, M_ROWS);
+    const uint64_t n = v.n_rows, total = h->total;
     auto d2d = [&](void* dst, const void* src, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
     };
-    d2d(gi + off, v.i, n * 4); d2d(gj + off, v.j, n * 4); d2d(gmi + off, v.mi, n * 8);
-    if (has_p) { if (!derive_p) d2d(gp + off, v.p, n * 8); d2d(gexc + off, v.exceed, n * 4); }
-    if (has_counts) d2d(gcnt + 9 * off, v.counts, n * 36);
-    if (has_p && derive_p && total)                        // every row, the root's own included
-        hipLaunchKernelGGL(k_p_from_exceed, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, gp, gexc, total, n_shuffles);
-    if (same_batch && v.n_sites)
+    if (h->has_p) { if (!h->derive_p) d2d(h->gp + off, v.p, n * 8); d2d(h->gexc + off, v.exceed, n * 4); }
+    if (h->has_p && h->derive_p && total)                  // every row, the root's own included
+        hipLaunchKernelGGL(k_p_from_exceed, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, h->gp, h->gexc, total, h->n_shuffles);
+    if (h->same_batch && v.n_sites)
         hipLaunchKernelGGL(k_mean_from_sums, dim3((uint32_t)((v.n_sites + 255) / 256)), dim3(256), 0, st,
-                           (uint32_t)v.n_sites, gsum, gnp, gmean);
+                           (uint32_t)v.n_sites, h->gsum, h->gnp, h->gmean);
     off = 0;
     for (int r = 0; r < world; ++r) {
-        const uint64_t c = M(r, M_ROWS), sb = M(r, M_BASE);
-        if (c && sb) hipLaunchKernelGGL(k_add_base, dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, gi + off, gj + off, c, (uint32_t)sb);
+        const uint64_t c = h->M(r, M_ROWS), sb = h->M(r, M_BASE);
+        if (c && sb) hipLaunchKernelGGL(k_add_base, dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, h->gi + off, h->gj + off, c, (uint32_t)sb);
         off += c;
     }
-    if (!same_batch) { d2d(gmean + M(root, M_BASE), v.mean, v.n_sites * 8); d2d(gnp + M(root, M_BASE), v.npairs, v.n_sites * 4); }
+    if (!h->same_batch) { d2d(h->gmean + h->M(root, M_BASE), v.mean, v.n_sites * 8); d2d(h->gnp + h->M(root, M_BASE), v.npairs, v.n_sites * 4); }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { release_all(); return set_error(LGMI_E_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) return set_error(LGMI_E_HIP, hipGetErrorString(e));
     DResultView gv;
-    gv.n_rows = total; gv.n_sites = total_sites;
-    gv.i = gi; gv.j = gj; gv.mi = gmi; gv.p = gp; gv.exceed = gexc; gv.counts = gcnt;
-    gv.mean = gmean; gv.npairs = gnp; gv.sum = gsum;
-    gv.n_shuffles = n_shuffles; gv.p_from_exceed = derive_p;
+    gv.n_rows = total; gv.n_sites = h->total_sites;
+    gv.i = h->gi; gv.j = h->gj; gv.mi = h->gmi; gv.p = h->gp; gv.exceed = h->gexc; gv.counts = h->gcnt;
+    gv.mean = h->gmean; gv.npairs = h->gnp; gv.sum = h->gsum;
+    gv.n_shuffles = h->n_shuffles; gv.p_from_exceed = h->derive_p;
     gv.info = v.info;                       // stage times stay the root's own
-    gv.info.n_rows = total; gv.info.n_examined = examined; gv.info.n_general_rows = general;
+    gv.info.n_rows = total; gv.info.n_examined = h->examined; gv.info.n_general_rows = general;
     *out = dresult_new_gathered(ctx, gv);
+    drop.keep = true;                       // the buffers belong to the gathered result now
     return LGMI_OK;
+}
+
+extern "C" int lgmi_comm_gather(lgmi_ctx* ctx, const lgmi_dresult* mine, int root, const lgmi_gather_opts* opts,
+                                lgmi_dresult** out, uint64_t* rank_row_begin) {
+    if (!out) return set_error(LGMI_E_ARG, "NULL argument");
+    *out = nullptr;
+    lgmi_gather* h = nullptr;
+    const int rc = lgmi_comm_gather_begin(ctx, mine, root, opts, &h);
+    if (rc) return rc;
+    return lgmi_comm_gather_finish(h, out, rank_row_begin);
 }
 
 extern "C" int lgmi_comm_gather_rows(lgmi_ctx* ctx, const lgmi_dresult* mine, int root, lgmi_result* out) {

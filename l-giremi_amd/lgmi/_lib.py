@@ -95,6 +95,8 @@ SYMBOLS = {
     'lgmi_dbatch_download': (C.c_int, [VP, C.POINTER(Batch)]),
     'lgmi_dbatch_free': (None, [VP]),
     'lgmi_run_device': (C.c_int, [VP, VP, C.POINTER(Params), C.POINTER(VP)]),
+    'lgmi_run_device_rows': (C.c_int, [VP, VP, C.POINTER(Params), C.POINTER(VP)]),
+    'lgmi_dresult_permute': (C.c_int, [VP, VP]),
     'lgmi_dresult_info': (C.c_int, [VP, C.POINTER(RunInfo)]),
     'lgmi_dresult_device_ptrs': (C.c_int, [VP, C.POINTER(Result)]),
     'lgmi_dresult_fetch': (C.c_int, [VP, C.POINTER(Result)]),
@@ -112,6 +114,8 @@ SYMBOLS = {
     'lgmi_comm_allgather_u64': (C.c_int, [VP, C.c_uint64, u64p]),
     'lgmi_comm_allgather_u64v': (C.c_int, [VP, u64p, C.c_uint32, u64p]),
     'lgmi_comm_gather': (C.c_int, [VP, VP, C.c_int, C.POINTER(GatherOpts), C.POINTER(VP), u64p]),
+    'lgmi_comm_gather_begin': (C.c_int, [VP, VP, C.c_int, C.POINTER(GatherOpts), C.POINTER(VP)]),
+    'lgmi_comm_gather_finish': (C.c_int, [VP, C.POINTER(VP), u64p]),
     'lgmi_comm_gather_rows': (C.c_int, [VP, VP, C.c_int, C.POINTER(Result)]),
     'lgmi_comm_destroy': (None, [VP]),
 }

@@ -121,6 +121,10 @@ class DeviceResult:
         _lib.check(self.engine.lib.lgmi_dresult_info(self.handle, C.byref(ri)))
         return ri.as_dict()
 
+    def permute(self):
+        """the permutation stage of a result made with run_device(..., rows_only=True)"""
+        _lib.check(self.engine.lib.lgmi_dresult_permute(self.engine.handle, self.handle))
+
     def fetch(self) -> MIResult:
         res = _lib.Result()
         _lib.check(self.engine.lib.lgmi_dresult_fetch(self.handle, C.byref(res)))
@@ -139,6 +143,24 @@ class DeviceResult:
             self.free()
         except Exception:
             pass
+
+
+class GatherInFlight:
+    """a gather between lgmi_comm_gather_begin and lgmi_comm_gather_finish (keeps its source result alive)"""
+
+    def __init__(self, engine, handle, source):
+        self.engine, self.handle, self.source = engine, handle, source
+
+    def finish(self):
+        """-> (DeviceResult on the root / None elsewhere, rank_row_begin list)"""
+        if not self.handle:
+            raise RuntimeError('gather already finished')
+        h, self.handle = self.handle, None
+        out = C.c_void_p()
+        begins = (C.c_uint64 * (self.engine.world + 1))()
+        _lib.check(self.engine.lib.lgmi_comm_gather_finish(h, C.byref(out), begins))
+        self.source = None
+        return (DeviceResult(self.engine, out) if out else None), [int(b) for b in begins]
 
 
 class Engine:
@@ -223,10 +245,13 @@ class Engine:
         return self.synth_dense(default_synth_spec(n_sites, n_reads, seed=seed, n_blocks=n_blocks))
 
     def run_device(self, dbatch: DeviceBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-                   emit_counts=False, exact_2x2=False, shard=None) -> DeviceResult:
+                   emit_counts=False, exact_2x2=False, shard=None, rows_only=False) -> DeviceResult:
+        """rows_only=True stops when the rows (i, j, mi, tables, per-site means) are final; DeviceResult.permute()
+        runs the permutation stage later — a multi-GPU host starts the row gather in between (comm_gather_begin)"""
         self._alive()
         prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard), C.c_void_p()
-        _lib.check(self.lib.lgmi_run_device(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
+        fn = self.lib.lgmi_run_device_rows if rows_only else self.lib.lgmi_run_device
+        _lib.check(fn(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
         return DeviceResult(self, h)
 
     def selftest_le_exp(self, x2, t):
@@ -319,6 +344,15 @@ class Engine:
         begins = (C.c_uint64 * (self.world + 1))()
         _lib.check(self.lib.lgmi_comm_gather(self.handle, dresult.handle, int(root), C.byref(opts), C.byref(h), begins))
         return (DeviceResult(self, h) if h else None), [int(b) for b in begins]
+
+    def comm_gather_begin(self, dresult: 'DeviceResult', root=0, site_base=0, same_batch=False) -> 'GatherInFlight':
+        """first half of comm_gather on the communication stream: sizes exchanged, (i, j, mi[, tables]) posted; returns
+        while they travel.  Call .finish() after dresult.permute()."""
+        self._alive()
+        opts = _lib.GatherOpts(int(site_base), 1 if same_batch else 0, (C.c_uint8 * 3)())
+        h = C.c_void_p()
+        _lib.check(self.lib.lgmi_comm_gather_begin(self.handle, dresult.handle, int(root), C.byref(opts), C.byref(h)))
+        return GatherInFlight(self, h, dresult)
 
     def comm_gather_rows(self, dresult: 'DeviceResult', root=0):
         """every rank's (row_i, row_j, row_mi[, row_p]) concatenated in rank order on `root`"""

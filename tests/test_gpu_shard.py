@@ -110,3 +110,44 @@ def test_single_rank_device_gather_keeps_everything(engine):
         assert (got.site_n_pairs[:base] == 0).all() and np.isnan(got.site_mean_mi[:base]).all()
     dr.free()
     db.free()
+
+
+def test_split_run_and_two_phase_gather(engine):
+    """lgmi_run_device_rows + lgmi_dresult_permute == lgmi_run_device, and the gather started between the two halves
+    (begin: sizes + (i, j, mi, tables) on the communication stream; finish: exceed, p, per-site figures) returns the
+    same result as the one-call gather — the shape a multi-GPU step uses to hide the row transfer under the
+    permutation kernels"""
+    pb = random_batch(777, n_blocks=3, tri_frac=0.3)
+    try:
+        engine.comm_init(engine.comm_unique_id(), 0, 1)
+    except Exception as e:
+        assert 'already' in str(e)
+    db = engine.upload(pb)
+    kw = dict(min_common=3, het_only=True, n_shuffles=25, seed=9, emit_counts=True)
+    whole = engine.run_device(db, **kw)
+    ref = whole.fetch()
+    whole.free()
+    for counts in (True, False):
+        kw['emit_counts'] = counts
+        dr = engine.run_device(db, rows_only=True, **kw)
+        assert dr.info()['ms_perm'] < 0.5 and dr.info()['n_rows'] == ref.n_rows
+        flight = engine.comm_gather_begin(dr, root=0, same_batch=True)
+        dr.permute()
+        assert dr.info()['n_general_rows'] == ref.info['n_general_rows']
+        g, begins = flight.finish()
+        got, own = g.fetch(), dr.fetch()
+        g.free()
+        dr.free()
+        assert begins == [0, ref.n_rows]
+        for res in (got, own):
+            for f in ('row_i', 'row_j', 'row_mi', 'row_p', 'row_exceed', 'site_n_pairs', 'site_mean_mi'):
+                np.testing.assert_array_equal(getattr(res, f), getattr(ref, f))
+            if counts:
+                np.testing.assert_array_equal(res.row_counts, ref.row_counts)
+            else:
+                assert res.row_counts is None
+    dr = engine.run_device(db, rows_only=True, min_common=3, het_only=True)       # no p requested: permute is a no-op
+    dr.permute()
+    np.testing.assert_array_equal(dr.fetch().row_mi, ref.row_mi)
+    dr.free()
+    db.free()
