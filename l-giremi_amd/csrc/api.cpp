@@ -936,45 +936,57 @@ extern "C" void lgmi_result_free(lgmi_result* res) {
     memset(res, 0, sizeof *res);
 }
 
+// HBM -> pinned host buffers in two parts, so that lgmi_run can bring the rows over while the permutation stage still
+// runs: part 1 = everything that is final after the emit stage, part 2 = row_p / row_exceed
+static int fetch_part(lgmi_dresult* r, HostResult* h, lgmi_result* out, hipStream_t st, int part) {
+    const size_t n = (size_t)r->n_rows, ns = (size_t)r->n_sites;
+    auto d2h = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    };
+    if (part == 1) {
+        uint32_t* hi = h->take<uint32_t>(n); uint32_t* hj = h->take<uint32_t>(n); double* hmi = h->take<double>(n);
+        double* hmean = h->take<double>(ns); uint32_t* hnp = h->take<uint32_t>(ns);
+        uint32_t* hc = r->has_counts ? h->take<uint32_t>(n * 9) : nullptr;
+        if (!hi || !hj || !hmi || !hmean || !hnp || (r->has_counts && !hc)) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
+        HIPCHK(d2h(hi, r->d_i, n * 4));
+        HIPCHK(d2h(hj, r->d_j, n * 4));
+        HIPCHK(d2h(hmi, r->d_mi, n * 8));
+        HIPCHK(d2h(hmean, r->d_mean, ns * 8));
+        HIPCHK(d2h(hnp, r->d_npairs, ns * 4));
+        if (r->has_counts) HIPCHK(d2h(hc, r->d_counts, n * 36));
+        out->n_rows = n; out->n_sites = ns;
+        out->row_i = hi; out->row_j = hj; out->row_mi = hmi; out->row_counts = hc;
+        out->site_mean_mi = hmean; out->site_n_pairs = hnp;
+    } else if (r->has_p) {
+        double* hp = h->take<double>(n); uint32_t* hex = h->take<uint32_t>(n);
+        if (!hp || !hex) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
+        HIPCHK(d2h(hp, r->d_p, n * 8));
+        HIPCHK(d2h(hex, r->d_exceed, n * 4));
+        out->row_p = hp; out->row_exceed = hex;
+    }
+    return LGMI_OK;
+}
+
 extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out) {
     if (!r || !out) return fail(LGMI_E_ARG, "NULL argument");
     memset(out, 0, sizeof *out);
+    if (r->perm_pending) return fail(LGMI_E_STATE, "the permutation stage of this result has not run (lgmi_dresult_permute)");
     HIPCHK(hipSetDevice(r->ctx->device));
     HostResult* h = new HostResult();
     h->pool = r->ctx->pinned;
     struct Guard { HostResult* p; ~Guard() { delete p; } } guard{h};
-    const size_t n = (size_t)r->n_rows, ns = (size_t)r->n_sites;
     hipStream_t st = r->ctx->stream;
-    uint32_t* hi = h->take<uint32_t>(n); uint32_t* hj = h->take<uint32_t>(n); double* hmi = h->take<double>(n);
-    double* hmean = h->take<double>(ns); uint32_t* hnp = h->take<uint32_t>(ns);
-    double* hp = r->has_p ? h->take<double>(n) : nullptr;
-    uint32_t* hex = r->has_p ? h->take<uint32_t>(n) : nullptr;
-    uint32_t* hc = r->has_counts ? h->take<uint32_t>(n * 9) : nullptr;
-    if (!hi || !hj || !hmi || !hmean || !hnp || (r->has_p && (!hp || !hex)) || (r->has_counts && !hc))
-        return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
-    auto d2h = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
-    };
-    HIPCHK(d2h(hi, r->d_i, n * 4));
-    HIPCHK(d2h(hj, r->d_j, n * 4));
-    HIPCHK(d2h(hmi, r->d_mi, n * 8));
-    HIPCHK(d2h(hmean, r->d_mean, ns * 8));
-    HIPCHK(d2h(hnp, r->d_npairs, ns * 4));
-    if (r->has_p) {
-        HIPCHK(d2h(hp, r->d_p, n * 8));
-        HIPCHK(d2h(hex, r->d_exceed, n * 4));
-    }
-    if (r->has_counts) HIPCHK(d2h(hc, r->d_counts, n * 36));
+    int rc = fetch_part(r, h, out, st, 1);
+    if (!rc) rc = fetch_part(r, h, out, st, 2);
+    if (rc) { memset(out, 0, sizeof *out); return rc; }
     HIPCHK(hipStreamSynchronize(st));
-    out->n_rows = n; out->n_sites = ns;
-    out->row_i = hi; out->row_j = hj; out->row_mi = hmi;
-    out->row_p = hp; out->row_exceed = hex; out->row_counts = hc;
-    out->site_mean_mi = hmean; out->site_n_pairs = hnp;
     out->owner_ = static_cast<ResultOwner*>(h);
     guard.p = nullptr;
     return LGMI_OK;
 }
 
+// upload + run + fetch in one call.  With permutation p-values the run is split: the rows start their way to the host
+// (communication stream) while the permutation stage runs on the main stream.
 extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_params* prm, lgmi_result* out,
                         lgmi_run_info* info) {
     if (!out) return fail(LGMI_E_ARG, "out is NULL");
@@ -983,10 +995,20 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
     int rc = lgmi_batch_upload(ctx, batch, &db);
     if (rc) return rc;
     lgmi_dresult* dr = nullptr;
-    rc = lgmi_run_device(ctx, db, prm, &dr);
+    rc = run_device_impl(ctx, db, prm, &dr, true);
     if (!rc) {
-        if (info) *info = dr->info;
-        rc = lgmi_dresult_fetch(dr, out);
+        HostResult* h = new HostResult();
+        h->pool = ctx->pinned;
+        hipStream_t cs = ctx_comm_stream(ctx);
+        rc = fetch_part(dr, h, out, cs, 1);                 // in flight under the permutation stage
+        if (!rc) rc = lgmi_dresult_permute(ctx, dr);
+        if (!rc) rc = fetch_part(dr, h, out, cs, 2);
+        if (!rc && hipStreamSynchronize(cs) != hipSuccess) rc = fail(LGMI_E_HIP, "hipStreamSynchronize failed in lgmi_run");
+        if (rc) { (void)hipStreamSynchronize(cs); delete h; memset(out, 0, sizeof *out); }
+        else {
+            out->owner_ = static_cast<ResultOwner*>(h);
+            if (info) *info = dr->info;
+        }
     }
     lgmi_dresult_free(dr);
     lgmi_dbatch_free(db);
