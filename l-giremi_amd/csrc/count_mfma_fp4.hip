@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     const v4i *cx0, *cx1, *cy0, *cy1;
     {
         const uint32_t gx = (t.x0 >> 5) + 2u * wx, gy = (t.y0 >> 5) + 2u * wy;
+        // per-lane pointers; wave-uniform bases in scalar registers (saddr loads) were measured 2 % slower
         const v4i* xb = reinterpret_cast<const v4i*>(ops + bp.xop_off) + lane;
         const v4i* yb = reinterpret_cast<const v4i*>(ops + bp.yop_off) + lane;
         cx0 = xb + ((uint64_t)(gx < gxn ? gx : 0u) * bp.op_steps + t0) * 128u;
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     LGMI_MFMA4(acc[1][1][0], O.a[2], O.b[2]); LGMI_MFMA4(acc[1][1][1], O.a[3], O.b[2]);                 \
     LGMI_MFMA4(acc[1][1][2], O.a[2], O.b[3]); LGMI_MFMA4(acc[1][1][3], O.a[3], O.b[3]);
 #ifndef LGMI_ABL
-#define LGMI_ABL 0      // timing-only ablations (tools/abl_mfma.sh): 1 operands never rebuilt, 2 no loads at all, 4 no loads inside the loop
+#define LGMI_ABL 0      // timing-only ablations (tools/abl_mfma.sh): 1 operands never rebuilt, 2 no loads at all, 4 no loads inside the loop,
+                        // 8 loads always hit L1, 16 one load after every fourth MFMA, 32 non-temporal loads, 64 a barrier per trip
 #endif
     // operands of bit I (0..3) of every nibble (table in the header)
 #if LGMI_ABL & 1
@@ -138,6 +140,10 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     // plane quads (C, A) of step ST (relative to the tile's first step) of group stream C
 #if LGMI_ABL & 2
 #define LGMI_LOAD2(QC, QA, C, ST) { QC = v4i{(int)(ST), 1, 2, 3}; QA = v4i{4, 5, (int)(ST), 7}; }
+#elif LGMI_ABL & 8     // every load re-reads step 0: the same instructions, always L1 hits
+#define LGMI_LOAD2(QC, QA, C, ST) { QC = C[0]; QA = C[64u]; }
+#elif LGMI_ABL & 32    // streaming hint
+#define LGMI_LOAD2(QC, QA, C, ST) { QC = __builtin_nontemporal_load(&C[(ST) * 128u]); QA = __builtin_nontemporal_load(&C[(ST) * 128u + 64u]); }
 #else
 #define LGMI_LOAD2(QC, QA, C, ST) { QC = C[(ST) * 128u]; QA = C[(ST) * 128u + 64u]; }
 #endif
@@ -159,11 +165,23 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
 #define LGMI_LOADX(FAR, KW) LGMI_LOAD2(FAR.x[0], FAR.x[1], cx0, (KW)) LGMI_LOAD2(FAR.x[2], FAR.x[3], cx1, (KW))
 #define LGMI_LOADY(FAR, KW) LGMI_LOAD2(FAR.y[0], FAR.y[1], cy0, (KW)) LGMI_LOAD2(FAR.y[2], FAR.y[3], cy1, (KW))
 #endif
+    // the same slot with one of its four loads after every fourth MFMA
+#define LGMI_SLOT_END_L(V)                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+        __builtin_amdgcn_sched_group_barrier(0x002, (V), 0);                                            \
+        if ((g_ & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#if !(LGMI_ABL & 16)
+#undef LGMI_SLOT_END_L
+#define LGMI_SLOT_END_L(V) LGMI_SLOT_END(V)
+#endif
 #define LGMI_STEP(CUR, NXT, FAR, KW)                                                                  \
     LGMI_LOADX(FAR, KW)                                                                               \
-    LGMI_OPS(Q, CUR, 1) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                                 \
+    LGMI_OPS(Q, CUR, 1) LGMI_MFMA16(P) LGMI_SLOT_END_L(4)                                               \
     LGMI_LOADY(FAR, KW)                                                                               \
-    LGMI_OPS(P, CUR, 2) LGMI_MFMA16(Q) LGMI_SLOT_END(5)                                                 \
+    LGMI_OPS(P, CUR, 2) LGMI_MFMA16(Q) LGMI_SLOT_END_L(5)                                               \
     LGMI_OPS(Q, CUR, 3) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                                 \
     LGMI_OPS(P, NXT, 0) LGMI_MFMA16(Q) LGMI_SLOT_END(3)
 
@@ -191,6 +209,12 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     LGMI_LOAD_ALL(rd, 3u) __builtin_amdgcn_sched_barrier(0);
     LGMI_OPS(P, ra, 0)
     for (uint32_t s = 0; s < n_trip; ++s) {
+#if LGMI_ABL & 64
+        __syncthreads();                                                   // the four waves re-aligned every five steps
+#endif
+#if LGMI_ABL & 8
+        asm volatile("" : "+v"(cx0), "+v"(cx1), "+v"(cy0), "+v"(cy1));   // keeps the invariant loads inside the loop
+#endif
         LGMI_STEP(ra, rb, re, st + 4u)
         LGMI_STEP(rb, rc, ra, st + 5u)
         LGMI_STEP(rc, rd, rb, st + 6u)
