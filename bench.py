@@ -246,7 +246,7 @@ def main():
         ms_count = sum(i['ms_count'] for i in infos) / len(infos)
         if True:
             examined_job = info['n_examined_total'] if strong else sum(int(p['n_examined']) for p in per_rank)
-            rows_job = sum(info.get('world_rows', [info['n_rows']]))
+            rows_job = sum(info['world_rows']) if 'world_rows' in info else sum(int(p['n_rows']) for p in per_rank)
             general_job = info['n_general_rows']                    # this rank's; scaled below for the job-wide rate
             # dominant kernel: k_count.  Algorithmic HBM bytes per launch:
             # every column's planes once (16 B per 64-read word) + site metadata + the 4 count planes
