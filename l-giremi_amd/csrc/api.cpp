@@ -665,6 +665,8 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     int rc;
 
     // the log-factorial table also serves the binomial draw of the 2 x 2 path: LF[0 .. n_shuffles]
+    if (want_p && db->max_reads >= (1u << 28))
+        return fail(LGMI_E_ARG, "the permutation test takes blocks of fewer than 2^28 reads (%u)", db->max_reads);
     if (want_p && (rc = ensure_perm_tables(ctx, std::max(db->max_reads, prm->n_shuffles)))) return rc;   // first use only
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     const auto t_plan0 = std::chrono::steady_clock::now();
@@ -720,7 +722,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
     if ((rc = salloc((void**)&d_cnt, (size_t)ns * 4 + 16))) return rc;
     d_err = (int*)(d_cnt + ns);
-    unsigned int* d_gencount = (unsigned int*)(d_cnt + ns) + 1;
+    unsigned int* d_gencount = (unsigned int*)(d_cnt + ns) + 1;    // [0] queued rows, [1] k_perm_general's next row (zeroed with d_cnt)
     d_wordpairs = nullptr;
     if ((rc = salloc((void**)&d_wordpairs, 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_mean, (size_t)ns * 8))) return rc;
@@ -885,8 +887,8 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
     unsigned int n_general = 0;
     if (res->cap_rows) {
         if ((rc = pool.alloc((void**)&d_genlist, (size_t)res->cap_rows * 4))) return rc;
-        if ((rc = pool.alloc((void**)&d_gencount, 4))) return rc;
-        HIPCHK(hipMemsetAsync(d_gencount, 0, 4, st));
+        if ((rc = pool.alloc((void**)&d_gencount, 8))) return rc;       // [0] queued rows, [1] k_perm_general's next row
+        HIPCHK(hipMemsetAsync(d_gencount, 0, 8, st));
         PermArgs pa{};
         pa.n_rows_dev = res->d_nrows; pa.max_rows = res->cap_rows;
         pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.G = ctx->d_G; pa.LF = ctx->d_LF;

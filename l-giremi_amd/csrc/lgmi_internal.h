@@ -155,7 +155,7 @@ struct PermArgs {
     uint32_t n_shuffles; uint64_t seed;
     int exact_2x2;                // rows with at most 2 x 2 non-empty classes get the exact p, not a binomial draw
     double* out_p; uint32_t* out_exceed;
-    uint32_t* gen_list; unsigned int* gen_count;
+    uint32_t* gen_list; unsigned int* gen_count;   // gen_count[0] rows queued by k_perm_fast, [1] next row of k_perm_general (both zero at launch)
 };
 void launch_perm_fast(hipStream_t st, const PermArgs& a);
 void launch_perm_general(hipStream_t st, const PermArgs& a);

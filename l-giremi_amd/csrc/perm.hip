@@ -37,17 +37,30 @@
 //    8 threshold-table draw replaced by a cheap hash      16 general rows not queued (k_perm_fast alone)
 //   32 exact-tail sums skipped      64 bisection skipped      128 binomial draw skipped
 // 1024 statistic look-ups skipped      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
+// 131072 streamlined 3x2 loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
 // Every surviving bit keeps all table indices inside the range the normal path uses and keeps every rejection
 // loop's acceptance probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the
 // acceptance test unsatisfiable, so k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536,
 // one of which indexed LF[] with set-up values it had skipped (GPU memory fault).  They are gone for good.
 #endif
-#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192)
+#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192 | 131072)
 #if LGMI_PABL & ~LGMI_PABL_KNOWN
 #error "LGMI_PABL: unknown ablation bit (see the list above; 256, 2048, 16384, 32768, 65536 were removed: they hang or fault)"
 #endif
 
 namespace lgmi {
+
+// The two host-built tables, read as base (scalar registers) + 32-bit byte offset: the look-ups compile to
+// `global_load_dwordx2 v, v_off, s[base]` — one shift per look-up instead of a 64-bit address in two more VGPRs.
+// (Entries < 2^28: lgmi_run_device checks it.)
+template <class T> struct Tab {
+    const T* p;
+    __device__ __forceinline__ T operator[](uint32_t i) const {
+        return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + (size_t)(i * (uint32_t)sizeof(T)));
+    }
+};
+typedef Tab<long long> TabG;
+typedef Tab<double> TabLF;
 
 #if LGMI_PABL
 __device__ __forceinline__ U4 cheap_rng(uint32_t a, uint32_t b) {
@@ -105,9 +118,9 @@ __device__ __forceinline__ double det_exp(double x) {
 // and checks |__expf / det_exp - 1| < 2.5e-5 and that le_exp never disagrees with det_exp on adversarial x2.
 __device__ __forceinline__ bool le_exp(double x2, double t) {
     const double e = (double)__expf((float)t);
-    if (x2 <= e * 0.9999) return true;
-    if (x2 >= e * 1.0001) return false;
-    return x2 <= det_exp(t);
+    bool r = x2 <= e * 0.9999;
+    if (!r && x2 < e * 1.0001) r = x2 <= det_exp(t);    // the only branch: a handful of lanes per million
+    return r;
 }
 
 __device__ __forceinline__ double det_log(double x) {   // x > 0, normal
@@ -138,11 +151,11 @@ __device__ __forceinline__ double det_sqrt(double a) {   // a > 0: division-free
 // ---------------------------------------------------------------- 2 x 2 exact tail
 struct HG22 { uint32_t N, K, n, kmin, kmax; double c0; };
 
-__device__ __forceinline__ long long stat22(const long long* __restrict__ G, const HG22& h, uint32_t k) {
+__device__ __forceinline__ long long stat22(TabG G, const HG22& h, uint32_t k) {
     return G[h.N - h.K - h.n + k] + G[h.n - k] + G[h.K - k] + G[k];
 }
 
-__device__ __forceinline__ double pmf22(const double* __restrict__ LF, const HG22& h, uint32_t k) {
+__device__ __forceinline__ double pmf22(TabLF LF, const HG22& h, uint32_t k) {
 #if LGMI_PABL & 4096
     { const uint32_t md = h.N + 1u;   // LF[] has at least N + 1 entries
       return det_exp(h.c0 - LF[(k & 15u) % md] - LF[((h.K - k) & 15u) % md] - LF[((h.n - k) & 15u) % md] - LF[((h.N - h.K - h.n + k) & 15u) % md] - 3.0e6); }
@@ -195,7 +208,7 @@ __device__ __forceinline__ long long first_true(long long lo, long long hi, long
     return r;
 }
 
-__device__ Tail22 bounds22(const long long* __restrict__ G, const HG22& h, uint32_t kobs) {
+__device__ Tail22 bounds22(TabG G, const HG22& h, uint32_t kobs) {
     const long long sobs = stat22(G, h, kobs);
     uint32_t kc = (uint32_t)(((unsigned long long)h.n * (unsigned long long)h.K) / (unsigned long long)h.N);
     if (kc < h.kmin) kc = h.kmin;
@@ -229,8 +242,9 @@ __device__ Tail22 bounds22(const long long* __restrict__ G, const HG22& h, uint3
 // grid.  The mass of a range is the INTEGER sum of its units: it does not depend on which lane sums which unit
 // or on the order of the additions (CPU specification: unit_mass / range_mass in oracle/lgmi_perm_oracle.c).
 static const uint32_t UNIT = 64, SUB = 16;
+static const uint32_t QBATCH = 4;     // rows a wave of k_perm_general takes from the shared counter at a time
 
-__device__ __forceinline__ unsigned long long unit_mass(const double* __restrict__ LF, const HG22& h, uint32_t k0, uint32_t len) {
+__device__ __forceinline__ unsigned long long unit_mass(TabLF LF, const HG22& h, uint32_t k0, uint32_t len) {
     uint32_t k = k0;
     double term = pmf22(LF, h, k), sum = term;
     uint32_t rem = len - 1u;
@@ -261,7 +275,7 @@ __device__ __forceinline__ unsigned long long unit_mass(const double* __restrict
 // variate instead of n_shuffles Bernoulli trials (the CPU specification is binom_draw in
 // oracle/lgmi_perm_oracle.c).  thr = trunc(P * 2^32).  n p < 10: sequential inversion (BINV), otherwise
 // Hoermann's transformed rejection (BTRS) tested against the exact log-factorials.  One lane per row.
-__device__ uint32_t binom_draw(const double* __restrict__ LF, uint32_t n, unsigned long long thr, uint32_t ci,
+__device__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned long long thr, uint32_t ci,
                                uint32_t cj, uint32_t k0, uint32_t k1) {
     if (thr == 0ull || n == 0u) return 0u;
     if (thr >= 4294967296ull) return n;
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     const uint64_t n_rows = *pa.n_rows_dev;
     const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
     const uint32_t* __restrict__ counts = pa.counts;
-    const long long* __restrict__ G = pa.G; const double* __restrict__ LF = pa.LF;
+    const TabG G{pa.G}; const TabLF LF{pa.LF};
     const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
     double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
     uint32_t* __restrict__ gen_list = pa.gen_list; unsigned int* __restrict__ gen_count = pa.gen_count;
@@ -333,6 +347,8 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     // persistent one-wave workgroups: a fixed grid strides over the 64-row chunks (the row count is only known on
     // the device, and 7 million one-wave workgroups per launch were a cost of their own)
     const uint64_t n_chunks = (n_rows + 63ull) / 64ull;
+    // (a fixed stride: taking the chunks from a shared counter, as k_perm_general takes its rows, was measured
+    // slower here — 79 ms against 63 with 4 chunks per atomic, 139 ms with one)
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // wave-uniform trip count: the grid drains
     const uint64_t r = chunk * 64ull + lane;
     // ---- phase A (one lane per row): classify, set up the hypergeometric, find the bounds
@@ -513,6 +529,11 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 // needed and sets up the next real draw inside the same trip.  The stream of uniforms of a
 // shuffle is consumed strictly in order, so the result is that of the sequential
 // specification (oracle/lgmi_perm_oracle.c: perm_one) whatever the interleaving.
+#if LGMI_PABL & 131072
+#define LGMI_IX(i) ((i) & 15u)
+#else
+#define LGMI_IX(i) (i)
+#endif
 #define HRUA_D1 1.7155277699214135
 #define HRUA_D2 0.8989161620588988
 
@@ -572,18 +593,27 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
     const uint32_t* __restrict__ gen_list = pa.gen_list; const unsigned int* __restrict__ gen_count = pa.gen_count;
     const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
     const uint32_t* __restrict__ counts = pa.counts;
-    const long long* __restrict__ G = pa.G; const double* __restrict__ LF = pa.LF;
+    const TabG G{pa.G}; const TabLF LF{pa.LF};
     const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
     double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
     __shared__ uint32_t tab_thr[FIRST_MAX];
     __shared__ uint16_t tab_guide[257];     // tab_guide[b] = the draw for u = b << 24: where the search for u >> 24 == b starts
     __shared__ uint32_t next_s;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_gen = *gen_count;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    for (uint32_t q = wave; q < n_gen; q += n_waves) {   // every wave reaches q >= n_gen: the grid drains
+    // rows are taken from a shared counter (gen_count[1], zero at launch), the next one asked for while the current
+    // one runs: rows differ in cost (table size, streamlined or general loop) and a fixed stride left the average
+    // wave idle for the last ~15 % of the kernel (SQ_WAVE_CYCLES against SQ_BUSY_CYCLES)
+    unsigned int* const next_row = pa.gen_count + 1;
+    uint32_t q_next = 0u;
+    if (lane == 0) q_next = atomicAdd(next_row, QBATCH);
+    for (;;) {                                           // every wave reaches q0 >= n_gen: the grid drains
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_next);
+        if (q0 >= n_gen) break;
+        if (lane == 0) q_next = atomicAdd(next_row, QBATCH);
+    for (uint32_t qk = 0; qk < QBATCH && qk < n_gen - q0; ++qk) {
+        const uint32_t q = q0 + qk;
         const uint32_t r = gen_list[q];
         const uint32_t ci = row_i[r], cj = row_j[r];
         uint32_t T[9];
@@ -760,12 +790,19 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
             // look-ups are issued, and one wait covers both (a trip had three dependent rounds of global loads)
             double d6 = 0.0, d8 = 0.0, d10a = 0.0, d10b = 0.0, d10c = 0.0, d10d = 0.0, d11 = 0.0;
             int phase = s_id < n_shuffles ? 0 : 3;       // 0 begin, 1 HRUA candidates, 3 finished
+            // What bounds this loop is the number of instructions a trip issues, of any kind (one per SIMD and
+            // 4-cycle round: VALU issue 0.66 = the VALU share of the trip's instructions; look-ups that always hit
+            // L1 do not change the time, tools/abl_perm.sh 131072).  Hence: few, large conditional blocks (every
+            // `if` is three scalar instructions around its body), look-ups issued in the reverse of the order
+            // their sums need them (one s_waitcnt instead of one per term), no squeeze tests before the exp.
+            // (Deferring the statistic's six look-ups to the lane's next accepted shuffle, so that their sum never
+            // waits, was built and measured: no gain — latency is not what this loop pays for.)
             for (;;) {
-                // one Philox call per trip and lane.  A lane that starts a shuffle (call 0) draws its first result
-                // from word 0 through the row's table and takes words 1, 2 for the first candidate of the second
-                // draw; a lane that is retrying takes words 0, 1 of its next call.
-                U4 o = {0u, 0u, 0u, 0u};
-                if (phase != 3) { o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN + call, k0, k1); call++; }
+                // one Philox call per trip and lane (a finished lane's words are not used).  A lane that starts a
+                // shuffle (call 0) draws its first result from word 0 through the row's table and takes words 1, 2
+                // for the first candidate of the second draw; a lane that is retrying takes words 0, 1 of its next call.
+                const U4 o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN + call, k0, k1);
+                call++;
                 uint32_t wx_ = o.x, wy_ = o.y;
                 if (phase == 0) {
                     uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
@@ -785,40 +822,44 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                     d6 = (double)m * hb.d4 + 0.5;
                     const double d7 = d7max;                     // the row's hat width (no square root per shuffle)
                     const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
-                    d10a = LF[d9]; d10b = LF[mn - d9]; d10c = LF[m - d9]; d10d = LF[mx - m + d9];
+                    d10d = LF[LGMI_IX(mx - m + d9)]; d10c = LF[LGMI_IX(m - d9)]; d10b = LF[LGMI_IX(mn - d9)]; d10a = LF[LGMI_IX(d9)];
                     d8 = HRUA_D1 * d7 + HRUA_D2;
                     const double cap = (double)((m < mn ? m : mn) + 1u);
                     const double lim = floor(d6 + 16.0 * d7);
                     d11 = cap < lim ? cap : lim;
                     phase = 1;
                 }
-                if (phase == 1) {
-                    const double x = ((double)wx_ + 0.5) * 2.3283064365386963e-10;
-                    const double y = ((double)wy_ + 0.5) * 2.3283064365386963e-10;
-                    const double w = d6 + d8 * (y - 0.5) / x;
-                    if (!(w < 0.0 || w >= d11)) {
-                        const uint32_t zc = (uint32_t)floor(w);
-                        const double lz = LF[zc] + LF[mn - zc] + LF[m - zc] + LF[mx - m + zc];
-                        const double tt = (d10a + d10b + d10c + d10d) - lz;
-                        bool acc = (x * (4.0 - x) - 3.0 <= tt);
-                        if (!acc && !(x * (x - tt) >= 1.0)) acc = le_exp(x * x, tt);   // 2 ln x <= tt
-                        if (acc) {
-                            uint32_t z = zc;
-                            if (good > pop2 - good) z = m - z;       // z counted the minority kind
-                            if (m < sample) z = good - z;            // drew the complement
-                            long long ss;
-                            if (nr == 3) {
-                                const uint32_t x2 = C0 - x0 - z;
-                                ss = G[x0] + G[z] + G[x2] + G[R0 - x0] + G[R1 - z] + G[R2 - x2];
-                            } else {
-                                const uint32_t t02 = R0 - x0 - z;
-                                ss = G[x0] + G[C0 - x0] + G[z] + G[C1 - z] + G[t02] + G[R1 - (C0 - x0) - (C1 - z)];
-                            }
-                            exceed += (ss >= sobs);
-                            s_id = atomicAdd(&next_s, 1u);
-                            call = 0u;
-                            phase = s_id < n_shuffles ? 0 : 3;
+                const double x = ((double)wx_ + 0.5) * 2.3283064365386963e-10;
+                const double y = ((double)wy_ + 0.5) * 2.3283064365386963e-10;
+                const double w = d6 + d8 * (y - 0.5) / x;
+                if (phase == 1 && !(w < 0.0 || w >= d11)) {
+                    const uint32_t zc = (uint32_t)floor(w);
+                    const double l3 = LF[LGMI_IX(mx - m + zc)], l2 = LF[LGMI_IX(m - zc)], l1 = LF[LGMI_IX(mn - zc)], l0 = LF[LGMI_IX(zc)];
+                    const double lz = l0 + l1 + l2 + l3;
+                    const double tt = (d10a + d10b + d10c + d10d) - lz;
+                    bool acc = le_exp(x * x, tt);                   // 2 ln x <= tt
+#if LGMI_PABL & 131072
+                    exceed += acc; acc = (wy_ & 0xFFu) < 184u;
+#endif
+                    if (acc) {
+                        uint32_t z = zc;
+                        if (good > pop2 - good) z = m - z;       // z counted the minority kind
+                        if (m < sample) z = good - z;            // drew the complement
+                        uint32_t i1, i2, i3, i4, i5;             // the table's other five cells
+                        if (nr == 3) {
+                            const uint32_t x2 = C0 - x0 - z;
+                            i1 = z; i2 = x2; i3 = R0 - x0; i4 = R1 - z; i5 = R2 - x2;
+                        } else {
+                            const uint32_t t02 = R0 - x0 - z;
+                            i1 = C0 - x0; i2 = z; i3 = C1 - z; i4 = t02; i5 = R1 - (C0 - x0) - (C1 - z);
                         }
+                        const long long g0 = G[LGMI_IX(x0)], g1 = G[LGMI_IX(i1)], g2 = G[LGMI_IX(i2)], g3 = G[LGMI_IX(i3)],
+                                        g4 = G[LGMI_IX(i4)], g5 = G[LGMI_IX(i5)];
+                        const long long ss = g5 + g4 + g3 + g2 + g1 + g0;   // integers: any order
+                        exceed += (ss >= sobs);
+                        s_id = atomicAdd(&next_s, 1u);
+                        call = 0u;
+                        phase = s_id < n_shuffles ? 0 : 3;
                     }
                 }
                 if (!__any(phase != 3)) break;
@@ -895,11 +936,10 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                 if (!(w < 0.0 || w >= g.d11)) {
                     const uint32_t zc = (uint32_t)floor(w);
                     const double tt = g.d10 - (LF[zc] + LF[g.mn - zc] + LF[g.m - zc] + LF[g.mx - g.m + zc]);
-                    bool acc = (x * (4.0 - x) - 3.0 <= tt);
 #if LGMI_PABL & 2
-                    if (!acc && !(x * (x - tt) >= 1.0)) acc = (x * x <= 1.0 + tt);
+                    const bool acc = (x * x <= 1.0 + tt);
 #else
-                    if (!acc && !(x * (x - tt) >= 1.0)) acc = le_exp(x * x, tt);   // 2 ln x <= tt
+                    const bool acc = le_exp(x * x, tt);   // 2 ln x <= tt
 #endif
                     if (acc) {
                         z = zc;
@@ -1010,7 +1050,8 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
             out_exceed[r] = exceed;
             out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
         }
-    }
+    }   // rows of the batch
+    }   // batch loop
 }
 
 // self-test hook (lgmi_selftest_le_exp): the decision of le_exp, the decision of det_exp alone, and both exponentials

@@ -310,9 +310,9 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
             if (w < 0.0 || w >= d11) continue;
             zc = (uint32_t)floor(w);
             tt = d10 - (t->LF[zc] + t->LF[mn - zc] + t->LF[m - zc] + t->LF[mx - m + zc]);
-            if (x * (4.0 - x) - 3.0 <= tt) { z = zc; break; }
-            if (x * (x - tt) >= 1.0) continue;
-            if (x * x <= lgo_det_exp(tt)) { z = zc; break; }   /* 2 ln x <= tt, without a log */
+            /* 2 ln x <= tt, without a log.  (Stadlober's two squeeze tests are left out: they only save the exp on a
+               scalar machine; on a 64-lane wave some lane always needs it, and each test is a branch.) */
+            if (x * x <= lgo_det_exp(tt)) { z = zc; break; }
         }
         if (good > bad) z = m - z;   /* z counted the minority kind */
     }
