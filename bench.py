@@ -104,8 +104,8 @@ def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='north_star_dense_50kx200k', choices=sorted(WORKLOADS))
     ap.add_argument('--shuffles', type=int, default=None,
                     help='default 1000 (BASELINE.json configs[1]: 1000-shuffle permutation p); cfg5: 10000')

@@ -61,6 +61,8 @@ struct Pool {
             return LGMI_OK;
         }
         void* p = nullptr;
+        static const bool log = getenv("LGMI_POOL_LOG") != nullptr;   // debugging aid: every pool miss, on stderr
+        if (log) fprintf(stderr, "[lgmi pool] hipMalloc %zu bytes (%zu free blocks cached)\n", n, free_.size());
         hipError_t e = hipMalloc(&p, n);
         if (e != hipSuccess) {  // give cached blocks back and retry once
             trim();

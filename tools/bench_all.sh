@@ -1,0 +1,11 @@
+# every workload's bench line, as committed under profiles/rNN_bench_*.json.  On an MI355X box:  bash tools/bench_all.sh r02
+set -u
+R=${1:-r02}; OUT=gpurun_out/bench_$R; mkdir -p $OUT
+run() { # name, args...
+  local n=$1; shift
+  timeout -k 10 500 python bench.py "$@" > $OUT/${R}_bench_$n.json 2> $OUT/$n.err || { echo "$n: bench failed ($OUT/$n.err)"; return 1; }
+  python -c "import json; d=json.load(open('$OUT/${R}_bench_$n.json')); print('$n', round(d['ms_per_step'],2), 'ms/step', '%.3g' % d['value'], d['unit'], 'roofline', round(d['roofline']['frac'],3))"
+}
+run ns && run ns_s0 --shuffles 0 --no-cpu-baseline && run cfg2_dense_10kx50k --workload cfg2_dense_10kx50k && \
+run cfg3_22x9091x45455 --workload cfg3_22x9091x45455 && run cfg5_dense_depthx4_S10000 --workload cfg5_dense_depthx4_S10000 && \
+run north_star_banded_50kx200k --workload north_star_banded_50kx200k
