@@ -207,7 +207,11 @@ def main():
             step()
         sync()
         t0 = time.perf_counter()
-        infos_ = [step() for _ in range(args.steps)]
+        infos_ = []
+        for _ in range(args.steps):
+            t_ = time.perf_counter()
+            infos_.append(step())                      # run_device returns with its stream drained
+            infos_[-1]['wall_ms'] = 1e3 * (time.perf_counter() - t_)
         sync()
         elapsed_ = group.allreduce_max(time.perf_counter() - t0)
         per_rank_ = group.gather({k: sum(i[k] for i in infos_) / len(infos_) for k in
@@ -277,6 +281,7 @@ def main():
                                            + (' of rank 0 (gather included)' if gather_state['on'] else ''),
                            'gather': ('liblgmi RCCL (lgmi_comm_gather)' if gather_state['on'] else
                                       (gather_state['note'] or ('skipped (--no-gather)' if world > 1 else 'n/a')))},
+                'step_wall_ms': [round(i.get('wall_ms', 0.0), 3) for i in infos],      # this rank's; `value` uses the max over ranks of the whole region
                 'stage_ms': {k: sum(i.get(k, 0.0) for i in infos) / len(infos)
                              for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
                                        'ms_perm_general', 'ms_mean', 'ms_gather')},

@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <chrono>
@@ -44,6 +45,33 @@ static int fail(int code, const char* fmt, ...) {
             return fail(e_ == hipErrorOutOfMemory ? LGMI_E_OOM : LGMI_E_HIP, "%s: %s (%s:%d)", #expr, \
                         hipGetErrorString(e_), __FILE__, __LINE__);                         \
     } while (0)
+
+
+// Waiting for a stream: hipStreamQuery polled every ~30 us instead of hipStreamSynchronize.  On some processes of the
+// same box the runtime's blocking wait woke up ~25 ms after a 450-ms stream had drained (every step of the run, none
+// of the next run's: bench.py's step_wall_ms against the event time); a bounded poll does not depend on how the
+// runtime chose to wait, and costs a few thousand cheap queries per second of waiting.
+static hipError_t wait_stream(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        std::this_thread::sleep_for(std::chrono::microseconds(30));
+    }
+}
+
+// LGMI_TRACE_HOST=1: host-side milestones of a run on stderr (ms since the call was entered) — where wall time that no
+// stream event sees goes
+struct HostTrace {
+    bool on; std::chrono::steady_clock::time_point t0; std::string line;
+    HostTrace() : on(getenv("LGMI_TRACE_HOST") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        char b[64];
+        snprintf(b, sizeof b, " %s=%.2f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        line += b;
+    }
+    ~HostTrace() { if (on) { mark("exit"); fprintf(stderr, "[lgmi host]%s\n", line.c_str()); } }
+};
 
 // ---------------------------------------------------------------- device memory pool
 // Grow-only cache of device allocations so that repeated runs (bench steps) do not
@@ -121,6 +149,8 @@ struct lgmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
+    unsigned long long* h_scal = nullptr;   // 8 pinned words: the scalars a run reads back (a pageable destination makes
+                                            // every small copy a staged, blocking one)
     Pool pool;
     long long* d_G = nullptr;   // round(n ln n * 2^28): permutation statistic (perm.hip)
     double* d_LF = nullptr;     // ln n!
@@ -212,6 +242,7 @@ extern "C" int lgmi_ctx_create(int device_id, lgmi_ctx** out) {
     c->device = device_id;
     HIPCHK(hipStreamCreate(&c->stream));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipHostMalloc((void**)&c->h_scal, 64, hipHostMallocDefault));
     size_t free_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &c->mem_total));
     *out = c;
@@ -229,6 +260,7 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     if (ctx->d_LF) (void)hipFree(ctx->d_LF);
     ctx->pool.destroy();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -277,7 +309,7 @@ void pool_release(lgmi_ctx* c, void* p) { c->pool.release(p); }
 extern "C" int lgmi_ctx_synchronize(lgmi_ctx* ctx) {
     if (!ctx) return fail(LGMI_E_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(wait_stream(ctx->stream));
     return LGMI_OK;
 }
 
@@ -373,7 +405,7 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
         HIPCHK(hipMemsetAsync(db->d.d_tri, 0, ns, st));
         launch_tri_flags(st, (uint32_t)ns, d_nw, d_poff, d_planes, db->d.d_tri);
         HIPCHK(hipMemcpyAsync(db->tri.data(), db->d.d_tri, ns, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(wait_stream(st));
     }
     // column table: real sites, then one pseudo column per tri site
     db->pseudo_of_site.assign(ns, NONE);
@@ -401,7 +433,7 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     HIPCHK(hipMemsetAsync(db->d.d_cplanes + off, 0, sizeof(ulonglong2), st));
     launch_prep_cols(st, (uint32_t)db->d.n_cols, (uint32_t)ns, db->d.d_cols, d_pseudo, d_poff, d_planes, db->d.d_cplanes);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(wait_stream(st));
     guard.p = nullptr;
     *out = db;
     return LGMI_OK;
@@ -473,7 +505,7 @@ extern "C" int lgmi_synth_dense(lgmi_ctx* ctx, const lgmi_synth_spec* sp, lgmi_d
         launch_synth_write(st, bs, W, d_depth + (size_t)3 * c * P, d_pos_ + (size_t)c * P, db->d.d_cplanes, c * P);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(wait_stream(st));
     guard.p = nullptr;
     *out = db;
     return LGMI_OK;
@@ -651,6 +683,7 @@ extern "C" void lgmi_dresult_free(lgmi_dresult* r) {
 static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out, bool defer_perm) {
     if (!ctx || !db || !prm || !out) return fail(LGMI_E_ARG, "NULL argument");
     *out = nullptr;
+    HostTrace tr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
     if (prm->reserved0) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
     if (prm->exact_2x2 > 1) return fail(LGMI_E_ARG, "exact_2x2 must be 0 or 1");
@@ -671,6 +704,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         return fail(LGMI_E_ARG, "the permutation test takes blocks of fewer than 2^28 reads (%u)", db->max_reads);
     if (want_p && (rc = ensure_perm_tables(ctx, std::max(db->max_reads, prm->n_shuffles)))) return rc;   // first use only
     HIPCHK(hipEventRecord(ctx->ev[0], st));
+    tr.mark("ev0");
     const auto t_plan0 = std::chrono::steady_clock::now();
     Plan pl;
     {
@@ -679,6 +713,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         build_plan(plan_input(db), prm->het_only != 0, sh_rank, sh_world, ck, xg, prm->n_shuffles, pl);
     }
     const float ms_plan_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
+    tr.mark("planned");
     const size_t n_items = (size_t)(pl.item_end - pl.item_begin);
     if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull || n_items >= 0x7FFFFFFFull)
         return fail(LGMI_E_ARG, "too many tiles");
@@ -731,18 +766,40 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if ((rc = pool.alloc((void**)&res->d_npairs, (size_t)ns * 4))) return rc;
     unsigned long long* d_sum = res->d_sum;
 
-    auto h2d = [&](void* d, const void* h, size_t n) -> hipError_t {
-        return n ? hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st) : hipSuccess;
+    // The plan goes up through one pinned staging buffer (cached by the context).  Straight from the pageable
+    // std::vectors the nine copies blocked the host for 25 - 35 ms in about half of the processes on the same box
+    // (LGMI_TRACE_HOST: "enqueued" 33 ms against 0.3 ms; the GPU idle meanwhile): what the runtime does with a
+    // pageable source (stage or pin on the fly) is its own choice.
+    struct Up { void* d; const void* h; size_t n; };
+    const Up ups[] = {
+        {d_plans, pl.plans.data(), pl.plans.size() * sizeof(BlockPlan)},
+        {d_xlist, pl.xlist.data(), pl.xlist.size() * 4},
+        {d_items, pl.items.data() + pl.item_begin, n_items * sizeof(uint2)},
+        {d_units, pl.units.data(), pl.units.size() * sizeof(uint2)},
+        {d_ylist, pl.ylist.data(), pl.ylist.size() * 4},
+        {d_smap, pl.smap.data(), pl.smap.size() * sizeof(SiteMap)},
+        {d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)},
+        {d_mtiles, pl.mtiles.data(), pl.mtiles.size() * sizeof(Tile)},
+        {d_opgroups, pl.op_groups.data(), pl.op_groups.size() * sizeof(OpGroup)},
     };
-    HIPCHK(h2d(d_plans, pl.plans.data(), pl.plans.size() * sizeof(BlockPlan)));
-    HIPCHK(h2d(d_xlist, pl.xlist.data(), pl.xlist.size() * 4));
-    HIPCHK(h2d(d_items, pl.items.data() + pl.item_begin, n_items * sizeof(uint2)));
-    HIPCHK(h2d(d_units, pl.units.data(), pl.units.size() * sizeof(uint2)));
-    HIPCHK(h2d(d_ylist, pl.ylist.data(), pl.ylist.size() * 4));
-    HIPCHK(h2d(d_smap, pl.smap.data(), pl.smap.size() * sizeof(SiteMap)));
-    HIPCHK(h2d(d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)));
-    HIPCHK(h2d(d_mtiles, pl.mtiles.data(), pl.mtiles.size() * sizeof(Tile)));
-    HIPCHK(h2d(d_opgroups, pl.op_groups.data(), pl.op_groups.size() * sizeof(OpGroup)));
+    size_t up_total = 0;
+    for (const Up& u : ups) up_total += (u.n + 255) & ~size_t(255);
+    struct Staging {                       // back to the pool once the stream no longer reads it
+        std::shared_ptr<PinnedPool> pool; hipStream_t st; void* p = nullptr; size_t got = 0;
+        ~Staging() { if (p) { (void)hipStreamSynchronize(st); pool->give(p, got); } }
+    } stage{ctx->pinned, st};
+    if (up_total) {
+        stage.p = ctx->pinned->take(up_total, &stage.got);
+        if (!stage.p) return fail(LGMI_E_OOM, "pinned staging buffer of %zu bytes for the plan", up_total);
+        size_t off = 0;
+        for (const Up& u : ups) {
+            if (!u.n) continue;
+            memcpy((char*)stage.p + off, u.h, u.n);
+            HIPCHK(hipMemcpyAsync(u.d, (char*)stage.p + off, u.n, hipMemcpyHostToDevice, st));
+            off += (u.n + 255) & ~size_t(255);
+        }
+    }
+    tr.mark("uploaded");
     if (ns) HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 16, st));
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
@@ -783,7 +840,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     uint64_t n_rows = 0;
     if (!by_bound) {
         HIPCHK(hipMemcpyAsync(&n_rows, d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(wait_stream(st));
         cap_rows = n_rows;
     }
     const size_t nr = (size_t)std::max<uint64_t>(cap_rows, 1);
@@ -826,12 +883,18 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if (ns) HIPCHK(hipMemcpyAsync(res->d_npairs, d_cnt, (size_t)ns * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[5], st));
-    int err = 0; unsigned long long wp = 0; unsigned int n_general = 0;
-    HIPCHK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&n_general, d_gencount, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&wp, d_wordpairs, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&n_rows, d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    unsigned long long* hs = ctx->h_scal;
+    hs[0] = hs[1] = hs[2] = hs[3] = 0;
+    HIPCHK(hipMemcpyAsync(&hs[0], d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&hs[1], d_gencount, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&hs[2], d_wordpairs, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&hs[3], d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
+    tr.mark("enqueued");
+    HIPCHK(wait_stream(st));
+    tr.mark("drained");
+    const int err = (int)(uint32_t)hs[0]; const unsigned int n_general = (unsigned int)hs[1];
+    const unsigned long long wp = hs[2];
+    n_rows = hs[3];
     if (err) return fail(LGMI_E_DOMAIN, "math domain error: a pair with 0 common reads reached the MI (min_common == 0)");
     if (n_rows > cap_rows) return fail(LGMI_E_STATE, "internal: %llu rows exceed the planned bound %llu",
                                        (unsigned long long)n_rows, (unsigned long long)cap_rows);
@@ -901,10 +964,12 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
         HIPCHK(hipEventRecord(ctx->ev[6], st));
         launch_perm_general(st, pa);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&n_general, d_gencount, 4, hipMemcpyDeviceToHost, st));
+        ctx->h_scal[1] = 0;
+        HIPCHK(hipMemcpyAsync(&ctx->h_scal[1], d_gencount, 4, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(wait_stream(st));
+    if (res->cap_rows) n_general = (unsigned int)ctx->h_scal[1];
     lgmi_run_info& inf = res->info;
     inf.n_general_rows = n_general;
     HIPCHK(hipEventElapsedTime(&inf.ms_perm, ctx->ev[3], ctx->ev[4]));
@@ -983,7 +1048,7 @@ extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out) {
     int rc = fetch_part(r, h, out, st, 1);
     if (!rc) rc = fetch_part(r, h, out, st, 2);
     if (rc) { memset(out, 0, sizeof *out); return rc; }
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(wait_stream(st));
     out->owner_ = static_cast<ResultOwner*>(h);
     guard.p = nullptr;
     return LGMI_OK;
@@ -1056,7 +1121,7 @@ extern "C" int lgmi_site_mean(lgmi_ctx* ctx, uint64_t n_rows, const uint32_t* ro
         HIPCHK(hipMemcpyAsync(mean_out, dmean, n_sites * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(n_out, dc, n_sites * 4, hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(wait_stream(st));
     return LGMI_OK;
 }
 
@@ -1084,7 +1149,7 @@ extern "C" int lgmi_selftest_le_exp(lgmi_ctx* ctx, uint64_t n, const double* x2,
         HIPCHK(hipMemcpyAsync(e_hw, dh, n * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(e_det, dd, n * 8, hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(wait_stream(st));
     return LGMI_OK;
 }
 
@@ -1113,6 +1178,6 @@ extern "C" int lgmi_ecdf(lgmi_ctx* ctx, uint64_t n_ref, const double* ref, uint6
     if (n_query) HIPCHK(hipMemcpyAsync(d_q, query, n_query * 8, hipMemcpyHostToDevice, st));
     HIPCHK(launch_ecdf(st, (uint32_t)n_ref, d_ref, d_sorted, d_temp, tb, n_query, d_q, d_out));
     if (n_query) HIPCHK(hipMemcpyAsync(out, d_out, n_query * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(wait_stream(st));
     return LGMI_OK;
 }

@@ -606,13 +606,16 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
     // one runs: rows differ in cost (table size, streamlined or general loop) and a fixed stride left the average
     // wave idle for the last ~15 % of the kernel (SQ_WAVE_CYCLES against SQ_BUSY_CYCLES)
     unsigned int* const next_row = pa.gen_count + 1;
+    // QBATCH rows per atomic (same-address atomics are served at ~60 M/s chip-wide); one at a time when there are so
+    // few rows that the batch itself would unbalance the waves
+    const uint32_t batch = n_gen >= 64u * gridDim.x ? QBATCH : 1u;
     uint32_t q_next = 0u;
-    if (lane == 0) q_next = atomicAdd(next_row, QBATCH);
+    if (lane == 0) q_next = atomicAdd(next_row, batch);
     for (;;) {                                           // every wave reaches q0 >= n_gen: the grid drains
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_next);
         if (q0 >= n_gen) break;
-        if (lane == 0) q_next = atomicAdd(next_row, QBATCH);
-    for (uint32_t qk = 0; qk < QBATCH && qk < n_gen - q0; ++qk) {
+        if (lane == 0) q_next = atomicAdd(next_row, batch);
+    for (uint32_t qk = 0; qk < batch && qk < n_gen - q0; ++qk) {
         const uint32_t q = q0 + qk;
         const uint32_t r = gen_list[q];
         const uint32_t ci = row_i[r], cj = row_j[r];
