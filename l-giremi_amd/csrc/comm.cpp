@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -48,8 +49,11 @@ struct Rccl {
 
 int load_rccl() {
     if (g.h) return LGMI_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // LGMI_RCCL_LIB: another library with the same ten entry points — the tests' file-based stand-in that lets two
+    // ranks share the one GPU of a test box (tests/helpers/fake_rccl.cpp); unset in any real run
+    const char* alt = getenv("LGMI_RCCL_LIB");
+    void* h = (alt && *alt) ? dlopen(alt, RTLD_NOW | RTLD_GLOBAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h && !(alt && *alt)) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return set_error(LGMI_E_RCCL, dlerror());
 #define SYM(field, name)                                                        \
     *(void**)(&g.field) = dlsym(h, name);                                       \
