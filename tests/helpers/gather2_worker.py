@@ -111,6 +111,27 @@ def main():
     dr.free()
     tiny.free()
 
+    # ---- (4) ranks that disagree (tables on one rank only) all get the error, before anything is posted: nobody hangs,
+    #          and the communicator still works afterwards
+    d = eng.upload(random_batch(8, n_blocks=2))
+    dr = eng.run_device(d, min_common=2, het_only=True, n_shuffles=5, seed=1, emit_counts=(rank == 0))
+    try:
+        eng.comm_gather(dr, root=0, site_base=0, same_batch=True)
+        raise AssertionError('mismatched flags were accepted')
+    except lgmi._lib.LgmiError as e:
+        assert 'ranks disagree' in str(e), str(e)
+    dr.free()
+    dr = eng.run_device(d, min_common=2, het_only=True, n_shuffles=5, seed=1, emit_counts=True, shard=(rank, world))
+    g, begins = eng.comm_gather(dr, root=0, site_base=0, same_batch=True)
+    if rank == 0:
+        x = eng.run_device(d, min_common=2, het_only=True, n_shuffles=5, seed=1, emit_counts=True)
+        same(g.fetch(), x.fetch(), True, 'after a refused gather')
+        x.free()
+        g.free()
+        checked.append('mismatch refused on every rank')
+    dr.free()
+    d.free()
+
     group.barrier()
     eng.close()
     if rank == 0:

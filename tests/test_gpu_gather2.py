@@ -52,4 +52,4 @@ def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world):
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (rank, se[-3000:])
     line = json.loads(outs[0][0].strip().splitlines()[-1])
-    assert line['ok'] and line['world'] == world and len(line['checked']) == 4
+    assert line['ok'] and line['world'] == world and len(line['checked']) == 5
