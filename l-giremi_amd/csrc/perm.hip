@@ -17,7 +17,8 @@
 //                   in the set is drawn as one Binomial(n_shuffles, P_tail) variate — pure
 //                   ALU + Philox, no table is materialised.  Larger tables are queued for
 //                   k_perm_general.
-//   k_perm_general  one wave per queued row, shuffles spread over the 64 lanes; each
+//   k_perm_general  a fixed grid of waves that take the queued rows from a shared counter, one
+//                   wave per row, shuffles spread over the 64 lanes; each
 //                   shuffle draws the table with conditional hypergeometric draws (urn
 //                   scheme for small samples, Stadlober's HRUA otherwise).
 //
@@ -1088,7 +1089,7 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
 {
     if (!a.max_rows || !a.n_shuffles) return;
     // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
-    // stride over the queued rows
+    // take the queued rows from a shared counter
     hipLaunchKernelGGL(k_perm_general, dim3(256 * 16), dim3(64), 0, st, a);
 }
 
