@@ -149,8 +149,8 @@ struct lgmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    unsigned long long* h_scal = nullptr;   // 8 pinned words: the scalars a run reads back (a pageable destination makes
-                                            // every small copy a staged, blocking one)
+    unsigned long long* h_scal = nullptr;   // 4 KB of pinned words: [0, 8) the scalars a run reads back (a pageable destination
+                                            // makes every small copy a staged, blocking one), [8, 512) comm.cpp's small exchanges
     Pool pool;
     long long* d_G = nullptr;   // round(n ln n * 2^28): permutation statistic (perm.hip)
     double* d_LF = nullptr;     // ln n!
@@ -242,7 +242,7 @@ extern "C" int lgmi_ctx_create(int device_id, lgmi_ctx** out) {
     c->device = device_id;
     HIPCHK(hipStreamCreate(&c->stream));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
-    HIPCHK(hipHostMalloc((void**)&c->h_scal, 64, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_scal, 4096, hipHostMallocDefault));
     size_t free_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &c->mem_total));
     *out = c;
@@ -275,6 +275,7 @@ hipStream_t ctx_comm_stream(lgmi_ctx* c) {               // created on first use
 }
 int ctx_device(lgmi_ctx* c) { return c->device; }
 void** ctx_comm_slot(lgmi_ctx* c) { return &c->comm; }
+uint64_t* ctx_pinned_words(lgmi_ctx* c, size_t* n_words) { *n_words = 504; return (uint64_t*)(c->h_scal + 8); }
 int* ctx_rank_slot(lgmi_ctx* c) { return &c->rank; }
 int* ctx_world_slot(lgmi_ctx* c) { return &c->world; }
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }

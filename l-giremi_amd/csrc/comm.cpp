@@ -22,6 +22,7 @@ hipStream_t ctx_stream(lgmi_ctx* c);
 hipStream_t ctx_comm_stream(lgmi_ctx* c);
 int ctx_device(lgmi_ctx* c);
 void** ctx_comm_slot(lgmi_ctx* c);
+uint64_t* ctx_pinned_words(lgmi_ctx* c, size_t* n_words);
 int* ctx_rank_slot(lgmi_ctx* c);
 int* ctx_world_slot(lgmi_ctx* c);
 int set_error(int code, const char* msg);
@@ -128,11 +129,20 @@ extern "C" int lgmi_comm_allgather_u64v(lgmi_ctx* ctx, const uint64_t* mine, uin
     uint64_t* d = nullptr;
     int rc = pool_alloc(ctx, (void**)&d, sizeof(uint64_t) * n * (size_t)(world + 1));
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(d + (size_t)world * n, mine, 8ull * n, hipMemcpyHostToDevice, st);
+    // through the context's pinned words when they fit (they do for everything the gather exchanges): copies to and
+    // from pageable memory are staged by the runtime and were seen to block the host for tens of milliseconds
+    size_t pw = 0;
+    uint64_t* pin = ctx_pinned_words(ctx, &pw);
+    const bool pinned = (size_t)n * (size_t)(world + 1) <= pw;
+    const uint64_t* src = mine;
+    uint64_t* dst = out_world;
+    if (pinned) { memcpy(pin, mine, 8ull * n); src = pin; dst = pin + n; }
+    hipError_t e = hipMemcpyAsync(d + (size_t)world * n, src, 8ull * n, hipMemcpyHostToDevice, st);
     ncclResult_t r = ncclSuccess;
     if (e == hipSuccess) r = g.AllGather(d + (size_t)world * n, d, n, ncclUint64, comm, st);
-    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(out_world, d, 8ull * n * world, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(dst, d, 8ull * n * world, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && r == ncclSuccess && pinned) memcpy(out_world, dst, 8ull * n * world);
     pool_release(ctx, d);
     if (r != ncclSuccess) return nccl_fail(r, "ncclAllGather");
     if (e != hipSuccess) return set_error(LGMI_E_HIP, hipGetErrorString(e));
