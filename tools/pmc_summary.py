@@ -16,6 +16,15 @@ import os
 import sys
 
 
+def previous(path):
+    """the summary already at `path` (several workloads share one file), {} when there is none"""
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def find(d, suffix):
     hits = sorted(glob.glob(os.path.join(d, '**', '*' + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
@@ -62,6 +71,7 @@ def main():
             wkb = wv.get(k, {}).get('WRITE_SIZE', 0.0) / n
             entry[short(k)] = {'launches': n, 'fetch_size_kb': fkb, 'write_size_kb': wkb, 'fetch_correction': 2.0,
                                'hbm_bytes': (2.0 * fkb + wkb) * 1024.0, 'ms': ft[k][1] / n / 1e6}
+        res = dict(previous(out), **res)        # other workloads' entries are kept
         res[workload] = entry
         for k, v in entry.items():              # what bench.py looks up: <workload>_mfma -> hbm_bytes of the count kernel
             if k.startswith('k_count_mfma'):
@@ -93,6 +103,7 @@ def main():
             if name == 'k_perm_fast':
                 e['units'] = float(rows)
             entry[name] = e
+        res = dict(previous(out), **res)        # other workloads' entries are kept
         res[workload] = entry
         json.dump(res, open(out, 'w'), indent=1)
     elif mode == 'stats':
