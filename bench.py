@@ -312,6 +312,18 @@ def main():
                                  'valu_insts_per_table_draw' if k == 'k_perm_general' else 'valu_insts_per_row':
                                      c['valu_insts'] * 64.0 / (c.get('units') or 1)}
                 out['perm_roofline'] = pr
+            # the ordered emission (validity count + scan + MI and row write): priced like the permutation kernels, on VALU
+            # issue from the committed SQ counter pass — nine f64 logarithms per row are most of its instructions
+            sq_e = committed_profile('pmc_sq_perm').get(args.workload, {}).get('k_emit<2>')
+            ms_emit = sum(i['ms_emit'] for i in infos) / len(infos)
+            if world == 1 and sq_e and sq_e.get('valu_insts') and sq_e.get('ms') and info['n_rows']:
+                out['emit_roofline'] = {'kernel': 'k_emit<2>', 'bound': 'valu_issue', 'ms_emit_stage': ms_emit,
+                                        'rows_per_s': info['n_rows'] / (ms_emit * 1e-3) if ms_emit > 0 else None,
+                                        'valu_issue_frac': sq_e['valu_insts'] / (sq_e['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
+                                        'active_lane_frac': sq_e.get('active_lanes', 0) / 64.0,
+                                        'valu_insts_per_row': sq_e['valu_insts'] * 64.0 / info['n_rows'],
+                                        'peak': VALU_WAVE_INSTR_PEAK, 'unit': 'wave64 VALU instructions/s',
+                                        'counters': committed_profile('pmc_sq_perm').get('_file')}
             traffic = committed_profile('pmc_k_count').get(args.workload + ('_mfma' if mfma else ''), {}).get('hbm_bytes')
             hbm = {'kernel': 'count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes, 'achieved': alg_bytes / secs / 1e9,
                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
