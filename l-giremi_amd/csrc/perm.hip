@@ -709,17 +709,21 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                     if (lane >= (uint32_t)o) incl += v;
                 }
                 const unsigned long long before = (incl - loc) >> 20;
+                for (uint32_t b = lane; b < 257u; b += 64u) tab_guide[b] = (uint16_t)(tab_n - 1u);
+                // the final threshold just before this lane's segment (the last one of the lane below; segments are
+                // dealt in lane order, so a lane with entries has a full lane below it)
+                const unsigned long long my_last = (loc >> 20) + before;
+                const uint32_t last_final = my_last >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)my_last;
+                const uint32_t below = __shfl_up(last_final, 1);
+                __syncthreads();                       // guide defaults written before any bucket is
+                // one pass: add what the lanes below sum to, clamp, and let entry e — the answer for every u in
+                // [thr[e-1], thr[e]) — start the buckets whose first value b << 24 falls in that range (thresholds do
+                // not decrease, so each bucket is written once)
+                uint32_t prev = lane > 0u && e0 < tab_n ? below : 0u;
                 for (uint32_t e = e0; e < e1; ++e) {
                     const unsigned long long t = (unsigned long long)tab_thr[e] + before;
-                    tab_thr[e] = t >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
-                }
-                for (uint32_t b = lane; b < 257u; b += 64u) tab_guide[b] = (uint16_t)(tab_n - 1u);
-                __syncthreads();
-                // entry e is the answer for every u in [thr[e-1], thr[e]): it starts the buckets whose first
-                // value b << 24 falls in that range (thresholds do not decrease, so each bucket is written once)
-                uint32_t prev = e0 > 0u && e0 < tab_n ? tab_thr[e0 - 1u] : 0u;
-                for (uint32_t e = e0; e < e1; ++e) {
-                    const uint32_t cur = tab_thr[e];
+                    const uint32_t cur = t >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+                    tab_thr[e] = cur;
                     if (cur > prev) {
                         const uint32_t b_hi = (cur - 1u) >> 24;
                         for (uint32_t b = (uint32_t)(((unsigned long long)prev + 0xFFFFFFull) >> 24); b <= b_hi; ++b)
