@@ -47,15 +47,19 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 
-// Waiting for a stream: hipStreamQuery polled every ~30 us instead of hipStreamSynchronize.  On some processes of the
+// Waiting for a stream: hipStreamQuery polled (back to back for the first 300 us, then every ~30 us) instead of
+// hipStreamSynchronize.  On some processes of the
 // same box the runtime's blocking wait woke up ~25 ms after a 450-ms stream had drained (every step of the run, none
 // of the next run's: bench.py's step_wall_ms against the event time); a bounded poll does not depend on how the
 // runtime chose to wait, and costs a few thousand cheap queries per second of waiting.
 static hipError_t wait_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
-        std::this_thread::sleep_for(std::chrono::microseconds(30));
+        // short waits (a banded batch is done in a millisecond or two) are spun through; longer ones sleep between polls
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300))
+            std::this_thread::sleep_for(std::chrono::microseconds(30));
     }
 }
 
