@@ -40,6 +40,8 @@ WORKLOADS = {
     'cfg3_22x9091x45455': dict(n_sites=9_091, n_reads=45_455, n_blocks=22),
     # BASELINE.json configs[4]: coverage depth x 4, mi_min_common_read = 6, 10,000 shuffles
     'cfg5_dense_depthx4_S10000': dict(n_sites=9_091, n_reads=181_820, n_blocks=22, shuffles=10_000),
+    # twice the north-star's sites in ONE block: 1.8e9 rows, ~160 GB of HBM in use — the headroom case (not a BASELINE config)
+    'headroom_dense_100kx200k': dict(n_sites=100_000, n_reads=200_000),
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # non-packed VALU: one wave64 instruction per 4 cycles per SIMD (MI355X_MICROARCH.md 'vector-instruction ISSUE
