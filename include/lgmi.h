@@ -282,6 +282,11 @@ void lgmi_shard_plan_free(lgmi_shard_plan* plan);
 int  lgmi_selftest_le_exp(lgmi_ctx* ctx, uint64_t n, const double* x2, const double* t, uint8_t* fast, uint8_t* det,
                           double* e_hw, double* e_det);
 
+/* device self-test of the logarithm the MI of a row is made of (emit.hip: mi_log — table-driven, for doubles that hold
+ * an integer >= 1): out[k] = mi_log(x[k]).  Host arrays of length n.  The reference's counterpart is numpy's log inside
+ * scikit-learn's mutual_info_score (sklearn/metrics/cluster/_supervised.py:911-921). */
+int  lgmi_selftest_log(lgmi_ctx* ctx, uint64_t n, const double* x, double* out);
+
 /* wait for everything queued on the context's stream (the bench's device sync) */
 int  lgmi_ctx_synchronize(lgmi_ctx* ctx);
 

@@ -1158,6 +1158,26 @@ extern "C" int lgmi_selftest_le_exp(lgmi_ctx* ctx, uint64_t n, const double* x2,
     return LGMI_OK;
 }
 
+// ---------------------------------------------------------------- device self-test of mi_log (emit.hip)
+extern "C" int lgmi_selftest_log(lgmi_ctx* ctx, uint64_t n, const double* x, double* out) {
+    if (!ctx || (n && (!x || !out))) return fail(LGMI_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    Pool& pool = ctx->pool;
+    double *dx = nullptr, *dy = nullptr;
+    struct Guard { Pool& p; double** a; double** b; ~Guard() { p.release(*a); p.release(*b); } } guard{pool, &dx, &dy};
+    int rc;
+    if ((rc = pool.alloc((void**)&dx, std::max<uint64_t>(n, 1) * 8)) || (rc = pool.alloc((void**)&dy, std::max<uint64_t>(n, 1) * 8))) return rc;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, st));
+        launch_selftest_log(st, n, dx, dy);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, dy, n * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(wait_stream(st));
+    return LGMI_OK;
+}
+
 // ---------------------------------------------------------------- ECDF (the reference's `mip`)
 extern "C" int lgmi_ecdf(lgmi_ctx* ctx, uint64_t n_ref, const double* ref, uint64_t n_query, const double* query,
                          double* out) {

@@ -159,6 +159,7 @@ struct PermArgs {
 };
 void launch_perm_fast(hipStream_t st, const PermArgs& a);
 void launch_perm_general(hipStream_t st, const PermArgs& a);
+void launch_selftest_log(hipStream_t st, uint64_t n, const double* x, double* out);
 void launch_selftest_le_exp(hipStream_t st, uint64_t n, const double* x2, const double* t, uint8_t* fast, uint8_t* det,
                             double* e_hw, double* e_det);
 

@@ -108,6 +108,7 @@ SYMBOLS = {
     'lgmi_plan_shard': (C.c_int, [C.POINTER(Batch), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ShardPlan)]),
     'lgmi_shard_plan_free': (None, [C.POINTER(ShardPlan)]),
     'lgmi_ctx_synchronize': (C.c_int, [VP]),
+    'lgmi_selftest_log': (C.c_int, [VP, C.c_uint64, f64p, f64p]),
     'lgmi_selftest_le_exp': (C.c_int, [VP, C.c_uint64, f64p, f64p, u8p, u8p, f64p, f64p]),
     'lgmi_comm_unique_id': (C.c_int, [VP]),
     'lgmi_comm_init': (C.c_int, [VP, VP, C.c_int, C.c_int]),

@@ -254,6 +254,14 @@ class Engine:
         _lib.check(fn(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
         return DeviceResult(self, h)
 
+    def selftest_log(self, x):
+        """mi_log (the table-driven logarithm of emit.hip) of every x[k], computed on the device"""
+        self._alive()
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.empty(len(x), np.float64)
+        _lib.check(self.lib.lgmi_selftest_log(self.handle, len(x), x.ctypes.data_as(_lib.f64p), out.ctypes.data_as(_lib.f64p)))
+        return out
+
     def selftest_le_exp(self, x2, t):
         """-> (le_exp decisions, det_exp decisions, hardware f32 exp, det_exp) for the pairs (x2[k], t[k])"""
         self._alive()

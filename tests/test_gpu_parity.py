@@ -528,3 +528,26 @@ def test_engine_close_releases_resident_objects():
     dr.free()                        # idempotent, no use-after-free
     with pytest.raises(RuntimeError):
         eng.run(random_batch(6, n_blocks=1))
+
+
+def test_mi_log_against_correctly_rounded_values(engine):
+    """emit.hip's table-driven logarithm (mi_log: the nine logarithms of every emitted row) on the device against the
+    correctly rounded value (decimal, 50 digits) for the arguments it can get — integers >= 1 held in doubles: counts
+    below 2^24 and products of two counts.  At most one ulp off, and that rarely; ln 1 is exactly 0."""
+    from decimal import Decimal, getcontext
+    getcontext().prec = 50
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([
+        np.arange(1, 20001),                                              # every small count
+        rng.integers(1, 1 << 24, 15000),                                  # counts
+        rng.integers(1, 1 << 24, 10000) * rng.integers(1, 1 << 24, 10000),   # margin products, < 2^48
+        2 ** np.arange(0, 53), 2 ** np.arange(1, 53) - 1, 2 ** np.arange(1, 52) + 1,
+    ]).astype(np.float64)
+    got = engine.selftest_log(xs)
+    want = np.array([float(Decimal(int(v)).ln()) for v in xs])           # float(Decimal) rounds to nearest
+    assert got[0] == 0.0 and np.all(got[xs == 1.0] == 0.0)
+    ulps = np.abs(got.view(np.int64) - want.view(np.int64))
+    assert ulps.max() <= 1, (ulps.max(), xs[np.argmax(ulps)])
+    assert np.mean(ulps == 0) > 0.995, np.mean(ulps == 0)
+    # the reference's own logarithm (numpy -> libm) differs from the correctly rounded value about as rarely
+    assert np.mean(np.log(xs) == want) > 0.99
