@@ -348,6 +348,8 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     // persistent one-wave workgroups: a fixed grid strides over the 64-row chunks (the row count is only known on
     // the device, and 7 million one-wave workgroups per launch were a cost of their own)
     const uint64_t n_chunks = (n_rows + 63ull) / 64ull;
+    __shared__ uint32_t s_queue[128];                       // rows waiting to be queued for k_perm_general
+    uint32_t qn = 0u;                                       // how many (wave-uniform)
     // (a fixed stride: taking the chunks from a shared counter, as k_perm_general takes its rows, was measured
     // slower here — 79 ms against 63 with 4 chunks per atomic, 139 ms with one)
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // wave-uniform trip count: the grid drains
@@ -395,14 +397,27 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     }
 #if !(LGMI_PABL & 16)
     if (n_shuffles) {
-        // queue the larger tables for k_perm_general: one atomic per wave, not one per row (millions of atomics on one
-        // address serialise in the L2); the order inside the queue is free
+        // queue the larger tables for k_perm_general.  They are collected in LDS over the wave's chunks and go out 64
+        // at a time: one atomic on the queue counter per 64 queued rows.  (One atomic per chunk — 73 % of the chunks
+        // have such a row — was 2.6 million atomics on one address, which the L2 serves at ~60 M/s: 14 of this
+        // kernel's 63 ms, tools/abl_perm.sh 16.)  The order inside the queue is free.
         const unsigned long long qb = __ballot(kind == 3);
         if (qb) {
-            uint32_t base = 0u;
-            if (lane == 0u) base = atomicAdd(gen_count, (unsigned int)__popcll(qb));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (kind == 3) gen_list[base + (uint32_t)__popcll(qb & ((1ull << lane) - 1ull))] = (uint32_t)r;
+            if (kind == 3) s_queue[qn + (uint32_t)__popcll(qb & ((1ull << lane) - 1ull))] = (uint32_t)r;
+            qn += (uint32_t)__popcll(qb);
+            if (qn >= 64u) {
+                __syncthreads();                                // (one wave per workgroup: a wave barrier)
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(gen_count, 64u);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                gen_list[base + lane] = s_queue[lane];
+                const uint32_t rest = qn - 64u;                 // < 64: what stays for the next round
+                const uint32_t keep = lane < rest ? s_queue[64u + lane] : 0u;
+                __syncthreads();
+                if (lane < rest) s_queue[lane] = keep;
+                qn = rest;
+                __syncthreads();
+            }
         }
     }
 #endif
@@ -517,6 +532,15 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     }
     __syncthreads();                                        // s_pre / s_acc are reused by the next chunk
     }   // chunk loop
+#if !(LGMI_PABL & 16)
+    if (qn) {                                               // what is left of the wave's queue
+        __syncthreads();
+        uint32_t base = 0u;
+        if (lane == 0u) base = atomicAdd(gen_count, qn);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (lane < qn) gen_list[base + lane] = s_queue[lane];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- general tables
