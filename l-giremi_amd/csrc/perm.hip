@@ -39,12 +39,14 @@
 //   32 exact-tail sums skipped      64 bisection skipped      128 binomial draw skipped
 // 1024 statistic look-ups skipped      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
 // 131072 streamlined 3x2 loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
+// 262144 streamlined 3x2 loop: the threshold-table search stops after three probes (what the long searches of the
+//        two tail buckets cost the whole wave)
 // Every surviving bit keeps all table indices inside the range the normal path uses and keeps every rejection
 // loop's acceptance probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the
 // acceptance test unsatisfiable, so k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536,
 // one of which indexed LF[] with set-up values it had skipped (GPU memory fault).  They are gone for good.
 #endif
-#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192 | 131072)
+#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192 | 131072 | 262144)
 #if LGMI_PABL & ~LGMI_PABL_KNOWN
 #error "LGMI_PABL: unknown ablation bit (see the list above; 256, 2048, 16384, 32768, 65536 were removed: they hang or fault)"
 #endif
@@ -838,7 +840,11 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                 uint32_t wx_ = o.x, wy_ = o.y;
                 if (phase == 0) {
                     uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
+#if LGMI_PABL & 262144
+                    for (int it_ = 0; it_ < 3 && lo < hi; ++it_) {
+#else
                     while (lo < hi) {
+#endif
                         const uint32_t mid = (lo + hi) >> 1;
                         if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
                     }
