@@ -41,12 +41,13 @@
 // 131072 streamlined 3x2 loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
 // 262144 streamlined 3x2 loop: the threshold-table search stops after three probes (what the long searches of the
 //        two tail buckets cost the whole wave)
+// 524288 streamlined 3x2 loop: lanes take shuffles by a fixed stride of 64 instead of from the shared LDS counter
 // Every surviving bit keeps all table indices inside the range the normal path uses and keeps every rejection
 // loop's acceptance probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the
 // acceptance test unsatisfiable, so k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536,
 // one of which indexed LF[] with set-up values it had skipped (GPU memory fault).  They are gone for good.
 #endif
-#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192 | 131072 | 262144)
+#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192 | 131072 | 262144 | 524288)
 #if LGMI_PABL & ~LGMI_PABL_KNOWN
 #error "LGMI_PABL: unknown ablation bit (see the list above; 256, 2048, 16384, 32768, 65536 were removed: they hang or fault)"
 #endif
@@ -895,7 +896,11 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                                         g4 = G[LGMI_IX(i4)], g5 = G[LGMI_IX(i5)];
                         const long long ss = g5 + g4 + g3 + g2 + g1 + g0;   // integers: any order
                         exceed += (ss >= sobs);
+#if LGMI_PABL & 524288
+                        s_id += 64u;
+#else
                         s_id = atomicAdd(&next_s, 1u);
+#endif
                         call = 0u;
                         phase = s_id < n_shuffles ? 0 : 3;
                     }
