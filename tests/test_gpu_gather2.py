@@ -49,6 +49,12 @@ def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world):
         for p in procs:
             if p.poll() is None:
                 p.kill()                                       # exactly the processes started here
+        # the stand-in's mailbox lives in /dev/shm (memory): nothing of it may outlive the test, passed or not; its
+        # directory name carries the pid of the rank that made the unique id (rank 0)
+        import glob
+        import shutil
+        for d in glob.glob('/dev/shm/frccl_%d_*' % procs[0].pid):
+            shutil.rmtree(d, ignore_errors=True)
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (rank, se[-3000:])
     line = json.loads(outs[0][0].strip().splitlines()[-1])
