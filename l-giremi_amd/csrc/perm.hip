@@ -28,6 +28,7 @@
 // within 1e-4 of the boundary (same decisions as det_exp as long as the hardware value is
 // within 1e-4 of it — measured 2e-7, pinned by a device-side sweep in the GPU tests).
 #include <algorithm>
+#include <cstdlib>
 
 #include "lgmi_internal.h"
 #include "philox.h"
@@ -38,16 +39,16 @@
 //    8 threshold-table draw replaced by a cheap hash      16 general rows not queued (k_perm_fast alone)
 //   32 exact-tail sums skipped      64 bisection skipped      128 binomial draw skipped
 // 1024 statistic look-ups skipped      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
-// 131072 streamlined 3x2 loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
-// 262144 streamlined 3x2 loop: the threshold-table search stops after three probes (what the long searches of the
-//        two tail buckets cost the whole wave)
-// 524288 streamlined 3x2 loop: lanes take shuffles by a fixed stride of 64 instead of from the shared LDS counter
+// 2048 lock-step loop: every LF / G look-up replaced by arithmetic (no vector-memory instruction; with 131072's hash)
+// 131072 lock-step loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
+// (262144, 524288 belonged to round 2's streamlined 3x2 loop — capped table search, fixed-stride shuffles; their
+//  measurements are in DESIGN.md §8 — and went with it when the lock-step streams came.)
 // Every surviving bit keeps all table indices inside the range the normal path uses and keeps every rejection
 // loop's acceptance probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the
 // acceptance test unsatisfiable, so k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536,
 // one of which indexed LF[] with set-up values it had skipped (GPU memory fault).  They are gone for good.
 #endif
-#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 4096 | 8192 | 131072 | 262144 | 524288)
+#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 2048 | 4096 | 8192 | 131072)
 #if LGMI_PABL & ~LGMI_PABL_KNOWN
 #error "LGMI_PABL: unknown ablation bit (see the list above; 256, 2048, 16384, 32768, 65536 were removed: they hang or fault)"
 #endif
@@ -62,6 +63,16 @@ template <class T> struct Tab {
     __device__ __forceinline__ T operator[](uint32_t i) const {
         return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + (size_t)(i * (uint32_t)sizeof(T)));
     }
+    // the look-ups of the lock-step loop (the timing ablations 2048 / 131072 apply to these only)
+    __device__ __forceinline__ T ls(uint32_t i) const {
+#if LGMI_PABL & 2048
+        return (T)(i & 15u);                      // no load at all
+#elif LGMI_PABL & 131072
+        return (*this)[i & 15u];                  // one L1-resident line
+#else
+        return (*this)[i];
+#endif
+    }
 };
 typedef Tab<long long> TabG;
 typedef Tab<double> TabLF;
@@ -74,6 +85,8 @@ __device__ __forceinline__ U4 cheap_rng(uint32_t a, uint32_t b) {
 
 static const uint32_t TAG_PERM2X2 = 0x5eed0004u;
 static const uint32_t TAG_PERMGEN = 0x60000000u;
+static const uint32_t TAG_LSX = 0x70000000u;      // lock-step rows: the first draws X[k]
+static const uint32_t TAG_LSC = 0x71000000u;      // lock-step rows: + lane = the lane's candidate stream
 
 #define LN2_HI 6.93147180369123816490e-01
 #define LN2_LO 1.90821492927058770002e-10
@@ -557,11 +570,6 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 // needed and sets up the next real draw inside the same trip.  The stream of uniforms of a
 // shuffle is consumed strictly in order, so the result is that of the sequential
 // specification (oracle/lgmi_perm_oracle.c: perm_one) whatever the interleaving.
-#if LGMI_PABL & 131072
-#define LGMI_IX(i) ((i) & 15u)
-#else
-#define LGMI_IX(i) (i)
-#endif
 #define HRUA_D1 1.7155277699214135
 #define HRUA_D2 0.8989161620588988
 
@@ -589,8 +597,9 @@ struct GState {
     uint32_t call;
     // table being drawn
     uint32_t s, rr0, rr1, pop_all, cc, pop, xa;
-    uint32_t sp1, sp2;     // words 1, 2 of the threshold-table draw's call: the next pair of uniforms (spare != 0)
-    int spare;
+    uint32_t sp1, sp2, sp3;   // words 1 - 3 of the last Philox call: two pairs of 24-bit uniforms (next_pair in the oracle)
+    int spare;                // how many of the two pairs are still unused
+    int aft;                  // the last draw was the threshold-table draw (the row's hat width applies to the next one)
     int d;                 // draw index: column d>>1, row d&1
     long long ss;
     // draw in flight
@@ -604,11 +613,20 @@ struct GState {
 //   tab_thr[e]   inverse-CDF thresholds of the first real draw of a shuffle.  Its parameters are the same in every
 //                shuffle of the row, so it is drawn with one 32-bit word and a binary search instead of a
 //                rejection loop (window of at most FIRST_MAX values around the mode, else the HRUA path stays)
-//   tab_guide[b] where the search starts for a word whose top byte is b (256 buckets: 1 - 3 probes instead of 11)
+//   tab_guide[b] where the search starts for a word whose top GUIDE_BITS bits are b (256 buckets: 1 - 3 probes instead of
+//                11; round 3 measured 1024 and 2048 buckets — 0 - 1 probes — within 1 % of 256: tools/exp_guide.sh)
 //   next_s       the next shuffle index nobody has taken: a lane that finishes a shuffle takes the next one, so
 //                the wave drains together whatever the lanes' rejection counts were (the exceed count is a sum
 //                over shuffles and every shuffle has its own Philox stream: who runs which one does not matter)
-static const uint32_t FIRST_MAX = 2032;
+#ifndef LGMI_FIRST_MAX
+#define LGMI_FIRST_MAX 2032
+#endif
+static const uint32_t FIRST_MAX = LGMI_FIRST_MAX;
+#ifndef LGMI_GUIDE_BITS
+#define LGMI_GUIDE_BITS 8
+#endif
+static const uint32_t GUIDE_SH = 32u - LGMI_GUIDE_BITS, GUIDE_N = 1u << LGMI_GUIDE_BITS;
+static const uint32_t XRING = 512;      // entries of the lock-step rows' ring of first draws (a power of two)
 
 // rint(p * 2^52) for 0 <= p < 1 without a 64-bit conversion: adding 2^52 leaves the rounded value in the mantissa
 __device__ __forceinline__ unsigned long long to_fixed52(double p) {
@@ -616,7 +634,10 @@ __device__ __forceinline__ unsigned long long to_fixed52(double p) {
     return (unsigned long long)__double_as_longlong(t) & 0x000FFFFFFFFFFFFFull;
 }
 
-__global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
+#ifndef LGMI_PERM_WPS
+#define LGMI_PERM_WPS 4            // waves per SIMD the register budget of k_perm_general is set for
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WPS, LGMI_PERM_WPS))) void k_perm_general(PermArgs pa)
 {
     const uint32_t* __restrict__ gen_list = pa.gen_list; const unsigned int* __restrict__ gen_count = pa.gen_count;
     const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
@@ -625,8 +646,9 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
     const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
     double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
     __shared__ uint32_t tab_thr[FIRST_MAX];
-    __shared__ uint16_t tab_guide[257];     // tab_guide[b] = the draw for u = b << 24: where the search for u >> 24 == b starts
+    __shared__ uint16_t tab_guide[GUIDE_N + 1u];   // tab_guide[b] = the draw for u = b << GUIDE_SH: where the search for u >> GUIDE_SH == b starts
     __shared__ uint32_t next_s;
+    __shared__ __attribute__((aligned(8))) uint16_t x_ring[XRING];   // lock-step rows: first draws waiting for a lane
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_gen = *gen_count;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -736,7 +758,7 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                     if (lane >= (uint32_t)o) incl += v;
                 }
                 const unsigned long long before = (incl - loc) >> 20;
-                for (uint32_t b = lane; b < 257u; b += 64u) tab_guide[b] = (uint16_t)(tab_n - 1u);
+                for (uint32_t b = lane; b < GUIDE_N + 1u; b += 64u) tab_guide[b] = (uint16_t)(tab_n - 1u);
                 // the final threshold just before this lane's segment (the last one of the lane below; segments are
                 // dealt in lane order, so a lane with entries has a full lane below it)
                 const unsigned long long my_last = (loc >> 20) + before;
@@ -744,7 +766,7 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                 const uint32_t below = __shfl_up(last_final, 1);
                 __syncthreads();                       // guide defaults written before any bucket is
                 // one pass: add what the lanes below sum to, clamp, and let entry e — the answer for every u in
-                // [thr[e-1], thr[e]) — start the buckets whose first value b << 24 falls in that range (thresholds do
+                // [thr[e-1], thr[e]) — start the buckets whose first value b << GUIDE_SH falls in that range (thresholds do
                 // not decrease, so each bucket is written once)
                 uint32_t prev = lane > 0u && e0 < tab_n ? below : 0u;
                 for (uint32_t e = e0; e < e1; ++e) {
@@ -752,8 +774,8 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                     const uint32_t cur = t >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
                     tab_thr[e] = cur;
                     if (cur > prev) {
-                        const uint32_t b_hi = (cur - 1u) >> 24;
-                        for (uint32_t b = (uint32_t)(((unsigned long long)prev + 0xFFFFFFull) >> 24); b <= b_hi; ++b)
+                        const uint32_t b_hi = (cur - 1u) >> GUIDE_SH;
+                        for (uint32_t b = (uint32_t)(((unsigned long long)prev + ((1ull << GUIDE_SH) - 1ull)) >> GUIDE_SH); b <= b_hi; ++b)
                             tab_guide[b] = (uint16_t)e;
                     }
                     prev = cur;
@@ -793,12 +815,16 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
 
         // ---- 3 x 2 and 2 x 3 tables whose two real draws are "threshold table, then HRUA" for every possible
         //      first result (the usual case: a tri-allelic site against a bi-allelic one at hundreds of reads or
-        //      more): the same draws, streams and arithmetic as the general state machine below, without its
-        //      generality — one begin (table draw + HRUA set-up) and one candidate per trip, the statistic in
-        //      closed form.  Anything else (urn-sized draws, draws that can be trivially determined, 3 x 3)
-        //      takes the general path.
+        //      more): the 64 lanes are the 64 LOCK-STEP CANDIDATE STREAMS of the specification (perm_lockstep in
+        //      oracle/lgmi_perm_oracle.c).  The first draws X[k] are made in bulk through the row's table, four per
+        //      Philox call with every lane busy, into a ring in LDS; a trip is one HRUA candidate per lane — a Philox
+        //      call per lane serves two trips, no lane ever needs a first draw inside the loop — and the lanes that
+        //      accept score their table (the statistic in closed form), take the next first draws in lane order
+        //      (a ballot, no atomics) and set up their next second draw.  The lanes stop together after the trip in
+        //      which the n_shuffles-th table is scored: no drain tail.  Anything else (urn-sized draws, draws that
+        //      can be trivially determined, 3 x 3) takes the general path below.
         bool simple = false;
-        if (tab_ok && nr * nc == 6) {
+        if (tab_ok && nr * nc == 6 && d7max > 0.0) {
             const uint32_t xlo = tab_klo, xhi = tab_klo + tab_n - 1u;
             if (nr == 3) {
                 const uint32_t pop2 = N - R0;
@@ -818,95 +844,98 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
             HrBase hb;
             hb.pop = pop2; hb.good = 0u; hb.d4 = 0.0; hb.cvar = 0.0; hb.c9 = 0.0;
             if (nr == 3) hr_base(rc2, R1, hb);
-            uint32_t s_id = lane, call = 0u, exceed = 0u, x0 = 0u;
-            uint32_t good = 0u, sample = 0u, m = 0u, mn = 0u, mx = 0u;
+            const double d8 = HRUA_D1 * d7max + HRUA_D2, lim16 = 16.0 * d7max;   // the row's hat (no square root per shuffle)
+            uint32_t filled = 0u, next = 0u, total = 0u;             // wave-uniform
+            uint32_t exceed = 0u;
+            uint32_t m = 0u, mn = 0u, mxm = 0u;                     // mxm = mx - m
+            long long gxa = 0, gxb = 0;                              // G of the two cells that depend on x0 only
             // d10 (the log-weight at the mode) is kept as its four table values and summed where it is used, in the
-            // order the specification adds them: the set-up's look-ups are then still in flight when the candidate's
-            // look-ups are issued, and one wait covers both (a trip had three dependent rounds of global loads)
-            double d6 = 0.0, d8 = 0.0, d10a = 0.0, d10b = 0.0, d10c = 0.0, d10d = 0.0, d11 = 0.0;
-            int phase = s_id < n_shuffles ? 0 : 3;       // 0 begin, 1 HRUA candidates, 3 finished
-            // What bounds this loop is the number of instructions a trip issues, of any kind (one per SIMD and
-            // 4-cycle round: VALU issue 0.66 = the VALU share of the trip's instructions; look-ups that always hit
-            // L1 do not change the time, tools/abl_perm.sh 131072).  Hence: few, large conditional blocks (every
-            // `if` is three scalar instructions around its body), look-ups issued in the reverse of the order
-            // their sums need them (one s_waitcnt instead of one per term), no squeeze tests before the exp.
-            // (Deferring the statistic's six look-ups to the lane's next accepted shuffle, so that their sum never
-            // waits, was built and measured: no gain — latency is not what this loop pays for.)
-            for (;;) {
-                // one Philox call per trip and lane (a finished lane's words are not used).  A lane that starts a
-                // shuffle (call 0) draws its first result from word 0 through the row's table and takes words 1, 2
-                // for the first candidate of the second draw; a lane that is retrying takes words 0, 1 of its next call.
-                const U4 o = philox4x32_10(s_id, ci, cj, TAG_PERMGEN + call, k0, k1);
-                call++;
-                uint32_t wx_ = o.x, wy_ = o.y;
-                if (phase == 0) {
-                    uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
-#if LGMI_PABL & 262144
-                    for (int it_ = 0; it_ < 3 && lo < hi; ++it_) {
-#else
-                    while (lo < hi) {
-#endif
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
-                    }
-                    x0 = tab_klo + lo;
-                    wx_ = o.y; wy_ = o.z;
-                    // second draw: HRUA set-up (the expressions of the general path)
-                    if (nr == 3) { good = R1; sample = C0 - x0; }
-                    else { good = R0 - x0; sample = C1; hr_base(rc2, good, hb); }
-                    const uint32_t bad = pop2 - good;
-                    m = sample < pop2 - sample ? sample : pop2 - sample;
-                    mn = good < bad ? good : bad;
-                    mx = good < bad ? bad : good;
-                    d6 = (double)m * hb.d4 + 0.5;
-                    const double d7 = d7max;                     // the row's hat width (no square root per shuffle)
-                    const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
-                    d10d = LF[LGMI_IX(mx - m + d9)]; d10c = LF[LGMI_IX(m - d9)]; d10b = LF[LGMI_IX(mn - d9)]; d10a = LF[LGMI_IX(d9)];
-                    d8 = HRUA_D1 * d7 + HRUA_D2;
-                    const double cap = (double)((m < mn ? m : mn) + 1u);
-                    const double lim = floor(d6 + 16.0 * d7);
-                    d11 = cap < lim ? cap : lim;
-                    phase = 1;
+            // order the specification adds them: the set-up's look-ups are then still in flight when the next
+            // candidate's look-ups are issued, and one wait covers both
+            double d6 = 0.0, d10a = 0.0, d10b = 0.0, d10c = 0.0, d10d = 0.0, d11 = 0.0;
+            // 256 more first draws: lane l makes call filled / 4 + l and writes X[4 c .. 4 c + 3] as offsets into the
+            // window (u16), one 8-byte store.  The ring holds X[next .. filled): at most 63 + 256 of its 512 entries
+            auto first_draw = [&](uint32_t u) {
+                uint32_t lo = tab_guide[u >> GUIDE_SH], hi = tab_guide[(u >> GUIDE_SH) + 1u];
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (u < tab_thr[mid]) hi = mid; else lo = mid + 1u;
                 }
-                const double x = ((double)wx_ + 0.5) * 2.3283064365386963e-10;
-                const double y = ((double)wy_ + 0.5) * 2.3283064365386963e-10;
-                const double w = d6 + d8 * (y - 0.5) / x;
-                if (phase == 1 && !(w < 0.0 || w >= d11)) {
-                    const uint32_t zc = (uint32_t)floor(w);
-                    const double l3 = LF[LGMI_IX(mx - m + zc)], l2 = LF[LGMI_IX(m - zc)], l1 = LF[LGMI_IX(mn - zc)], l0 = LF[LGMI_IX(zc)];
-                    const double lz = l0 + l1 + l2 + l3;
-                    const double tt = (d10a + d10b + d10c + d10d) - lz;
-                    bool acc = le_exp(x * x, tt);                   // 2 ln x <= tt
-#if LGMI_PABL & 131072
-                    exceed += acc; acc = (wy_ & 0xFFu) < 184u;
+                return lo;
+            };
+            auto refill = [&]() {
+                const uint32_t c = (filled >> 2) + lane;
+                const U4 o = philox4x32_10(c, ci, cj, TAG_LSX, k0, k1);
+                const uint32_t e0 = first_draw(o.x), e1 = first_draw(o.y), e2 = first_draw(o.z), e3 = first_draw(o.w);
+                uint2 v; v.x = e0 | (e1 << 16); v.y = e2 | (e3 << 16);
+                *reinterpret_cast<uint2*>(&x_ring[(4u * c) & (XRING - 1u)]) = v;
+                filled += 256u;
+                __syncthreads();                         // (one wave per workgroup: orders the stores before the reads)
+            };
+            // HRUA set-up of the second draw for first result x0 (the expressions of the general path)
+            auto setup = [&](uint32_t e) {
+                const uint32_t x0 = tab_klo + e;
+                uint32_t good, sample;
+                if (nr == 3) { good = R1; sample = C0 - x0; }
+                else { good = R0 - x0; sample = C1; hr_base(rc2, good, hb); }
+                const uint32_t bad = pop2 - good;
+                m = sample < pop2 - sample ? sample : pop2 - sample;
+                mn = good < bad ? good : bad;
+                mxm = (good < bad ? bad : good) - m;
+                d6 = (double)m * hb.d4 + 0.5;
+                const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
+                gxa = G.ls(x0); gxb = G.ls((nr == 3 ? R0 : C0) - x0);
+                d10d = LF.ls(mxm + d9); d10c = LF.ls(m - d9); d10b = LF.ls(mn - d9); d10a = LF.ls(d9);
+                const double cap = (double)((m < mn ? m : mn) + 1u);
+                const double lim = floor(d6 + lim16);
+                d11 = cap < lim ? cap : lim;
+            };
+            // one trip: candidate (wx, wy) of every lane; true when the row is finished (wave-uniform)
+            auto trip = [&](uint32_t wx, uint32_t wy) {
+                if (filled - next < 64u) refill();
+                const double u = (double)wx + 0.5;
+                const double v = (double)(int)(wy ^ 0x80000000u) + 0.5;
+                const double w = d6 + d8 * v / u;
+                bool acc = false;
+                // the candidate's four arguments zc, mn - zc, m - zc, mx - m + zc (minority kind in the smaller part,
+                // ...) ARE the table's four cells that depend on the second draw, in some order: the accepted table's
+                // statistic is the G of the same four indices plus the two cells x0 alone fixes (looked up at set-up) —
+                // no mapping back to "z of the first row", no second set of index arithmetic
+                uint32_t zc = 0u;
+                if (!(w < 0.0 || w >= d11)) {
+                    zc = (uint32_t)floor(w);
+                    const double l3 = LF.ls(mxm + zc), l2 = LF.ls(m - zc), l1 = LF.ls(mn - zc), l0 = LF.ls(zc);
+                    const double tt = (d10a + d10b + d10c + d10d) - (l0 + l1 + l2 + l3);
+                    const double x = u * 2.3283064365386963e-10;
+                    acc = le_exp(x * x, tt);                     // 2 ln x <= tt
+#if LGMI_PABL & (131072 | 2048)
+                    exceed += acc; acc = (wy & 0xFFu) < 184u;
 #endif
-                    if (acc) {
-                        uint32_t z = zc;
-                        if (good > pop2 - good) z = m - z;       // z counted the minority kind
-                        if (m < sample) z = good - z;            // drew the complement
-                        uint32_t i1, i2, i3, i4, i5;             // the table's other five cells
-                        if (nr == 3) {
-                            const uint32_t x2 = C0 - x0 - z;
-                            i1 = z; i2 = x2; i3 = R0 - x0; i4 = R1 - z; i5 = R2 - x2;
-                        } else {
-                            const uint32_t t02 = R0 - x0 - z;
-                            i1 = C0 - x0; i2 = z; i3 = C1 - z; i4 = t02; i5 = R1 - (C0 - x0) - (C1 - z);
-                        }
-                        const long long g0 = G[LGMI_IX(x0)], g1 = G[LGMI_IX(i1)], g2 = G[LGMI_IX(i2)], g3 = G[LGMI_IX(i3)],
-                                        g4 = G[LGMI_IX(i4)], g5 = G[LGMI_IX(i5)];
-                        const long long ss = g5 + g4 + g3 + g2 + g1 + g0;   // integers: any order
-                        exceed += (ss >= sobs);
-#if LGMI_PABL & 524288
-                        s_id += 64u;
-#else
-                        s_id = atomicAdd(&next_s, 1u);
-#endif
-                        call = 0u;
-                        phase = s_id < n_shuffles ? 0 : 3;
-                    }
                 }
-                if (!__any(phase != 3)) break;
+                const unsigned long long bal = __ballot(acc);
+                if (acc) {
+                    const long long g3 = G.ls(mxm + zc), g2 = G.ls(m - zc), g1 = G.ls(mn - zc), g0 = G.ls(zc);
+                    const long long gx = gxa + gxb;                  // (before the set-up below overwrites them)
+                    const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    setup(x_ring[(next + rank) & (XRING - 1u)]);
+                    const long long ss = g3 + g2 + g1 + g0 + gx;     // integers: any order
+                    // tables are numbered in lane order; those beyond n_shuffles are surplus of the last trip
+                    exceed += (uint32_t)((ss >= sobs) & (total + rank < n_shuffles));
+                }
+                const uint32_t na = (uint32_t)__popcll(bal);
+                next += na;
+                total += na;
+                return total >= n_shuffles;
+            };
+            refill();
+            setup(x_ring[lane]);
+            next = 64u;
+            for (uint32_t c = 0u;; ++c) {                        // the row ends for all lanes together
+                const U4 o = philox4x32_10(c, ci, cj, TAG_LSC + lane, k0, k1);
+                if (trip(o.x, o.y)) break;
+                if (trip(o.z, o.w)) break;
             }
+            __syncthreads();                                     // the ring's last reads precede the next row's stores
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) exceed += __shfl_xor(exceed, o);
             if (lane == 0) {
@@ -918,7 +947,7 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
 
         GState g;
         g.s = lane; g.phase = 3; g.call = 0; g.d = 0; g.ss = 0;
-        g.rr0 = 0; g.rr1 = 0; g.pop_all = 0; g.cc = 0; g.pop = 0; g.xa = 0; g.sp1 = 0; g.sp2 = 0; g.spare = 0;
+        g.rr0 = 0; g.rr1 = 0; g.pop_all = 0; g.cc = 0; g.pop = 0; g.xa = 0; g.sp1 = 0; g.sp2 = 0; g.sp3 = 0; g.spare = 0; g.aft = 0;
         g.good = 0; g.sample = 0; g.m = 0; g.mn = 0; g.mx = 0; g.d6 = 0; g.d8 = 0; g.d10 = 0; g.d11 = 0;
         g.rem_total = 0; g.rem_good = 0; g.left = 0;
         uint32_t rr2 = 0;
@@ -931,15 +960,16 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
 #if LGMI_PABL & 8
             const U4 o = cheap_rng(g.s + ci, g.call + cj);
             g.call++;
-            { const uint32_t e_ = (tab_n >> 1) + (o.x & 7u); return tab_klo + (e_ < tab_n ? e_ : tab_n - 1u); }   // stays inside the window
+            { g.sp1 = o.y; g.sp2 = o.z; g.sp3 = o.w; g.spare = 2; g.aft = 1;
+              const uint32_t e_ = (tab_n >> 1) + (o.x & 7u); return tab_klo + (e_ < tab_n ? e_ : tab_n - 1u); }   // stays inside the window
 #else
             const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
 #endif
             g.call++;
-            g.sp1 = o.y; g.sp2 = o.z; g.spare = 1;     // the next pair of uniforms comes from this call
+            g.sp1 = o.y; g.sp2 = o.z; g.sp3 = o.w; g.spare = 2; g.aft = 1;   // the next two pairs of uniforms come from this call
             // smallest e with u < thr[e] (the last entry when there is none); the guide table narrows the
             // search to the entries between the answers for the bucket's first value and the next bucket's
-            uint32_t lo = tab_guide[o.x >> 24], hi = tab_guide[(o.x >> 24) + 1u];
+            uint32_t lo = tab_guide[o.x >> GUIDE_SH], hi = tab_guide[(o.x >> GUIDE_SH) + 1u];
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (o.x < tab_thr[mid]) hi = mid; else lo = mid + 1u;
@@ -947,31 +977,34 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
             return tab_klo + lo;
         };
         if (need_begin) {
-            g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
+            g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0; g.spare = 0; g.aft = 0;
             g.cc = C0; g.pop = N;
             if (tab_ok) { z = table_draw(); have_z = true; need_begin = false; }
         }
 
         for (;;) {
-            // ---- (1) one candidate / urn step for the lanes that are inside a draw.  One Philox call
-            //          per trip (no divergent refills): words 0 and 1 make the uniforms (w + 0.5) * 2^-32
+            // ---- (1) one candidate / urn step for the lanes that are inside a draw: the next pair of 24-bit
+            //          uniforms, two pairs per Philox call (pair A = words 1, 2 >> 8, pair B = word 3 >> 8 and the low
+            //          bytes of words 1 - 3; word 0 is the threshold-table draw's)
             const bool in_draw = !need_begin && g.phase != 3;
             double ux = 0.5, uy = 0.5;
             if (in_draw) {
-                uint32_t wx_, wy_;
-                if (g.spare) {                          // right after a threshold-table draw
-                    g.spare = 0; wx_ = g.sp1; wy_ = g.sp2;
-                } else {
+                if (g.spare == 0) {
 #if LGMI_PABL & 1
                     const U4 o = philox4x32_r<5>(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
 #else
                     const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
 #endif
                     g.call++;
-                    wx_ = o.x; wy_ = o.y;
+                    g.sp1 = o.y; g.sp2 = o.z; g.sp3 = o.w; g.spare = 2;
                 }
-                ux = ((double)wx_ + 0.5) * 2.3283064365386963e-10;
-                uy = ((double)wy_ + 0.5) * 2.3283064365386963e-10;
+                uint32_t vx, vy;
+                if (g.spare == 2) { vx = g.sp1 >> 8; vy = g.sp2 >> 8; }
+                else { vx = g.sp3 >> 8; vy = ((g.sp1 & 0xFFu) << 16) | ((g.sp2 & 0xFFu) << 8) | (g.sp3 & 0xFFu); }
+                g.spare--;
+                g.aft = 0;
+                ux = ((double)vx + 0.5) * 5.9604644775390625e-08;
+                uy = ((double)vy + 0.5) * 5.9604644775390625e-08;
             }
             if (in_draw && g.phase == 1) {
                 const double x = ux, y = uy;
@@ -1040,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                                 exceed += (g.ss >= sobs);
                                 g.s = atomicAdd(&next_s, 1u);
                                 if (g.s >= n_shuffles) { g.phase = 3; done = true; break; }
-                                g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0;
+                                g.rr0 = R0; g.rr1 = R1; rr2 = R2; g.pop_all = N; g.ss = 0; g.d = 0; g.call = 0; g.spare = 0; g.aft = 0;
                                 if (tab_ok) { g.cc = C0; g.pop = N; z = table_draw(); have_z = true; }
                             }
                         }
@@ -1071,7 +1104,7 @@ __global__ __launch_bounds__(64) void k_perm_general(PermArgs pa)
                         const double d7 = (double)__fsqrt_rn((float)((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5));
 #else
                         // the draw right after the table draw of a 3 x 2 / 2 x 3 row takes the row's hat width
-                        const bool bounded = d7max > 0.0 && g.spare && pop == key_pop2 && (nr == 3 ? good == key2 : sample == key2);
+                        const bool bounded = d7max > 0.0 && g.aft && pop == key_pop2 && (nr == 3 ? good == key2 : sample == key2);
                         const double d7 = bounded ? d7max : det_sqrt((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5);
 #endif
                         const uint32_t d9 = (uint32_t)floor((double)(g.m + 1u) * hb.c9);
@@ -1129,7 +1162,9 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
     if (!a.max_rows || !a.n_shuffles) return;
     // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
     // take the queued rows from a shared counter
-    hipLaunchKernelGGL(k_perm_general, dim3(256 * 16), dim3(64), 0, st, a);
+    // (LGMI_PERM_WPC: one-wave workgroups per CU, for occupancy experiments — tools/abl_perm.sh; 16 = four per SIMD)
+    static const int wpc = [] { const char* e = getenv("LGMI_PERM_WPC"); const int v = e ? atoi(e) : 16; return v >= 1 && v <= 32 ? v : 16; }();
+    hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, a);
 }
 
 }  // namespace lgmi

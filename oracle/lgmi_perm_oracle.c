@@ -142,25 +142,43 @@ static int tables_init(perm_tables* t, uint32_t max_n)
 }
 
 /* ------------------------------------------------------------------ uniform streams */
-typedef struct { uint32_t c0, c1, c2, k0, k1, call; uint32_t buf[4]; int have; } gen_stream;
+typedef struct {
+    uint32_t c0, c1, c2, k0, k1, call;
+    uint32_t buf[4];
+    int have;          /* pairs of uniforms still unused in buf: 0, 1 or 2 */
+    int after_table;   /* the last draw was the threshold-table draw (hg_draw: the row-constant hat width) */
+} gen_stream;
 
-/* one Philox call per candidate / urn step: u[0], u[1] = ((word + 0.5) * 2^-32) of the first two
- * words (exact in double, never 0 or 1); the other two words are not used.  Exception: the pair that follows a
- * threshold-table draw comes from words 1 and 2 of the table draw's own call (word 0 drew the table), so that a
- * shuffle's first two draws cost one call. */
+/* Uniforms of the conditional draws: 24-bit, u = (v + 0.5) * 2^-24 (exact in double, never 0 or 1), TWO pairs per
+ * Philox call (round 3; rounds 1-2 took one 32-bit pair per call and threw half of every call away):
+ *     pair A = (word1 >> 8, word2 >> 8)
+ *     pair B = (word3 >> 8, (word1 & 0xFF) << 16 | (word2 & 0xFF) << 8 | (word3 & 0xFF))
+ * i.e. words 1-3 are cut into four disjoint 24-bit fields.  Word 0 belongs to the threshold-table draw: call 0 of a
+ * shuffle whose first draw has a table spends it there and its pairs A, B serve the draws that follow; in every other
+ * call word 0 is not used.  A rejection loop consumes A, B, then the next call's A, B, ...: the kernel evaluates both
+ * candidates of a call side by side (two independent dependency chains per lane) and takes the first acceptable one,
+ * so one call ends a ratio-of-uniforms draw with probability 1 - 0.28^2 = 0.92 instead of 0.72.  24 bits: the
+ * candidate w = d6 + d8 (y - 1/2) / x moves by <= 1e-5 of an integer bin per step of y, the acceptance test by 6e-8
+ * relative per step of x — the same discretisation single-precision generators live with. */
 static void next_pair(gen_stream* g, double* u0, double* u1)
 {
-    if (g->have) {
-        /* right after a threshold-table draw: words 1 and 2 of the call that drew it */
-        g->have = 0;
-        *u0 = ((double)g->buf[1] + 0.5) * 2.3283064365386963e-10;
-        *u1 = ((double)g->buf[2] + 0.5) * 2.3283064365386963e-10;
-        return;
+    uint32_t vx, vy;
+    if (!g->have) {
+        philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
+        g->call++;
+        g->have = 2;
     }
-    philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
-    g->call++;
-    *u0 = ((double)g->buf[0] + 0.5) * 2.3283064365386963e-10;
-    *u1 = ((double)g->buf[1] + 0.5) * 2.3283064365386963e-10;
+    if (g->have == 2) {
+        vx = g->buf[1] >> 8;
+        vy = g->buf[2] >> 8;
+    } else {
+        vx = g->buf[3] >> 8;
+        vy = ((g->buf[1] & 0xFFu) << 16) | ((g->buf[2] & 0xFFu) << 8) | (g->buf[3] & 0xFFu);
+    }
+    g->have--;
+    g->after_table = 0;
+    *u0 = ((double)vx + 0.5) * 5.9604644775390625e-08;     /* 2^-24 */
+    *u1 = ((double)vy + 0.5) * 5.9604644775390625e-08;
 }
 
 /* ------------------------------------------------------------------ hypergeometric draw */
@@ -263,7 +281,8 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
         uint32_t lo = 0, hi = ft->n - 1, u;
         philox(g->c0, g->c1, g->c2, TAG_PERMGEN + g->call, g->k0, g->k1, g->buf);
         g->call++;
-        g->have = 1;                 /* words 1, 2 serve the next pair of uniforms */
+        g->have = 2;                 /* words 1 - 3 of this call are the next two pairs of uniforms */
+        g->after_table = 1;
         u = g->buf[0];
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -293,7 +312,7 @@ static uint32_t hg_draw(const perm_tables* t, uint32_t pop, uint32_t good, uint3
         const double cvar = d4 * (1.0 - d4) * rp1;
         const double c9 = (double)(mn + 1) * rp2;
         const double d6 = (double)m * d4 + 0.5;
-        const int bounded = ft && ft->valid && ft->d7_next > 0.0 && g->have && pop == ft->pop2 &&
+        const int bounded = ft && ft->valid && ft->d7_next > 0.0 && g->after_table && pop == ft->pop2 &&
                             (ft->nr3 ? good == ft->key2 : sample == ft->key2);
         const double d7 = bounded ? ft->d7_next : lgo_det_sqrt((double)(pop - m) * (double)m * cvar + 0.5);
         const double d8 = HRUA_D1 * d7 + HRUA_D2;
@@ -553,6 +572,139 @@ static void hrua_width_bound(first_table* ft, uint32_t N, int nr, uint32_t R0, u
     ft->d7_next = lgo_det_sqrt(varmax + 0.5) * (1.0 + 9.094947017729282e-13);   /* 1 + 2^-40 */
 }
 
+/* ------------------------------------------------------------------ 3 x 2 / 2 x 3 rows: 64 lock-step candidate streams
+ *
+ * Round 3.  A table with six non-empty cells has two real draws: x0 (first row, first column) from the row's
+ * threshold table, then one HRUA draw whose parameters depend on x0.  When that second draw is HRUA-sized for every
+ * x0 of the table's window (simple_row below — the usual case) the row's n_shuffles tables are produced by 64
+ * candidate streams that advance in lock-step "trips" instead of by n_shuffles independent per-shuffle streams:
+ *
+ *   X[k], k = 0, 1, ...   the first draws: word k & 3 of Philox(counter = (k >> 2, row_i, row_j, TAG_LSX)) through
+ *                         the row's threshold table (inverse CDF, as in hg_draw);
+ *   stream l = 0 .. 63    candidate pairs (wx, wy): words (0, 1) of Philox((c, row_i, row_j, TAG_LSC + l)) in trip
+ *                         2c, words (2, 3) in trip 2c + 1.  u = wx + 1/2, v = (wy - 2^31) + 1/2 (both exact), the
+ *                         candidate is w = d6 + d8 v / u (the 2^-32 scalings of Stadlober's (y - 1/2) / x cancel) and
+ *                         it is accepted iff 0 <= w < d11 and (u 2^-32)^2 <= exp(t(floor w)), as in hg_draw.
+ *   Stream l starts with X[l]; `next` = 64.  In trip t every stream tests one candidate for its current x0.  The
+ *   streams that accept complete a table each; taken in stream order they are tables number total, total + 1, ...:
+ *   a table with number < n_shuffles counts (exceed += S >= S_obs), the others are surplus of the last trip and are
+ *   dropped; the a-th accepting stream of the trip goes on with X[next + a].  Then next and total grow by the number of
+ *   acceptances, and the row ends after the trip in which total reaches n_shuffles.
+ *
+ * Exactly n_shuffles tables are scored; each is an exact draw from the null (an x0 from its marginal, then a
+ * rejection-sampled second cell given x0; which tables count depends on acceptance events only, never on the
+ * accepted values).  Why: on the GPU the 64 lanes of a wave are the 64 streams.  All lanes need a candidate pair in
+ * every trip and none needs a first draw, so one Philox call serves two trips of every lane (round 2: one call per
+ * trip, half of its words unused, the table search under a 72 % mask inside the loop), the first draws are made in bulk
+ * with all lanes busy and all four words of a call used, nothing is handed out through atomics, and the wave has
+ * no drain tail — the lanes stop together. */
+#define TAG_LSX 0x70000000u
+#define TAG_LSC 0x71000000u
+
+static int simple_row(const first_table* ft, uint32_t N, uint32_t nr, uint32_t nc, uint32_t R0, uint32_t C0, uint32_t C1)
+{
+    uint32_t xlo, xhi, pop2;
+    if (!ft->valid || nr * nc != 6 || !(ft->d7_next > 0.0)) return 0;
+    xlo = ft->klo; xhi = ft->klo + ft->n - 1;
+    if (nr == 3) {
+        pop2 = N - R0;
+        return (C0 - xhi >= 10u) && (pop2 - (C0 - xlo) >= 10u) && (C0 - xlo < pop2);
+    } else {
+        const uint32_t m2 = C1 < (N - C0) - C1 ? C1 : (N - C0) - C1;
+        pop2 = N - C0;
+        return (m2 >= 10u) && (R0 - xhi >= 1u) && (R0 - xlo < pop2);
+    }
+}
+
+typedef struct { uint32_t x0, good, sample, m, mn, mx; double d6, d10, d11; } ls_par;
+
+static uint32_t ls_first(const first_table* ft, uint32_t row_i, uint32_t row_j, uint32_t k0, uint32_t k1, uint32_t k)
+{
+    uint32_t buf[4], lo = 0, hi = ft->n - 1, u;
+    philox(k >> 2, row_i, row_j, TAG_LSX, k0, k1, buf);
+    u = buf[k & 3u];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (u < ft->thr[mid]) hi = mid; else lo = mid + 1;
+    }
+    return ft->klo + lo;
+}
+
+static void ls_setup(const perm_tables* t, ls_par* p, uint32_t x0, int nr3, uint32_t pop2, uint32_t R0, uint32_t R1,
+                     uint32_t C0, uint32_t C1, double d7)
+{
+    /* the expressions of hg_draw's HRUA branch with the row's hat width d7 */
+    const double rp = 1.0 / (double)pop2, rp2 = 1.0 / ((double)pop2 + 2.0);
+    uint32_t bad, d9;
+    double d4, c9, cap, lim;
+    p->x0 = x0;
+    if (nr3) { p->good = R1; p->sample = C0 - x0; } else { p->good = R0 - x0; p->sample = C1; }
+    bad = pop2 - p->good;
+    p->m = p->sample < pop2 - p->sample ? p->sample : pop2 - p->sample;
+    p->mn = p->good < bad ? p->good : bad;
+    p->mx = p->good < bad ? bad : p->good;
+    d4 = (double)p->mn * rp;
+    c9 = (double)(p->mn + 1u) * rp2;
+    p->d6 = (double)p->m * d4 + 0.5;
+    d9 = (uint32_t)floor((double)(p->m + 1u) * c9);
+    p->d10 = t->LF[d9] + t->LF[p->mn - d9] + t->LF[p->m - d9] + t->LF[p->mx - p->m + d9];
+    cap = (double)((p->m < p->mn ? p->m : p->mn) + 1u);
+    lim = floor(p->d6 + 16.0 * d7);
+    p->d11 = cap < lim ? cap : lim;
+}
+
+static uint32_t perm_lockstep(const perm_tables* t, const first_table* ft, uint32_t N, int nr3, uint32_t R0, uint32_t R1,
+                              uint32_t R2, uint32_t C0, uint32_t C1, int64_t sobs, uint32_t row_i, uint32_t row_j,
+                              uint32_t n_shuffles, uint32_t k0, uint32_t k1, uint32_t* rec /* (x0, z) of every scored table, or NULL */)
+{
+    const uint32_t pop2 = nr3 ? N - R0 : N - C0;
+    const double d7 = ft->d7_next, d8 = HRUA_D1 * d7 + HRUA_D2;
+    ls_par par[64];
+    uint32_t buf[64][4];
+    uint32_t l, trip, next = 64, total = 0, exceed = 0;
+    for (l = 0; l < 64; ++l) ls_setup(t, &par[l], ls_first(ft, row_i, row_j, k0, k1, l), nr3, pop2, R0, R1, C0, C1, d7);
+    for (trip = 0; total < n_shuffles; ++trip) {
+        uint32_t acc = 0;
+        for (l = 0; l < 64; ++l) {
+            ls_par* p = &par[l];
+            uint32_t wx, wy, zc, z;
+            double u, v, w, tt, x;
+            if ((trip & 1u) == 0) philox(trip >> 1, row_i, row_j, TAG_LSC + l, k0, k1, buf[l]);
+            wx = buf[l][2 * (trip & 1u)];
+            wy = buf[l][2 * (trip & 1u) + 1];
+            u = (double)wx + 0.5;
+            v = (double)(int32_t)(wy ^ 0x80000000u) + 0.5;
+            w = p->d6 + d8 * v / u;
+            if (w < 0.0 || w >= p->d11) continue;
+            zc = (uint32_t)floor(w);
+            tt = p->d10 - (t->LF[zc] + t->LF[p->mn - zc] + t->LF[p->m - zc] + t->LF[p->mx - p->m + zc]);
+            x = u * 2.3283064365386963e-10;                 /* 2^-32 */
+            if (!(x * x <= lgo_det_exp(tt))) continue;
+            z = zc;
+            if (p->good > pop2 - p->good) z = p->m - z;     /* z counted the minority kind */
+            if (p->m < p->sample) z = p->good - z;          /* drew the complement */
+            if (total + acc < n_shuffles) {
+                const uint32_t x0 = p->x0;
+                int64_t ss;
+                if (rec) { rec[2 * (total + acc)] = x0; rec[2 * (total + acc) + 1] = z; }
+                if (nr3) {
+                    const uint32_t x2 = C0 - x0 - z;
+                    ss = t->G[x0] + t->G[z] + t->G[x2] + t->G[R0 - x0] + t->G[R1 - z] + t->G[R2 - x2];
+                } else {
+                    ss = t->G[x0] + t->G[C0 - x0] + t->G[z] + t->G[C1 - z] + t->G[R0 - x0 - z] +
+                         t->G[R1 - (C0 - x0) - (C1 - z)];
+                }
+                exceed += (ss >= sobs);
+            }
+            ls_setup(t, p, ls_first(ft, row_i, row_j, k0, k1, next + acc), nr3, pop2, R0, R1, C0, C1, d7);
+            acc++;
+        }
+        next += acc;
+        total += acc;
+    }
+    return exceed;
+}
+
 static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row_i, uint32_t row_j,
                          uint32_t n_shuffles, uint64_t seed, double* ptail_out)
 {
@@ -587,10 +739,13 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
         first_table_build(t, N, R[nzr[0]], C[nzc[0]], &ft);   /* the first non-empty row and column */
         if (ft.valid && nr * nc == 6 && N - R[nzr[0]] > 1 && N - C[nzc[0]] > 1)
             hrua_width_bound(&ft, N, (int)nr, R[nzr[0]], R[nzr[1]], C[nzc[0]], C[nzc[1]]);
+        if (simple_row(&ft, N, nr, nc, R[nzr[0]], C[nzc[0]], C[nzc[1]]))
+            return perm_lockstep(t, &ft, N, nr == 3, R[nzr[0]], R[nzr[1]], nr == 3 ? R[nzr[2]] : 0, C[nzc[0]], C[nzc[1]],
+                                 sobs, row_i, row_j, n_shuffles, k0, k1, NULL);
         for (s = 0; s < n_shuffles; ++s) {
             gen_stream g;
             uint32_t rr[3] = {R[0], R[1], R[2]}, Ts[9], pop_all = N;
-            g.c0 = s; g.c1 = row_i; g.c2 = row_j; g.k0 = k0; g.k1 = k1; g.call = 0; g.have = 0;
+            g.c0 = s; g.c1 = row_i; g.c2 = row_j; g.k0 = k0; g.k1 = k1; g.call = 0; g.have = 0; g.after_table = 0;
             for (b = 0; b < 3; ++b) {
                 /* column b: distribute C[b] reads over the rows' remaining capacities */
                 uint32_t cc = C[b], pop = pop_all;
@@ -670,7 +825,7 @@ int lgo_hg_draw_many2(uint32_t pop, uint32_t good, uint32_t sample, uint64_t see
     if (use_table && !ft.valid) { free(t.G); free(t.LF); return -2; }
     for (i = 0; i < n; ++i) {
         gen_stream g;
-        g.c0 = i; g.c1 = 1; g.c2 = 2; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0;
+        g.c0 = i; g.c1 = 1; g.c2 = 2; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 0; g.have = 0; g.after_table = 0;
         out[i] = hg_draw(&t, pop, good, sample, &g, use_table ? &ft : NULL);
     }
     free(t.G); free(t.LF);
@@ -695,10 +850,35 @@ int lgo_hg_draw_wide(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed
         gen_stream g;
         g.c0 = i; g.c1 = 5; g.c2 = 6; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.call = 1;
         philox(i, 5, 6, TAG_PERMGEN, g.k0, g.k1, g.buf);     /* as if a table draw had just used word 0 of call 0 */
-        g.have = 1;
+        g.have = 2; g.after_table = 1;
         out[i] = hg_draw(&t, pop, good, sample, &g, ft);
     }
     free(t.G); free(t.LF); free(ft);
+    return 0;
+}
+
+/* the tables the lock-step streams of a 3 x 2 / 2 x 3 row score: (x0, z) pairs in scoring order, 2 * n_shuffles words.
+ * Returns 0, or -2 when the row does not take the lock-step path */
+int lgo_lockstep_tables(const uint32_t T[9], uint64_t seed, uint32_t n_shuffles, uint32_t* rec)
+{
+    perm_tables t;
+    first_table ft;
+    uint32_t R[3], C[3], N = 0, nzr[3], nzc[3], nr = 0, nc = 0, a;
+    for (a = 0; a < 3; ++a) {
+        R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2];
+        C[a] = T[a] + T[3 + a] + T[6 + a];
+        N += R[a];
+    }
+    for (a = 0; a < 3; ++a) { if (R[a]) nzr[nr++] = a; if (C[a]) nzc[nc++] = a; }
+    if (nr * nc != 6) return -2;
+    if (tables_init(&t, N)) return -1;
+    first_table_build(&t, N, R[nzr[0]], C[nzc[0]], &ft);
+    if (ft.valid && N - R[nzr[0]] > 1 && N - C[nzc[0]] > 1)
+        hrua_width_bound(&ft, N, (int)nr, R[nzr[0]], R[nzr[1]], C[nzc[0]], C[nzc[1]]);
+    if (!simple_row(&ft, N, nr, nc, R[nzr[0]], C[nzc[0]], C[nzc[1]])) { free(t.G); free(t.LF); return -2; }
+    (void)perm_lockstep(&t, &ft, N, nr == 3, R[nzr[0]], R[nzr[1]], nr == 3 ? R[nzr[2]] : 0, C[nzc[0]], C[nzc[1]],
+                        stat9(&t, T), 3u, 4u, n_shuffles, (uint32_t)seed, (uint32_t)(seed >> 32), rec);
+    free(t.G); free(t.LF);
     return 0;
 }
 

@@ -317,3 +317,119 @@ def test_streams_are_keyed_by_seed_and_pair():
     p3, e3 = run_perm(T, 999, seed=1)
     assert (e1 == e3).all() and (e1 != e2).any() and len(set(e1.tolist())) > 1
     assert np.allclose(p1, (1 + e1) / 1000.0)
+
+
+# ---------------------------------------------------------------- lock-step streams of 3 x 2 / 2 x 3 rows (round 3)
+LOCKSTEP_TABLES = [
+    # 3 x 2 (a tri-allelic site against a bi-allelic one): rows = classes 0, 1, 2 of site i
+    [12, 30, 0, 60, 45, 0, 150, 140, 0],
+    [0, 0, 0, 40, 90, 35, 120, 60, 55],          # 2 x 3
+    [25, 0, 20, 300, 0, 310, 800, 0, 700],
+    [0, 0, 0, 900, 400, 150, 300, 700, 160],
+    [0, 60, 70, 0, 500, 450, 0, 2000, 2100],
+]
+
+
+def _margins(T):
+    T = np.asarray(T).reshape(3, 3)
+    R, Cm = T.sum(axis=1), T.sum(axis=0)
+    return T, [int(x) for x in R if x], [int(x) for x in Cm if x]
+
+
+def _lockstep_pmf(T):
+    """exact joint pmf of (x0, z) of a six-cell table, with x0 and z as perm_lockstep defines them, and the statistic"""
+    from scipy.special import gammaln
+    T, R, Cm = _margins(T)
+    N = sum(R)
+    out = {}
+    if len(R) == 3:          # x0 = T00, z = T10; column 0 holds (x0, z, C0 - x0 - z)
+        R0, R1, R2 = R
+        C0, C1 = Cm
+        const = sum(gammaln(np.array(R) + 1.0)) + sum(gammaln(np.array(Cm) + 1.0)) - gammaln(N + 1.0)
+        for x0 in range(0, min(R0, C0) + 1):
+            for z in range(0, min(R1, C0 - x0) + 1):
+                x2 = C0 - x0 - z
+                if x2 > R2:
+                    continue
+                cells = np.array([x0, z, x2, R0 - x0, R1 - z, R2 - x2], float)
+                out[(x0, z)] = (np.exp(const - gammaln(cells + 1.0).sum()), cells)
+    else:                    # x0 = T00, z = T01; row 0 holds (x0, z, R0 - x0 - z)
+        R0, R1 = R
+        C0, C1, C2 = Cm
+        const = sum(gammaln(np.array(R) + 1.0)) + sum(gammaln(np.array(Cm) + 1.0)) - gammaln(N + 1.0)
+        for x0 in range(0, min(R0, C0) + 1):
+            for z in range(0, min(C1, R0 - x0) + 1):
+                t02 = R0 - x0 - z
+                if t02 > C2 or C0 - x0 > R1 or C1 - z > R1 - (C0 - x0):
+                    continue
+                cells = np.array([x0, z, t02, C0 - x0, C1 - z, C2 - t02], float)
+                out[(x0, z)] = (np.exp(const - gammaln(cells + 1.0).sum()), cells)
+    return out
+
+
+def _lockstep_rec(lib, T, S, seed=11):
+    lib.lgo_lockstep_tables.restype = C.c_int
+    lib.lgo_lockstep_tables.argtypes = [u32p, C.c_uint64, C.c_uint32, u32p]
+    rec = np.zeros(2 * S, np.uint32)
+    rc = lib.lgo_lockstep_tables(np.asarray(T, np.uint32).ctypes.data_as(u32p), seed, S, rec.ctypes.data_as(u32p))
+    return rc, rec.reshape(-1, 2)
+
+
+@pytest.mark.parametrize('T', LOCKSTEP_TABLES)
+def test_lockstep_tables_follow_the_null_distribution(lib, T):
+    """the (x0, z) the 64 lock-step streams score are draws from the multivariate hypergeometric null: chi-square of
+    the joint counts against the exact pmf (cells pooled until they expect >= 8), and of each margin"""
+    S = 200000
+    rc, rec = _lockstep_rec(lib, T, S)
+    assert rc == 0, 'the table does not take the lock-step path'
+    pmf = _lockstep_pmf(T)
+    assert abs(sum(p for p, _ in pmf.values()) - 1.0) < 1e-9
+    keys = sorted(pmf, key=lambda k: -pmf[k][0])
+    index = {k: n for n, k in enumerate(keys)}
+    obs = np.zeros(len(keys))
+    for x0, z in rec:
+        obs[index[(int(x0), int(z))]] += 1          # a KeyError here = a table outside the support
+    exp = np.array([pmf[k][0] for k in keys]) * S
+    # pool the tail of the probability-sorted cells into one bin of expectation >= 8
+    cut = int(np.searchsorted(-exp, -8.0))
+    o = np.append(obs[:cut], obs[cut:].sum())
+    e = np.append(exp[:cut], exp[cut:].sum())
+    chi2 = ((o - e) ** 2 / np.maximum(e, 1e-300)).sum()
+    assert stats.chi2.sf(chi2, len(o) - 1) > 1e-4, (chi2, len(o))
+    for axis in (0, 1):                            # the two margins separately (far fewer bins: sharper)
+        vals = np.array([k[axis] for k in keys])
+        lo, hi = vals.min(), vals.max()
+        e1 = np.bincount(vals - lo, weights=exp, minlength=hi - lo + 1)
+        o1 = np.bincount(rec[:, axis].astype(np.int64) - lo, minlength=hi - lo + 1).astype(float)
+        keep = e1 >= 8
+        o1 = np.append(o1[keep], o1[~keep].sum())
+        e1 = np.append(e1[keep], e1[~keep].sum())
+        ok = e1 > 0
+        chi2 = ((o1[ok] - e1[ok]) ** 2 / e1[ok]).sum()
+        assert stats.chi2.sf(chi2, ok.sum() - 1) > 1e-4, (axis, chi2)
+
+
+@pytest.mark.parametrize('T', LOCKSTEP_TABLES[:4])
+def test_lockstep_monte_carlo_p_agrees_with_enumeration(lib, T):
+    S = 60000
+    p, ex = run_perm([T], S)
+    pmf = _lockstep_pmf(T)
+    Tm = np.asarray(T, float).reshape(3, 3)
+    g = lambda c: float((np.where(c > 0, c * np.log(np.maximum(c, 1)), 0.0)).sum())
+    sobs = g(Tm.ravel())
+    exact = sum(pr for pr, cells in pmf.values() if g(cells) >= sobs - 1e-9 * max(1.0, abs(sobs)))
+    sd = np.sqrt(max(exact * (1 - exact), 1e-12) / S)
+    assert abs(ex[0] / S - exact) < 5 * sd + 2e-4, (ex[0] / S, exact)
+    # exactly S tables were scored: the recorded list is full, and a second run is identical
+    rc, rec = _lockstep_rec(lib, T, 1000)
+    rc2, rec2 = _lockstep_rec(lib, T, 1000)
+    assert rc == 0 and (rec == rec2).all() and (rec[:, 0] > 0).any()
+
+
+def test_lockstep_prefix_property(lib):
+    """the tables scored with n_shuffles = S are the first S of those scored with a larger n_shuffles (the streams do
+    not depend on n_shuffles), so exceed(S) is a prefix count"""
+    T = LOCKSTEP_TABLES[0]
+    _, a = _lockstep_rec(lib, T, 700)
+    _, b = _lockstep_rec(lib, T, 2500)
+    assert (b[:700] == a).all()
