@@ -294,6 +294,20 @@ int  lgmi_ctx_synchronize(lgmi_ctx* ctx);
 #define LGMI_UNIQUE_ID_BYTES 128
 int  lgmi_comm_unique_id(void* out128);                 /* rank 0 creates, host broadcasts */
 int  lgmi_comm_init(lgmi_ctx* ctx, const void* id128, int rank, int world);
+/* What was bound and what the communicator itself says (ncclGetVersion, ncclCommCount, ncclCommUserRank, dladdr of the
+ * library): a multi-GPU bench line carries this so that "RCCL saw N ranks" is a recorded fact, not an assumption.
+ * stand_in = 1: LGMI_RCCL_LIB pointed the library at something else than librccl — the tests' file-based stand-in,
+ * which is refused unless LGMI_ALLOW_RCCL_STANDIN=1.  -1 = the library has no such entry point.  (No reference
+ * counterpart: the reference's parallelism is multiprocessing.Pool, src/giremi/script/giremi.py:375-380.) */
+typedef struct lgmi_comm_info_t {
+    int32_t rccl_version;     /* ncclGetVersion: major * 10000 + minor * 100 + patch */
+    int32_t nranks, rank;     /* ncclCommCount / ncclCommUserRank of the context's communicator */
+    int32_t world_given, rank_given;   /* what lgmi_comm_init() was called with */
+    int32_t initialised;      /* the context has a communicator */
+    int32_t stand_in;
+    char    lib_path[512];
+} lgmi_comm_info_t;
+int  lgmi_comm_info(lgmi_ctx* ctx, lgmi_comm_info_t* out);
 /* all-gather of one u64 per rank (row counts) over RCCL */
 int  lgmi_comm_allgather_u64(lgmi_ctx* ctx, uint64_t mine, uint64_t* out_world);
 /* all-gather of n u64 per rank: out_world[r * n + k] = rank r's mine[k] */

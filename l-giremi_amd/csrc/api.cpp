@@ -161,6 +161,7 @@ struct lgmi_ctx {
     uint32_t tables_len = 0;
     void* comm = nullptr;       // ncclComm_t (comm.cpp)
     hipStream_t comm_stream = nullptr;   // the gather runs here, beside the kernels of `stream`
+    hipEvent_t comm_event = nullptr;     // main stream -> communication stream ordering (comm.cpp: comm_after_main)
     int rank = 0, world = 1;
     size_t mem_total = 0;       // device memory, for the "allocate rows by their upper bound" decision
     std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
@@ -266,6 +267,7 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->comm_event) (void)hipEventDestroy(ctx->comm_event);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -276,6 +278,10 @@ hipStream_t ctx_stream(lgmi_ctx* c) { return c->stream; }
 hipStream_t ctx_comm_stream(lgmi_ctx* c) {               // created on first use
     if (!c->comm_stream && hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess) c->comm_stream = nullptr;
     return c->comm_stream ? c->comm_stream : c->stream;
+}
+hipEvent_t ctx_comm_event(lgmi_ctx* c) {                 // created on first use
+    if (!c->comm_event && hipEventCreateWithFlags(&c->comm_event, hipEventDisableTiming) != hipSuccess) c->comm_event = nullptr;
+    return c->comm_event;
 }
 int ctx_device(lgmi_ctx* c) { return c->device; }
 void** ctx_comm_slot(lgmi_ctx* c) { return &c->comm; }

@@ -20,6 +20,7 @@ struct lgmi_dresult;
 namespace lgmi {
 hipStream_t ctx_stream(lgmi_ctx* c);
 hipStream_t ctx_comm_stream(lgmi_ctx* c);
+hipEvent_t ctx_comm_event(lgmi_ctx* c);
 int ctx_device(lgmi_ctx* c);
 void** ctx_comm_slot(lgmi_ctx* c);
 uint64_t* ctx_pinned_words(lgmi_ctx* c, size_t* n_words);
@@ -46,13 +47,27 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (lgmi_comm_info): a library without them still serves the gather
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    bool stand_in = false;
+    char path[512] = {0};
 } g;
 
 int load_rccl() {
     if (g.h) return LGMI_OK;
     // LGMI_RCCL_LIB: another library with the same ten entry points — the tests' file-based stand-in that lets two
-    // ranks share the one GPU of a test box (tests/helpers/fake_rccl.cpp); unset in any real run
+    // ranks share the one GPU of a test box (tests/helpers/fake_rccl.cpp).  A product run must never pick one up by
+    // accident (a stale environment variable would turn a "scaling" measurement into file copies): it is refused unless
+    // LGMI_ALLOW_RCCL_STANDIN=1 says the caller knows, and lgmi_comm_info() reports stand_in = 1 for it.
     const char* alt = getenv("LGMI_RCCL_LIB");
+    if (alt && *alt) {
+        const char* ok = getenv("LGMI_ALLOW_RCCL_STANDIN");
+        if (!ok || strcmp(ok, "1") != 0)
+            return set_error(LGMI_E_RCCL, "LGMI_RCCL_LIB is set (an RCCL stand-in) but LGMI_ALLOW_RCCL_STANDIN=1 is not: refusing to "
+                                          "run the gather over anything but librccl");
+    }
     void* h = (alt && *alt) ? dlopen(alt, RTLD_NOW | RTLD_GLOBAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h && !(alt && *alt)) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return set_error(LGMI_E_RCCL, dlerror());
@@ -63,6 +78,12 @@ int load_rccl() {
     SYM(AllGather, "ncclAllGather") SYM(Reduce, "ncclReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
     SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    *(void**)(&g.GetVersion) = dlsym(h, "ncclGetVersion");
+    *(void**)(&g.CommCount) = dlsym(h, "ncclCommCount");
+    *(void**)(&g.CommUserRank) = dlsym(h, "ncclCommUserRank");
+    g.stand_in = alt && *alt;
+    Dl_info di;
+    if (dladdr((void*)g.CommInitRank, &di) && di.dli_fname) snprintf(g.path, sizeof g.path, "%s", di.dli_fname);
     g.h = h;
     return LGMI_OK;
 }
@@ -114,10 +135,50 @@ extern "C" int lgmi_comm_init(lgmi_ctx* ctx, const void* id128, int rank, int wo
 
 extern "C" void lgmi_comm_destroy(lgmi_ctx* ctx) {
     if (!ctx || !*ctx_comm_slot(ctx)) return;
+    // every collective of this file runs on the communication stream: nothing may still be queued there (a _begin
+    // without its _finish, an error path) when the communicator goes
+    (void)hipStreamSynchronize(ctx_comm_stream(ctx));
     (void)hipStreamSynchronize(ctx_stream(ctx));
     if (g.CommDestroy) (void)g.CommDestroy((ncclComm_t)*ctx_comm_slot(ctx));
     *ctx_comm_slot(ctx) = nullptr;
 }
+
+// what a SCALE line needs to prove that RCCL saw N ranks: the library that was bound, its version, the communicator's
+// own idea of its size and of this rank, and whether it is the tests' stand-in
+extern "C" int lgmi_comm_info(lgmi_ctx* ctx, lgmi_comm_info_t* out) {
+    if (!ctx || !out) return set_error(LGMI_E_ARG, "NULL argument");
+    memset(out, 0, sizeof *out);
+    out->nranks = -1; out->rank = -1; out->rccl_version = -1;
+    if (!g.h) return set_error(LGMI_E_STATE, "no RCCL library is loaded (lgmi_comm_unique_id / lgmi_comm_init come first)");
+    out->stand_in = g.stand_in ? 1 : 0;
+    snprintf(out->lib_path, sizeof out->lib_path, "%s", g.path);
+    int v = -1;
+    if (g.GetVersion && g.GetVersion(&v) == ncclSuccess) out->rccl_version = v;
+    ncclComm_t comm = (ncclComm_t)*ctx_comm_slot(ctx);
+    out->initialised = comm ? 1 : 0;
+    if (comm) {
+        int n = -1, r = -1;
+        if (g.CommCount && g.CommCount(comm, &n) == ncclSuccess) out->nranks = n;
+        if (g.CommUserRank && g.CommUserRank(comm, &r) == ncclSuccess) out->rank = r;
+        out->world_given = *ctx_world_slot(ctx);
+        out->rank_given = *ctx_rank_slot(ctx);
+    }
+    return LGMI_OK;
+}
+
+namespace {
+// order the communication stream after everything queued so far on the main stream (the kernels that made the rows a
+// gather is about to send): an event, not a host-side wait in somebody else's function
+int comm_after_main(lgmi_ctx* ctx) {
+    hipStream_t ms = ctx_stream(ctx), cs = ctx_comm_stream(ctx);
+    if (ms == cs) return LGMI_OK;
+    hipEvent_t ev = ctx_comm_event(ctx);
+    if (!ev) return set_error(LGMI_E_HIP, "no event for the communication stream");
+    HIPCHK2(hipEventRecord(ev, ms));
+    HIPCHK2(hipStreamWaitEvent(cs, ev, 0));
+    return LGMI_OK;
+}
+}  // namespace
 
 extern "C" int lgmi_comm_allgather_u64v(lgmi_ctx* ctx, const uint64_t* mine, uint32_t n, uint64_t* out_world) {
     if (!ctx || !mine || !out_world || n == 0) return set_error(LGMI_E_ARG, "NULL argument");
@@ -213,7 +274,11 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
     if (opts) o = *opts;
     if (o.reserved[0] || o.reserved[1] || o.reserved[2] || o.same_batch > 1) return set_error(LGMI_E_ARG, "bad gather options");
     HIPCHK2(hipSetDevice(ctx_device(ctx)));
-    hipStream_t st = ctx_comm_stream(ctx);      // the rows of `mine` are final: its producer synchronised its stream
+    hipStream_t st = ctx_comm_stream(ctx);
+    {   // the rows of `mine` were made on the main stream: the communication stream waits for them on the device
+        const int rc0 = comm_after_main(ctx);
+        if (rc0) return rc0;
+    }
     DResultView v;
     dresult_view(mine, &v);
 
@@ -341,8 +406,12 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
     const int world = h->world, rank = h->rank, root = h->root;
     if (hipSetDevice(ctx_device(ctx)) != hipSuccess) return set_error(LGMI_E_HIP, "hipSetDevice");
     hipStream_t st = ctx_comm_stream(ctx);
+    {   // the permutation stage, if it ran in between, ran on the main stream: wait for it on the device
+        const int rc0 = comm_after_main(ctx);
+        if (rc0) return rc0;
+    }
     DResultView v;
-    dresult_view(h->mine, &v);      // (the permutation stage, if it ran in between, was synchronised by its caller)
+    dresult_view(h->mine, &v);
     if (rank_row_begin) {
         rank_row_begin[0] = 0;
         for (int r = 0; r < world; ++r) rank_row_begin[r + 1] = rank_row_begin[r] + h->M(r, M_ROWS);

@@ -626,7 +626,20 @@ static const uint32_t FIRST_MAX = LGMI_FIRST_MAX;
 #define LGMI_GUIDE_BITS 8
 #endif
 static const uint32_t GUIDE_SH = 32u - LGMI_GUIDE_BITS, GUIDE_N = 1u << LGMI_GUIDE_BITS;
-static const uint32_t XRING = 512;      // entries of the lock-step rows' ring of first draws (a power of two)
+static const uint32_t XRING = 512;
+// Lock-step rows: what the set-up of a second draw looks up depends on the first result x0 alone — the log-weight at the
+// mode (four LF) and the G of the two cells x0 fixes — and the first results of a row pile up around their mode.  The
+// window entries that expect to be drawn at least once in n_shuffles draws (mode +- sd sqrt(2 ln(n_shuffles / 2.5 sd)))
+// get the two sums once per row, 16 bytes each, in the part of the threshold table's LDS the row's window leaves free
+// (a 5 % third allele at 2e5 reads: ~600 of the 2032 words are thresholds, room for 350 entries); a shuffle whose x0 falls
+// there reads LDS instead of making six scattered look-ups.  Same values, same order of the additions: nothing changes
+// in the specification, and which entries are cached changes no result (so the range may come from approximate math).
+// Why: the kernel is bound by the L1's rate of scattered look-ups — 15 per table draw before this
+// (profiles/r03_pmc_perm_general.json); a fixed 256-entry cache of its own cost occupancy (11 workgroups per CU) and
+// still took north-star from 280 to 243 ms, cfg5 from 1786 to 1448 ms (profiles/r03_perm_general_cache.txt).
+#ifndef LGMI_LS_CACHE
+#define LGMI_LS_CACHE 1            // 0: no cache (timing comparisons)
+#endif      // entries of the lock-step rows' ring of first draws (a power of two)
 
 // rint(p * 2^52) for 0 <= p < 1 without a 64-bit conversion: adding 2^52 leaves the rounded value in the mantissa
 __device__ __forceinline__ unsigned long long to_fixed52(double p) {
@@ -645,7 +658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
     const TabG G{pa.G}; const TabLF LF{pa.LF};
     const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
     double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
-    __shared__ uint32_t tab_thr[FIRST_MAX];
+    __shared__ __attribute__((aligned(16))) uint32_t tab_thr[FIRST_MAX];   // thresholds [0, tab_n), then the lock-step rows' cache
     __shared__ uint16_t tab_guide[GUIDE_N + 1u];   // tab_guide[b] = the draw for u = b << GUIDE_SH: where the search for u >> GUIDE_SH == b starts
     __shared__ uint32_t next_s;
     __shared__ __attribute__((aligned(8))) uint16_t x_ring[XRING];   // lock-step rows: first draws waiting for a lane
@@ -694,7 +707,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
         // ---- per-row threshold table of the first draw (wave-uniform control flow; integer prefix sums, so the
         //      result does not depend on the order of the additions — see the CPU specification)
         bool tab_ok = false;
-        uint32_t tab_klo = 0, tab_n = 0;
+        uint32_t tab_klo = 0, tab_n = 0, tab_mode = 0;
+        float tab_sd = 1.0f;
         {
             const uint32_t pop = N, good = R0, sample = C0;
             const uint32_t m = sample < pop - sample ? sample : pop - sample;
@@ -715,6 +729,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 if (mode < kmin) mode = kmin;
                 if (mode > kmax) mode = kmax;
                 tab_klo = mode - kmin > w ? mode - w : kmin;
+                tab_mode = mode;
+                tab_sd = (float)sd;
                 const uint32_t khi = kmax - mode > w ? mode + w : kmax;
                 tab_n = khi - tab_klo + 1u;
                 tab_ok = tab_n <= FIRST_MAX;
@@ -848,11 +864,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
             uint32_t filled = 0u, next = 0u, total = 0u;             // wave-uniform
             uint32_t exceed = 0u;
             uint32_t m = 0u, mn = 0u, mxm = 0u;                     // mxm = mx - m
-            long long gxa = 0, gxb = 0;                              // G of the two cells that depend on x0 only
-            // d10 (the log-weight at the mode) is kept as its four table values and summed where it is used, in the
-            // order the specification adds them: the set-up's look-ups are then still in flight when the next
-            // candidate's look-ups are issued, and one wait covers both
-            double d6 = 0.0, d10a = 0.0, d10b = 0.0, d10c = 0.0, d10d = 0.0, d11 = 0.0;
+            long long gx = 0;                                        // G of the two cells that depend on x0 only
+            double d6 = 0.0, d10 = 0.0, d11 = 0.0;
             // 256 more first draws: lane l makes call filled / 4 + l and writes X[4 c .. 4 c + 3] as offsets into the
             // window (u16), one 8-byte store.  The ring holds X[next .. filled): at most 63 + 256 of its 512 entries
             auto first_draw = [&](uint32_t u) {
@@ -873,7 +886,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 __syncthreads();                         // (one wave per workgroup: orders the stores before the reads)
             };
             // HRUA set-up of the second draw for first result x0 (the expressions of the general path)
-            auto setup = [&](uint32_t e) {
+            // the window entries [c_lo, c_lo + c_n) around the first draw's mode have their look-ups in LDS, behind the thresholds
+            const uint32_t c_word0 = (tab_n + 3u) & ~3u;
+            uint32_t c_lo = 0u, c_n = 0u;
+            if (LGMI_LS_CACHE) {
+                const uint32_t room = (FIRST_MAX - c_word0) / 4u;
+                const float per_sd = (float)n_shuffles / (2.5f * tab_sd);
+                const uint32_t h = (uint32_t)(tab_sd * __fsqrt_rn(2.0f * __logf(per_sd > 1.0f ? per_sd : 1.0f))) + 1u;
+                const uint32_t me = tab_mode - tab_klo;
+                const uint32_t lo = me > h ? me - h : 0u, hi = me + h + 1u < tab_n ? me + h + 1u : tab_n;
+                c_n = hi - lo < room ? hi - lo : room;
+                c_lo = lo + (hi - lo - c_n) / 2u;
+            }
+            ulonglong2* const cache = reinterpret_cast<ulonglong2*>(tab_thr + c_word0);
+            auto setup = [&](uint32_t e, bool fill) {
                 const uint32_t x0 = tab_klo + e;
                 uint32_t good, sample;
                 if (nr == 3) { good = R1; sample = C0 - x0; }
@@ -883,13 +909,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 mn = good < bad ? good : bad;
                 mxm = (good < bad ? bad : good) - m;
                 d6 = (double)m * hb.d4 + 0.5;
-                const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
-                gxa = G.ls(x0); gxb = G.ls((nr == 3 ? R0 : C0) - x0);
-                d10d = LF.ls(mxm + d9); d10c = LF.ls(m - d9); d10b = LF.ls(mn - d9); d10a = LF.ls(d9);
                 const double cap = (double)((m < mn ? m : mn) + 1u);
                 const double lim = floor(d6 + lim16);
                 d11 = cap < lim ? cap : lim;
+                if (!fill && e - c_lo < c_n) {
+                    const ulonglong2 v = cache[e - c_lo];
+                    d10 = __longlong_as_double((long long)v.x);
+                    gx = (long long)v.y;
+                } else {
+                    const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
+                    const long long ga = G.ls(x0), gb = G.ls((nr == 3 ? R0 : C0) - x0);
+                    const double a3 = LF.ls(mxm + d9), a2 = LF.ls(m - d9), a1 = LF.ls(mn - d9), a0 = LF.ls(d9);
+                    d10 = a0 + a1 + a2 + a3;                     // the specification's order
+                    gx = ga + gb;
+                }
             };
+            for (uint32_t e = c_lo + lane; e < c_lo + c_n; e += 64u) {
+                setup(e, true);
+                ulonglong2 v; v.x = (unsigned long long)__double_as_longlong(d10); v.y = (unsigned long long)gx;
+                cache[e - c_lo] = v;
+            }
+            // (the barrier of the first refill() below orders these stores before any read)
             // one trip: candidate (wx, wy) of every lane; true when the row is finished (wave-uniform)
             auto trip = [&](uint32_t wx, uint32_t wy) {
                 if (filled - next < 64u) refill();
@@ -905,7 +945,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 if (!(w < 0.0 || w >= d11)) {
                     zc = (uint32_t)floor(w);
                     const double l3 = LF.ls(mxm + zc), l2 = LF.ls(m - zc), l1 = LF.ls(mn - zc), l0 = LF.ls(zc);
-                    const double tt = (d10a + d10b + d10c + d10d) - (l0 + l1 + l2 + l3);
+                    const double tt = d10 - (l0 + l1 + l2 + l3);
                     const double x = u * 2.3283064365386963e-10;
                     acc = le_exp(x * x, tt);                     // 2 ln x <= tt
 #if LGMI_PABL & (131072 | 2048)
@@ -915,10 +955,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 const unsigned long long bal = __ballot(acc);
                 if (acc) {
                     const long long g3 = G.ls(mxm + zc), g2 = G.ls(m - zc), g1 = G.ls(mn - zc), g0 = G.ls(zc);
-                    const long long gx = gxa + gxb;                  // (before the set-up below overwrites them)
+                    const long long gx_this = gx;                    // (before the set-up below overwrites it)
                     const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                    setup(x_ring[(next + rank) & (XRING - 1u)]);
-                    const long long ss = g3 + g2 + g1 + g0 + gx;     // integers: any order
+                    setup(x_ring[(next + rank) & (XRING - 1u)], false);
+                    const long long ss = g3 + g2 + g1 + g0 + gx_this;   // integers: any order
                     // tables are numbered in lane order; those beyond n_shuffles are surplus of the last trip
                     exceed += (uint32_t)((ss >= sobs) & (total + rank < n_shuffles));
                 }
@@ -928,7 +968,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 return total >= n_shuffles;
             };
             refill();
-            setup(x_ring[lane]);
+            setup(x_ring[lane], false);
             next = 64u;
             for (uint32_t c = 0u;; ++c) {                        // the row ends for all lanes together
                 const U4 o = philox4x32_10(c, ci, cj, TAG_LSC + lane, k0, k1);
@@ -1163,7 +1203,10 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
     // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
     // take the queued rows from a shared counter
     // (LGMI_PERM_WPC: one-wave workgroups per CU, for occupancy experiments — tools/abl_perm.sh; 16 = four per SIMD)
-    static const int wpc = [] { const char* e = getenv("LGMI_PERM_WPC"); const int v = e ? atoi(e) : 16; return v >= 1 && v <= 32 ? v : 16; }();
+    // as many as the LDS of a CU holds, 16 at most (12 or 8 run the loop as fast as 16: profiles/r03_perm_general_occupancy.txt)
+    const int fit = (int)((160u * 1024u) / (FIRST_MAX * 4u + (GUIDE_N + 1u) * 2u + XRING * 2u + 64u));
+    const int dflt = fit < 16 ? (fit < 1 ? 1 : fit) : 16;
+    static const int wpc = [dflt] { const char* e = getenv("LGMI_PERM_WPC"); const int v = e ? atoi(e) : dflt; return v >= 1 && v <= 32 ? v : dflt; }();
     hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, a);
 }
 

@@ -69,6 +69,11 @@ class GatherOpts(C.Structure):
     _fields_ = [('site_base', C.c_uint32), ('same_batch', C.c_uint8), ('reserved', C.c_uint8 * 3)]
 
 
+class CommInfo(C.Structure):     # include/lgmi.h: lgmi_comm_info_t
+    _fields_ = [('rccl_version', C.c_int32), ('nranks', C.c_int32), ('rank', C.c_int32), ('world_given', C.c_int32),
+                ('rank_given', C.c_int32), ('initialised', C.c_int32), ('stand_in', C.c_int32), ('lib_path', C.c_char * 512)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('n_sites', C.c_uint32), ('n_reads', C.c_uint32),
                 ('het_every', C.c_uint32), ('dropout_u16', C.c_uint32), ('het_noise_u16', C.c_uint32),
@@ -112,6 +117,7 @@ SYMBOLS = {
     'lgmi_selftest_le_exp': (C.c_int, [VP, C.c_uint64, f64p, f64p, u8p, u8p, f64p, f64p]),
     'lgmi_comm_unique_id': (C.c_int, [VP]),
     'lgmi_comm_init': (C.c_int, [VP, VP, C.c_int, C.c_int]),
+    'lgmi_comm_info': (C.c_int, [VP, C.POINTER(CommInfo)]),
     'lgmi_comm_allgather_u64': (C.c_int, [VP, C.c_uint64, u64p]),
     'lgmi_comm_allgather_u64v': (C.c_int, [VP, u64p, C.c_uint32, u64p]),
     'lgmi_comm_gather': (C.c_int, [VP, VP, C.c_int, C.POINTER(GatherOpts), C.POINTER(VP), u64p]),

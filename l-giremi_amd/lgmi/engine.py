@@ -318,15 +318,25 @@ class Engine:
         _lib.check(self.lib.lgmi_comm_init(self.handle, buf, int(rank), int(world)))
         self.rank, self.world = int(rank), int(world)
 
-    def comm_init_group(self, group):
-        """rank 0 creates the RCCL unique id; `group` (lgmi.dist.SocketGroup, or a torch.distributed-like module)
-        carries the 128 bytes"""
-        self.comm_init_torch(group, group.get_rank(), group.get_world_size())
-
-    def comm_init_torch(self, dist, rank: int, world: int):
-        """rank 0 creates the RCCL unique id; torch.distributed carries the 128 bytes"""
+    def comm_init_group(self, group, rank=None, world=None):
+        """rank 0 creates the RCCL unique id; `group` — lgmi.dist.SocketGroup, or any object with torch.distributed's
+        broadcast_object_list / get_rank / get_world_size (nothing here imports torch) — carries the 128 bytes"""
         from .dist import exchange_unique_id
-        self.comm_init(exchange_unique_id(dist, self.comm_unique_id if rank == 0 else None), rank, world)
+        rank = group.get_rank() if rank is None else int(rank)
+        world = group.get_world_size() if world is None else int(world)
+        self.comm_init(exchange_unique_id(group, self.comm_unique_id if rank == 0 else None), rank, world)
+
+    def comm_info(self) -> dict:
+        """what was bound and what the communicator says about itself (lgmi_comm_info): RCCL version, library path,
+        ncclCommCount / ncclCommUserRank, and whether it is the tests' stand-in"""
+        self._alive()
+        ci = _lib.CommInfo()
+        _lib.check(self.lib.lgmi_comm_info(self.handle, C.byref(ci)))
+        v = int(ci.rccl_version)
+        return {'rccl_version': v, 'rccl_version_str': ('%d.%d.%d' % (v // 10000, v // 100 % 100, v % 100)) if v >= 0 else None,
+                'lib_path': ci.lib_path.decode('utf-8', 'replace'), 'nranks': int(ci.nranks), 'rank': int(ci.rank),
+                'world_given': int(ci.world_given), 'rank_given': int(ci.rank_given),
+                'initialised': bool(ci.initialised), 'stand_in': bool(ci.stand_in)}
 
     def comm_allgather_u64(self, value: int):
         self._alive()

@@ -40,10 +40,9 @@ def mismatch_pair_mutual_info(mismatches: dict, min_common_reads=5, engine: Opti
     if batch.bad_sites.any():
         # the reference ranks the alleles of BOTH sites of every qualifying pair — het-involved or not — before the
         # het filter (mutual_information.py:25-32, mismatch.py:392-396): a site whose depth dict has < 2 alleles raises
-        # IndexError as soon as it is in any pair with enough common reads.  Such sites never reach this point in the
-        # pipeline (mismatch.py:275-282), so the extra all-pairs pass only runs for hand-made inputs.
-        chk = eng.run(batch, min_common=_min_common(min_common_reads), het_only=False)
-        if chk.n_rows and (batch.bad_sites[chk.row_i].any() or batch.bad_sites[chk.row_j].any()):
+        # IndexError as soon as it is in any pair with enough common reads.  `res` already is the all-pairs result
+        # (het_only=False), so it answers that directly.
+        if res.n_rows and (batch.bad_sites[res.row_i].any() or batch.bad_sites[res.row_j].any()):
             raise IndexError('list index out of range')   # fewer than two alleles in depth (:30,:32)
     pos, names = batch.site_pos, batch.type_names
     keys = sorted(mismatches.keys())                       # hand back the caller's own key objects

@@ -124,6 +124,11 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     return ncclSuccess;
 }
 
+// what lgmi_comm_info() asks (optional entry points of the real library)
+ncclResult_t ncclGetVersion(int* v) { *v = 0; return ncclSuccess; }                       // 0.0.0: not a release of RCCL
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* n) { *n = reinterpret_cast<Comm*>(comm)->world; return ncclSuccess; }
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* r) { *r = reinterpret_cast<Comm*>(comm)->rank; return ncclSuccess; }
+
 ncclResult_t ncclGroupStart() { ++g_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { return (--g_depth == 0) ? flush() : ncclSuccess; }
 

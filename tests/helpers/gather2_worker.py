@@ -30,6 +30,9 @@ def main():
     eng = lgmi.Engine(0)
     eng.comm_init_group(group)
     assert eng.world == world
+    ci = eng.comm_info()      # the communicator's own account of itself; the stand-in is reported as one
+    assert ci['stand_in'] and ci['initialised'] and ci['nranks'] == world and ci['rank'] == rank, ci
+    assert ci['world_given'] == world and ci['rank_given'] == rank and 'fake' in ci['lib_path'], ci
     checked = []
 
     # ---- (1) strong scaling: every rank holds the SAME dense block (tri-allelic sites, matrix-core tiles), runs its
@@ -135,7 +138,7 @@ def main():
     group.barrier()
     eng.close()
     if rank == 0:
-        print(json.dumps({'ok': True, 'world': world, 'checked': checked}))
+        print(json.dumps({'ok': True, 'world': world, 'checked': checked, 'comm_info': ci}))
 
 
 if __name__ == '__main__':

@@ -177,3 +177,73 @@ def test_shard_by_cost_edge_cases():
     s = shard_by_cost([1, 1, 1, 1, 1, 1, 1, 1], 8)
     assert sorted(x for q in s for x in q) == list(range(8)) and all(len(q) == 1 for q in s)
     assert shard_by_cost([3, 3, 2, 2, 2], 2) == [[0, 3], [1, 2, 4]] or True
+
+
+def test_frames_are_json_not_pickle():
+    from lgmi import dist as D
+    obj = {'a': [1, 2.5, None, True, 'x'], 'b': b'\x00\x01\xff', 't': (1, (2, 3)),
+           'nd': np.arange(6, dtype=np.uint32).reshape(2, 3), 'f': np.float64(1.5), 'i': np.int64(7)}
+    back = D.loads(D.dumps(obj))
+    assert back['a'] == obj['a'] and back['b'] == obj['b'] and back['t'] == (1, (2, 3)) and back['f'] == 1.5 and back['i'] == 7
+    assert back['nd'].dtype == np.uint32 and (back['nd'] == obj['nd']).all()
+    assert b'pickle' not in D.dumps(obj) and D.dumps(obj)[:1] == b'{'
+    for bad in (object(), {1: 2}, {'__b': 1}, np.array([object()], dtype=object), {3.5}):
+        with pytest.raises(TypeError):
+            D.dumps(bad)
+    import inspect
+    assert 'pickle.loads' not in inspect.getsource(D.SocketGroup)
+
+
+def _strict_worker(rank, world, port, q):
+    from lgmi.dist import SocketGroup
+    g = SocketGroup(rank, world, '127.0.0.1', port, timeout=60.0, token='secret-of-this-test')
+    q.put({'rank': rank, 'all': g.allgather(rank * 3)})
+    g.barrier()
+    g.close()
+
+
+def test_rendezvous_drops_strangers_and_duplicate_ranks():
+    """rank 0 keeps only connections that present the group's token with a rank in 1 .. world-1 not seen before; a
+    connection that closes mid-hello, a wrong token, rank 0 / rank >= world and a second rank 1 leave the group intact"""
+    import hashlib
+    import socket
+    import time
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    p0 = ctx.Process(target=_strict_worker, args=(0, world, port, q))
+    p0.start()
+    tok = hashlib.sha256(b'secret-of-this-test').hexdigest()[:32].encode('ascii')
+
+    def poke(payload, expect_ok):
+        deadline = time.time() + 30
+        while True:
+            try:
+                s = socket.create_connection(('127.0.0.1', port), timeout=2.0)
+                break
+            except OSError:
+                assert time.time() < deadline
+                time.sleep(0.05)
+        s.settimeout(5.0)
+        s.sendall(payload)
+        if expect_ok is None:
+            s.close()
+            return None
+        try:
+            got = s.recv(2)
+        except OSError:
+            got = b''
+        assert (got == b'ok') == expect_ok, (payload, got)
+        return s
+    poke(b'\x01\x00', None)                                          # closes in the middle of the hello
+    poke((1).to_bytes(4, 'little') + b'0' * 32, False)               # wrong token
+    poke((0).to_bytes(4, 'little') + tok, False)                     # rank 0 is the listener itself
+    poke((7).to_bytes(4, 'little') + tok, False)                     # rank >= world
+    p1 = ctx.Process(target=_strict_worker, args=(1, world, port, q))
+    p1.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda o: o['rank'])
+    for p in (p0, p1):
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(o['all'] == [0, 3] for o in outs)

@@ -37,7 +37,7 @@ def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-                   LGMI_RDZV_PORT=str(port), LGMI_RCCL_LIB=fake_rccl)
+                   LGMI_RDZV_PORT=str(port), LGMI_RCCL_LIB=fake_rccl, LGMI_ALLOW_RCCL_STANDIN='1')
         env.pop('TORCHELASTIC_USE_AGENT_STORE', None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'helpers', 'gather2_worker.py')], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -59,3 +59,19 @@ def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (rank, se[-3000:])
     line = json.loads(outs[0][0].strip().splitlines()[-1])
     assert line['ok'] and line['world'] == world and len(line['checked']) == 5
+    assert line['comm_info']['stand_in'] is True and line['comm_info']['nranks'] == world
+
+
+def test_stand_in_is_refused_without_the_explicit_switch(fake_rccl):
+    """LGMI_RCCL_LIB alone (a stale environment variable) must not put the product's gather on a stand-in"""
+    code = ("import sys; sys.path.insert(0, %r); import lgmi\n"
+            "e = lgmi.Engine(0)\n"
+            "try:\n"
+            "    e.comm_unique_id(); print('ACCEPTED')\n"
+            "except lgmi._lib.LgmiError as x:\n"
+            "    print('REFUSED' if 'LGMI_ALLOW_RCCL_STANDIN' in str(x) else 'OTHER: %%s' %% x)\n"
+            % os.path.join(os.path.dirname(HERE), 'l-giremi_amd'))
+    env = dict(os.environ, LGMI_RCCL_LIB=fake_rccl)
+    env.pop('LGMI_ALLOW_RCCL_STANDIN', None)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip().splitlines()[-1] == 'REFUSED', (r.stdout, r.stderr[-2000:])
