@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LGMI_ABI_VERSION 3
+#define LGMI_ABI_VERSION 4
 
 /* error codes */
 #define LGMI_OK        0
@@ -107,7 +107,11 @@ typedef struct lgmi_params {
                               summed from log-factorials) instead of a Monte-Carlo estimate; their
                               row_exceed is LGMI_EXCEED_EXACT.  Larger tables keep the n_shuffles
                               estimate (row_p NaN, row_exceed LGMI_EXCEED_EXACT when n_shuffles == 0) */
-    uint8_t  reserved0;    /* must be 0 */
+    uint8_t  no_row_p;     /* 1: when every row_p is a function of its row_exceed — Monte-Carlo estimates,
+                              p = (1 + row_exceed) / (n_shuffles + 1), i.e. n_shuffles > 0 without exact_2x2 — the
+                              p array is not made at all: lgmi_result.row_p is NULL, row_p_derived is 1 and the
+                              caller derives what it needs (8 of 28 bytes per row less on the way to the host, no
+                              8-byte store per row in the permutation kernels).  0: row_p is always an array */
     /* tile-level sharding of ONE batch over several GPUs (the reference's analogue is the chunked
      * Pool.map of script/giremi.py:367-394): the result rows, in reference order, are cut into shard_world
      * contiguous, cost-balanced ranges (cost model: csrc/plan.cpp); this call computes range shard_rank only (count tiles that feed it,
@@ -132,12 +136,15 @@ typedef struct lgmi_result {
     const uint32_t* row_i;
     const uint32_t* row_j;
     const double*   row_mi;
-    const double*   row_p;        /* NULL when n_shuffles == 0 */
+    const double*   row_p;        /* NULL when n_shuffles == 0 (and no exact_2x2), or when row_p_derived */
     const uint32_t* row_exceed;   /* NULL when n_shuffles == 0 */
     const uint32_t* row_counts;   /* NULL unless emit_counts   */
     const double*   site_mean_mi; /* [n_sites] */
     const uint32_t* site_n_pairs; /* [n_sites] */
     void* owner_;                 /* private */
+    uint32_t n_shuffles;          /* of the run that made the rows */
+    uint32_t row_p_derived;       /* 1: row_p is NULL because lgmi_params.no_row_p asked for that:
+                                     p[r] = (1 + row_exceed[r]) / (n_shuffles + 1) */
 } lgmi_result;
 
 /* figures of one run: work done and HIP-event time of each stage (ms), taken
@@ -165,7 +172,10 @@ typedef struct lgmi_run_info {
     float ms_plan_host;        /* host wall time of the per-run planning (tile list, work items), ms       */
     float ms_perm_fast;        /* k_perm_fast: classification + exact 2 x 2 tails + binomial draws         */
     float ms_perm_general;     /* k_perm_general: Monte-Carlo table draws of the larger tables             */
-    uint32_t reserved2;
+    uint32_t n_seq_shards;     /* > 1: lgmi_run_device ran the batch as that many sequential shards because one
+                                  launch sequence would not fit the memory budget (LGMI_MEM_BUDGET_MB, default 70 % of
+                                  the device memory) or p-values were asked for 2^32 candidate rows or more; the
+                                  stage times are sums over the shards.  0 / 1: one sequence                  */
 } lgmi_run_info;
 
 /* device-side synthetic chromosome generator (SURVEY 8d "dense" regime):

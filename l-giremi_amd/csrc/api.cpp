@@ -191,6 +191,7 @@ struct lgmi_dresult {
     uint32_t* d_i = nullptr; uint32_t* d_j = nullptr;
     double* d_mi = nullptr; double* d_p = nullptr;
     uint32_t* d_exceed = nullptr; uint32_t* d_counts = nullptr;
+    uint4* d_rec = nullptr;                // per row what the permutation stage needs (EmitArgs::out_rec); gone once it has run
     double* d_mean = nullptr; uint32_t* d_npairs = nullptr;
     unsigned long long* d_sum = nullptr;   // per-site sum of MI in 2^-40 fixed point (what d_mean was made from)
     bool has_p = false, has_counts = false;
@@ -293,7 +294,7 @@ Pool& ctx_pool(lgmi_ctx* c) { return c->pool; }
 void dresult_view(const lgmi_dresult* r, DResultView* v) {
     v->n_rows = r->n_rows; v->n_sites = r->n_sites;
     v->i = r->d_i; v->j = r->d_j; v->mi = r->d_mi;
-    v->p = r->has_p ? r->d_p : nullptr; v->exceed = r->has_p ? r->d_exceed : nullptr;
+    v->p = r->has_p ? r->d_p : nullptr; v->exceed = r->has_p ? r->d_exceed : nullptr;     // (p may be NULL: no_row_p)
     v->counts = r->has_counts ? r->d_counts : nullptr;
     v->mean = r->d_mean; v->npairs = r->d_npairs; v->sum = r->d_sum;
     v->n_shuffles = r->n_shuffles; v->p_from_exceed = r->p_from_exceed;
@@ -308,7 +309,7 @@ lgmi_dresult* dresult_new_gathered(lgmi_ctx* c, const DResultView& v) {
     r->d_counts = const_cast<uint32_t*>(v.counts);
     r->d_mean = const_cast<double*>(v.mean); r->d_npairs = const_cast<uint32_t*>(v.npairs);
     r->d_sum = const_cast<unsigned long long*>(v.sum);
-    r->has_p = v.p != nullptr; r->has_counts = v.counts != nullptr;
+    r->has_p = v.exceed != nullptr; r->has_counts = v.counts != nullptr;
     r->n_shuffles = v.n_shuffles; r->p_from_exceed = v.p_from_exceed;
     r->info = v.info;
     return r;
@@ -686,7 +687,7 @@ extern "C" void lgmi_dresult_free(lgmi_dresult* r) {
     if (!r) return;
     Pool& p = r->ctx->pool;
     p.release(r->d_i); p.release(r->d_j); p.release(r->d_mi); p.release(r->d_p);
-    p.release(r->d_exceed); p.release(r->d_counts); p.release(r->d_mean); p.release(r->d_npairs);
+    p.release(r->d_exceed); p.release(r->d_counts); p.release(r->d_rec); p.release(r->d_mean); p.release(r->d_npairs);
     p.release(r->d_sum); p.release(r->d_nrows);
     delete r;
 }
@@ -696,7 +697,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     *out = nullptr;
     HostTrace tr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
-    if (prm->reserved0) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
+    if (prm->no_row_p > 1) return fail(LGMI_E_ARG, "lgmi_params.no_row_p must be 0 or 1");
     if (prm->exact_2x2 > 1) return fail(LGMI_E_ARG, "exact_2x2 must be 0 or 1");
     if (prm->n_shuffles > (1u << 24)) return fail(LGMI_E_ARG, "n_shuffles must be <= 2^24");
     uint32_t sh_world = prm->shard_world, sh_rank = prm->shard_rank;
@@ -741,6 +742,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     res->sharded = sh_world > 1;
     res->n_shuffles = prm->n_shuffles;
     res->p_from_exceed = prm->n_shuffles > 0 && !prm->exact_2x2;
+    const bool keep_p = want_p && !(res->p_from_exceed && prm->no_row_p);   // row_p as an array of its own
     // scratch (returned to the pool at the end of the call) and the result
     std::vector<void*> scratch;
     struct Guard {
@@ -845,7 +847,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     // Row arrays: the number of rows is only known on the device here.  When the upper bound (every examined pair
     // is emitted — what a dense block does) fits a third of the device memory the arrays are sized by it and the
     // stream runs on without the host; otherwise one 8-byte read-back sizes them exactly.
-    const size_t row_bytes = 16 + ((want_counts || want_p) ? 36 : 0) + (want_p ? 16 : 0);
+    const size_t row_bytes = 16 + ((want_counts || want_p) ? 36 : 0) + (want_p ? 20 : 0) + (keep_p ? 8 : 0);
     uint64_t cap_rows = pl.n_examined;
     const bool by_bound = (double)cap_rows * (double)row_bytes <= (double)ctx->mem_total / 3.0 && !getenv("LGMI_EXACT_ROW_ALLOC");
     uint64_t n_rows = 0;
@@ -860,10 +862,12 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if ((rc = pool.alloc((void**)&res->d_mi, nr * 8))) return rc;
     if (want_counts || want_p) if ((rc = pool.alloc((void**)&res->d_counts, nr * 36))) return rc;
     if (want_p) {
-        if ((rc = pool.alloc((void**)&res->d_p, nr * 8))) return rc;
+        if (keep_p && (rc = pool.alloc((void**)&res->d_p, nr * 8))) return rc;
         if ((rc = pool.alloc((void**)&res->d_exceed, nr * 4))) return rc;
+        if ((rc = pool.alloc((void**)&res->d_rec, nr * 16))) return rc;
     }
     ea.out_i = res->d_i; ea.out_j = res->d_j; ea.out_mi = res->d_mi; ea.out_counts = res->d_counts;
+    ea.out_rec = res->d_rec; ea.counts_sparse = (want_p && !want_counts) ? 1 : 0;
     launch_emit_write(st, ea);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -880,7 +884,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         if ((rc = salloc((void**)&d_genlist, (size_t)cap_rows * 4))) return rc;
         PermArgs pa{};
         pa.n_rows_dev = d_rowstart + n_items; pa.max_rows = cap_rows;
-        pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
+        pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.rec = res->d_rec; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
         pa.n_shuffles = prm->n_shuffles; pa.seed = prm->seed; pa.exact_2x2 = prm->exact_2x2;
         pa.out_p = res->d_p; pa.out_exceed = res->d_exceed; pa.gen_list = d_genlist; pa.gen_count = d_gencount;
         launch_perm_fast(st, pa);
@@ -919,11 +923,11 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     inf.n_tile_pairs = (uint64_t)pl.tiles.size() * TILE * TILE + (uint64_t)pl.mtiles.size() * 128 * 128;
     inf.word_pairs = wp;
     inf.bytes_in = pl.bytes_in;
-    inf.bytes_out = n_rows * (16ull + (want_p ? 12ull : 0ull) + (want_counts ? 36ull : 0ull));
+    inf.bytes_out = n_rows * (16ull + (want_p ? 4ull : 0ull) + (keep_p ? 8ull : 0ull) + (want_counts ? 36ull : 0ull));
     inf.n_count_launches = (pl.tiles.empty() ? 0 : 1) + (pl.mtiles.empty() ? 0 : 1);
     inf.n_mfma_tiles = (uint32_t)std::min<size_t>(pl.mtiles.size(), 0xFFFFFFFFu);
     inf.mfma_dtype = pl.mtiles.empty() ? 0u : (pl.mfma_fp4 ? 2u : 1u);
-    inf.reserved = 0; inf.reserved2 = 0;
+    inf.reserved = 0; inf.n_seq_shards = 1;
     inf.ms_plan_host = ms_plan_host;
     HIPCHK(hipEventElapsedTime(&inf.ms_prep, ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&inf.ms_count, ctx->ev[1], ctx->ev[2]));
@@ -934,12 +938,134 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HIPCHK(hipEventElapsedTime(&inf.ms_mean, ctx->ev[4], ctx->ev[5]));
     HIPCHK(hipEventElapsedTime(&inf.ms_total, ctx->ev[0], ctx->ev[5]));
     if (!want_counts && res->d_counts && !res->perm_pending) { pool.release(res->d_counts); res->d_counts = nullptr; }
+    if (res->d_rec && !res->perm_pending) { pool.release(res->d_rec); res->d_rec = nullptr; }
+    guard.r = nullptr;
+    *out = res;
+    return LGMI_OK;
+}
+
+// ---- one GPU, one call, more work than one launch sequence can hold: the run is cut into sequential shards with the
+// planner the multi-GPU path uses (csrc/plan.cpp: any contiguous range of the ordered work items is a shard whose rows
+// are that range of the unsharded rows, and the per-site sums are integers).  Each shard's slots, operands and
+// bound-sized row arrays live only while it runs; its rows are appended to the final arrays, which hold what the
+// caller asked for and nothing else.  When: the working set of the single sequence — slot matrix + operands + row arrays
+// sized by the examined-pair bound — exceeds the budget (LGMI_MEM_BUDGET_MB, default 70 % of the device memory), or
+// p-values are wanted for 2^32 candidate rows or more (the permutation kernels carry row numbers in 32 bits).
+// The reference's analogue: the chunked Pool.map over footprints (src/giremi/script/giremi.py:367-394).
+static size_t row_bytes_working(bool want_p, bool keep_p, bool want_counts) {
+    return 16 + ((want_counts || want_p) ? 36 : 0) + (want_p ? 20 : 0) + (keep_p ? 8 : 0);
+}
+static size_t row_bytes_final(bool want_p, bool keep_p, bool want_counts) {
+    return 16 + (want_p ? 4 : 0) + (keep_p ? 8 : 0) + (want_counts ? 36 : 0);
+}
+
+static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, const Plan& pl) {
+    const bool want_p = prm->n_shuffles > 0 || prm->exact_2x2;
+    const bool keep_p = want_p && !(prm->n_shuffles > 0 && !prm->exact_2x2 && prm->no_row_p);
+    const bool want_counts = prm->emit_counts != 0;
+    double budget = 0.70 * (double)ctx->mem_total;
+    if (const char* e = getenv("LGMI_MEM_BUDGET_MB")) { const double v = atof(e); if (v > 0.0) budget = v * 1048576.0; }
+    const double fixed = (double)pl.total_slots * 16.0 + (double)pl.op_total * 16.0;       // what every shard allocates in full
+    const double rows_work = (double)pl.n_examined * (double)row_bytes_working(want_p, keep_p, want_counts);
+    const double rows_final = (double)pl.n_examined * (double)row_bytes_final(want_p, keep_p, want_counts);
+    int k = 1;
+    if (fixed + rows_work > budget) {
+        const double room = budget - fixed - rows_final;
+        // shards are balanced by cost, not by row count: leave a third of slack on the estimate
+        k = room > 0.0 ? (int)std::ceil(1.35 * rows_work / room) : 64;
+    }
+    if (want_p && pl.n_examined >= 0xFFFFFFFFull)
+        k = std::max<int>(k, (int)(pl.n_examined / 0xC0000000ull) + 1);
+    (void)db;
+    return std::min(std::max(k, 1), 1024);
+}
+
+static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, int k, uint64_t bound_rows,
+                            lgmi_dresult** out) {
+    const bool want_p = prm->n_shuffles > 0 || prm->exact_2x2;
+    const bool p_from_exceed = prm->n_shuffles > 0 && !prm->exact_2x2;
+    const bool keep_p = want_p && !(p_from_exceed && prm->no_row_p);
+    const bool want_counts = prm->emit_counts != 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    Pool& pool = ctx->pool;
+    const uint32_t ns = (uint32_t)db->d.n_sites;
+    lgmi_dresult* res = new lgmi_dresult();
+    res->ctx = ctx; res->n_sites = ns; res->has_p = want_p; res->has_counts = want_counts;
+    res->n_shuffles = prm->n_shuffles; res->p_from_exceed = p_from_exceed;
+    struct Guard { lgmi_dresult* r; ~Guard() { if (r) lgmi_dresult_free(r); } } guard{res};
+    int rc;
+    const size_t nr = (size_t)std::max<uint64_t>(bound_rows, 1);
+    if ((rc = pool.alloc((void**)&res->d_i, nr * 4))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_j, nr * 4))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_mi, nr * 8))) return rc;
+    if (want_counts && (rc = pool.alloc((void**)&res->d_counts, nr * 36))) return rc;
+    if (want_p && (rc = pool.alloc((void**)&res->d_exceed, nr * 4))) return rc;
+    if (keep_p && (rc = pool.alloc((void**)&res->d_p, nr * 8))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_npairs, std::max<size_t>(ns, 1) * 4))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_mean, std::max<size_t>(ns, 1) * 8))) return rc;
+    if (ns) {
+        HIPCHK(hipMemsetAsync(res->d_sum, 0, (size_t)ns * 8, st));
+        HIPCHK(hipMemsetAsync(res->d_npairs, 0, (size_t)ns * 4, st));
+    }
+    lgmi_run_info tot = {};
+    uint64_t off = 0;
+    for (int s = 0; s < k; ++s) {
+        lgmi_params ps = *prm;
+        ps.shard_rank = (uint16_t)s; ps.shard_world = (uint16_t)k;
+        lgmi_dresult* part = nullptr;
+        if ((rc = run_device_impl(ctx, db, &ps, &part, false))) return rc;
+        struct PartGuard { lgmi_dresult* p; ~PartGuard() { lgmi_dresult_free(p); } } pg{part};
+        const uint64_t n = part->n_rows;
+        if (off + n > bound_rows) return fail(LGMI_E_STATE, "internal: the shards' rows exceed the planned bound");
+        auto d2d = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+            return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) : hipSuccess;
+        };
+        HIPCHK(d2d(res->d_i + off, part->d_i, n * 4));
+        HIPCHK(d2d(res->d_j + off, part->d_j, n * 4));
+        HIPCHK(d2d(res->d_mi + off, part->d_mi, n * 8));
+        if (want_counts) HIPCHK(d2d(res->d_counts + 9 * off, part->d_counts, n * 36));
+        if (want_p) HIPCHK(d2d(res->d_exceed + off, part->d_exceed, n * 4));
+        if (keep_p) HIPCHK(d2d(res->d_p + off, part->d_p, n * 8));
+        launch_sites_add(st, ns, res->d_sum, part->d_sum, res->d_npairs, part->d_npairs);
+        HIPCHK(hipGetLastError());
+        HIPCHK(wait_stream(st));                       // the part's arrays go back to the pool next
+        const lgmi_run_info& pi = part->info;
+        if (s == 0) tot = pi;
+        else {
+            tot.n_rows += pi.n_rows; tot.n_examined += pi.n_examined; tot.n_tile_pairs += pi.n_tile_pairs;
+            tot.word_pairs += pi.word_pairs; tot.bytes_out += pi.bytes_out; tot.n_general_rows += pi.n_general_rows;
+            tot.ms_total += pi.ms_total; tot.ms_prep += pi.ms_prep; tot.ms_count += pi.ms_count; tot.ms_emit += pi.ms_emit;
+            tot.ms_perm += pi.ms_perm; tot.ms_mean += pi.ms_mean; tot.ms_plan_host += pi.ms_plan_host;
+            tot.ms_perm_fast += pi.ms_perm_fast; tot.ms_perm_general += pi.ms_perm_general;
+            tot.n_count_launches += pi.n_count_launches;
+            tot.n_mfma_tiles = (uint32_t)std::min<uint64_t>((uint64_t)tot.n_mfma_tiles + pi.n_mfma_tiles, 0xFFFFFFFFull);
+        }
+        off += n;
+    }
+    launch_site_mean(st, ns, res->d_sum, res->d_npairs, res->d_mean);
+    HIPCHK(hipGetLastError());
+    HIPCHK(wait_stream(st));
+    res->n_rows = off;
+    tot.n_rows = off;
+    tot.n_examined = tot.n_examined_total;             // the whole batch was run
+    tot.n_seq_shards = (uint32_t)k;
+    res->info = tot;
     guard.r = nullptr;
     *out = res;
     return LGMI_OK;
 }
 
 extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out) {
+    if (ctx && db && prm && out && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
+        Plan pl;
+        int ck; uint32_t xg;
+        plan_env(&ck, &xg);
+        build_plan(plan_input(db), prm->het_only != 0, 0, 1, ck, xg, prm->n_shuffles, pl);
+        const int k = split_count(ctx, db, prm, pl);
+        if (k > 1) return run_device_split(ctx, db, prm, k, pl.n_examined, out);
+    }
     return run_device_impl(ctx, db, prm, out, false);
 }
 
@@ -967,7 +1093,7 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
         HIPCHK(hipMemsetAsync(d_gencount, 0, 8, st));
         PermArgs pa{};
         pa.n_rows_dev = res->d_nrows; pa.max_rows = res->cap_rows;
-        pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
+        pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.rec = res->d_rec; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
         pa.n_shuffles = res->prm.n_shuffles; pa.seed = res->prm.seed; pa.exact_2x2 = res->prm.exact_2x2;
         pa.out_p = res->d_p; pa.out_exceed = res->d_exceed; pa.gen_list = d_genlist; pa.gen_count = d_gencount;
         launch_perm_fast(st, pa);
@@ -989,6 +1115,7 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
     inf.ms_total += inf.ms_perm;
     res->perm_pending = false;
     if (!res->has_counts && res->d_counts) { pool.release(res->d_counts); res->d_counts = nullptr; }
+    if (res->d_rec) { pool.release(res->d_rec); res->d_rec = nullptr; }
     return LGMI_OK;
 }
 
@@ -1003,7 +1130,8 @@ extern "C" int lgmi_dresult_device_ptrs(const lgmi_dresult* r, lgmi_result* v) {
     memset(v, 0, sizeof *v);
     v->n_rows = r->n_rows; v->n_sites = r->n_sites;
     v->row_i = r->d_i; v->row_j = r->d_j; v->row_mi = r->d_mi;
-    v->row_p = r->has_p ? r->d_p : nullptr;
+    v->row_p = r->has_p ? r->d_p : nullptr;          /* NULL when lgmi_params.no_row_p dropped it */
+    v->n_shuffles = r->n_shuffles; v->row_p_derived = (r->has_p && !r->d_p) ? 1u : 0u;
     v->row_exceed = r->has_p ? r->d_exceed : nullptr;
     v->row_counts = r->has_counts ? r->d_counts : nullptr;
     v->site_mean_mi = r->d_mean; v->site_n_pairs = r->d_npairs;
@@ -1038,11 +1166,14 @@ static int fetch_part(lgmi_dresult* r, HostResult* h, lgmi_result* out, hipStrea
         out->row_i = hi; out->row_j = hj; out->row_mi = hmi; out->row_counts = hc;
         out->site_mean_mi = hmean; out->site_n_pairs = hnp;
     } else if (r->has_p) {
-        double* hp = h->take<double>(n); uint32_t* hex = h->take<uint32_t>(n);
-        if (!hp || !hex) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
-        HIPCHK(d2h(hp, r->d_p, n * 8));
+        // row_p travels only when it exists as an array (lgmi_params.no_row_p: it is (1 + exceed) / (n_shuffles + 1),
+        // 8 of the 28 bytes a row used to cost on the way to the host)
+        double* hp = r->d_p ? h->take<double>(n) : nullptr; uint32_t* hex = h->take<uint32_t>(n);
+        if ((r->d_p && !hp) || !hex) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
+        if (r->d_p) HIPCHK(d2h(hp, r->d_p, n * 8));
         HIPCHK(d2h(hex, r->d_exceed, n * 4));
         out->row_p = hp; out->row_exceed = hex;
+        out->n_shuffles = r->n_shuffles; out->row_p_derived = r->d_p ? 0u : 1u;
     }
     return LGMI_OK;
 }
@@ -1075,7 +1206,17 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
     int rc = lgmi_batch_upload(ctx, batch, &db);
     if (rc) return rc;
     lgmi_dresult* dr = nullptr;
-    rc = run_device_impl(ctx, db, prm, &dr, true);
+    bool split = false;
+    if (prm && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
+        // more than one launch sequence holds: sequential shards (lgmi_run_device), no overlap of fetch and permutation
+        Plan pl;
+        int ck; uint32_t xg;
+        plan_env(&ck, &xg);
+        build_plan(plan_input(db), prm->het_only != 0, 0, 1, ck, xg, prm->n_shuffles, pl);
+        const int k = split_count(ctx, db, prm, pl);
+        if (k > 1) { split = true; rc = run_device_split(ctx, db, prm, k, pl.n_examined, &dr); }
+    }
+    if (!split) rc = run_device_impl(ctx, db, prm, &dr, true);
     if (!rc) {
         HostResult* h = new HostResult();
         h->pool = ctx->pinned;

@@ -249,7 +249,7 @@ struct lgmi_gather {
     int root = 0, world = 1, rank = 0;
     std::vector<uint64_t> meta;
     uint64_t total = 0, total_sites = 0, examined = 0;
-    bool has_p = false, has_counts = false, same_batch = false, derive_p = false;
+    bool has_p = false, has_counts = false, same_batch = false, derive_p = false, no_p_array = false;
     uint32_t n_shuffles = 0;
     uint32_t *gi = nullptr, *gj = nullptr, *gexc = nullptr, *gcnt = nullptr, *gnp = nullptr;
     double *gmi = nullptr, *gp = nullptr, *gmean = nullptr;
@@ -285,7 +285,8 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
     // ---- 1. everybody learns everybody's sizes and flags
     uint64_t my_meta[M_N];
     my_meta[M_ROWS] = v.n_rows;
-    my_meta[M_FLAGS] = (v.p ? 1u : 0u) | (v.counts ? 2u : 0u) | (o.same_batch ? 4u : 0u) | (v.p && v.p_from_exceed ? 8u : 0u);
+    my_meta[M_FLAGS] = (v.exceed ? 1u : 0u) | (v.counts ? 2u : 0u) | (o.same_batch ? 4u : 0u) | (v.exceed && v.p_from_exceed ? 8u : 0u) |
+                       (v.exceed && !v.p ? 16u : 0u);          // 16: no p array at all (lgmi_params.no_row_p)
     my_meta[M_BASE] = o.site_base;
     my_meta[M_SITES] = v.n_sites;
     my_meta[M_EXAMINED] = v.info.n_examined;
@@ -312,6 +313,7 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
                                      "with different site counts or a non-zero site_base)");
     h->has_p = h->M(0, M_FLAGS) & 1u; h->has_counts = h->M(0, M_FLAGS) & 2u; h->same_batch = h->M(0, M_FLAGS) & 4u;
     h->derive_p = h->M(0, M_FLAGS) & 8u;               // p travels as its exceed count
+    h->no_p_array = h->M(0, M_FLAGS) & 16u;            // and is not materialised on the root either
     h->n_shuffles = (uint32_t)h->M(0, M_SHUFFLES);
     const uint64_t total = h->total, total_sites = h->total_sites;
 
@@ -322,7 +324,7 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
         int e = pool_alloc(ctx, (void**)&h->gi, tn * 4);
         if (!e) e = pool_alloc(ctx, (void**)&h->gj, tn * 4);
         if (!e) e = pool_alloc(ctx, (void**)&h->gmi, tn * 8);
-        if (!e && h->has_p) e = pool_alloc(ctx, (void**)&h->gp, tn * 8);
+        if (!e && h->has_p && !h->no_p_array) e = pool_alloc(ctx, (void**)&h->gp, tn * 8);
         if (!e && h->has_p) e = pool_alloc(ctx, (void**)&h->gexc, tn * 4);
         if (!e && h->has_counts) e = pool_alloc(ctx, (void**)&h->gcnt, tn * 36);
         if (!e) e = pool_alloc(ctx, (void**)&h->gmean, tsn * 8);
@@ -480,7 +482,7 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
     };
     if (h->has_p) { if (!h->derive_p) d2d(h->gp + off, v.p, n * 8); d2d(h->gexc + off, v.exceed, n * 4); }
-    if (h->has_p && h->derive_p && total)                  // every row, the root's own included
+    if (h->has_p && h->derive_p && !h->no_p_array && total)   // every row, the root's own included
         hipLaunchKernelGGL(k_p_from_exceed, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, h->gp, h->gexc, total, h->n_shuffles);
     if (h->same_batch && v.n_sites)
         hipLaunchKernelGGL(k_mean_from_sums, dim3((uint32_t)((v.n_sites + 255) / 256)), dim3(256), 0, st,

@@ -133,6 +133,12 @@ struct EmitArgs {
     uint32_t* row_cnt;        // [n_items]   pass 1 out
     const uint64_t* row_start;// [n_items+1] pass 2 in
     uint32_t* out_i; uint32_t* out_j; double* out_mi; uint32_t* out_counts; // pass 2 out
+    // what the permutation stage needs of a row, 16 bytes instead of its 36-byte table (NULL: no p-values):
+    //   (N, K, n, kind << 30 | k_obs)   kind 1: at most one non-empty class on a side (p = 1)
+    //                                   kind 2: 2 x 2 non-empty, the hypergeometric (N, K, n) and the observed count
+    //                                   kind 3: larger — the only rows whose table is written when counts_sparse
+    uint4* out_rec;
+    int counts_sparse;        // out_counts is scratch for the permutation stage only: tables of kind-3 rows, nothing else
     unsigned long long* site_sum; uint32_t* site_cnt;  // [n_sites] fixed-point sums
     int* err_flag;            // set to 1 when a pair with N == 0 reaches the MI
     unsigned long long* word_pairs;  // pass 1: sum over examined pairs of overlapping words
@@ -143,6 +149,8 @@ void launch_scan(hipStream_t st, const uint32_t* cnt, uint64_t* start, uint32_t 
 void launch_emit_write(hipStream_t st, const EmitArgs& a);
 void launch_site_mean(hipStream_t st, uint32_t n_sites, const unsigned long long* sum,
                       const uint32_t* cnt, double* mean);
+void launch_sites_add(hipStream_t st, uint32_t n_sites, unsigned long long* sum, const unsigned long long* sum_part,
+                      uint32_t* cnt, const uint32_t* cnt_part);
 void launch_rows_mean(hipStream_t st, uint64_t n_rows, const uint32_t* ri, const uint32_t* rj,
                       const double* mi, unsigned long long* sum, uint32_t* cnt);
 
@@ -151,10 +159,11 @@ struct PermArgs {
     const uint64_t* n_rows_dev;   // number of rows, on the device (the host may not know it yet)
     uint64_t max_rows;            // upper bound the grids are sized by
     const uint32_t* row_i; const uint32_t* row_j; const uint32_t* counts;
+    const uint4* rec;             // per row (N, K, n, kind << 30 | k_obs), written by k_emit<2> (EmitArgs::out_rec)
     const long long* G; const double* LF;
     uint32_t n_shuffles; uint64_t seed;
     int exact_2x2;                // rows with at most 2 x 2 non-empty classes get the exact p, not a binomial draw
-    double* out_p; uint32_t* out_exceed;
+    double* out_p; uint32_t* out_exceed;   // out_p may be NULL (lgmi_params.no_row_p: p is a function of exceed)
     uint32_t* gen_list; unsigned int* gen_count;   // gen_count[0] rows queued by k_perm_fast, [1] next row of k_perm_general (both zero at launch)
 };
 void launch_perm_fast(hipStream_t st, const PermArgs& a);

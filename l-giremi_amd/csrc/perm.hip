@@ -355,7 +355,6 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 {
     const uint64_t n_rows = *pa.n_rows_dev;
     const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
-    const uint32_t* __restrict__ counts = pa.counts;
     const TabG G{pa.G}; const TabLF LF{pa.LF};
     const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
     double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
@@ -375,23 +374,13 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     HG22 h = {1u, 0u, 0u, 0u, 0u, 0.0};
     Tail22 tb = {0, 0, 1, 0.0};
     if (r < n_rows) {
-        uint32_t T[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) T[k] = counts[9 * r + k];
-        uint32_t R[3], C[3], N = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2];
-            C[a] = T[a] + T[3 + a] + T[6 + a];
-            N += R[a];
-        }
-        const int nr = (R[0] != 0) + (R[1] != 0) + (R[2] != 0), nc = (C[0] != 0) + (C[1] != 0) + (C[2] != 0);
-        if (nr <= 1 || nc <= 1) {
-            kind = 1;
-        } else if (nr == 2 && nc == 2) {
-            kind = 2;
-            const int a2 = R[2] ? 2 : 1, b2 = C[2] ? 2 : 1;   // second non-empty row / column
-            h.N = N; h.K = R[a2]; h.n = C[b2];
+        // the row's record from k_emit<2>: (N, K, n, kind << 30 | k_obs) — classification and margins were made where
+        // the table was in registers (emit.hip: perm_record)
+        const uint4 rc = pa.rec[r];
+        kind = (int)(rc.w >> 30);
+        if (kind == 2) {
+            const uint32_t N = rc.x;
+            h.N = N; h.K = rc.y; h.n = rc.z;
             h.kmin = h.K + h.n > N ? h.K + h.n - N : 0u;
             h.kmax = h.K < h.n ? h.K : h.n;
             h.c0 = LF[h.K];
@@ -399,15 +388,15 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
             h.c0 += LF[h.n];
             h.c0 += LF[N - h.n];
             h.c0 -= LF[N];
+            const uint32_t kobs = rc.w & 0x3FFFFFFFu;
 #if LGMI_PABL & 64
-            tb.klo = T[3 * a2 + b2]; tb.khi = tb.klo + 40 <= (long long)h.kmax + 1 ? tb.klo + 40 : (long long)h.kmax + 1; tb.centre = 1;   // stays inside the support
+            tb.klo = kobs; tb.khi = tb.klo + 40 <= (long long)h.kmax + 1 ? tb.klo + 40 : (long long)h.kmax + 1; tb.centre = 1;   // stays inside the support
 #else
-            tb = bounds22(G, h, T[3 * a2 + b2]);
+            tb = bounds22(G, h, kobs);
 #endif
-        } else {
-            kind = 3;
+        } else if (kind == 3) {
 #if !(LGMI_PABL & 16)
-            if (!n_shuffles) { out_exceed[r] = LGMI_EXCEED_EXACT; out_p[r] = __longlong_as_double(0x7ff8000000000000ll); }   // exact_2x2 only: no estimate
+            if (!n_shuffles) { out_exceed[r] = LGMI_EXCEED_EXACT; if (out_p) out_p[r] = __longlong_as_double(0x7ff8000000000000ll); }   // exact_2x2 only: no estimate
 #endif
         }
     }
@@ -520,7 +509,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
             if (p < 0.0) p = 0.0;
         }
         out_exceed[r] = LGMI_EXCEED_EXACT;
-        out_p[r] = p;
+        out_p[r] = p;                                       // (the exact p is never derivable: out_p is there)
         kind = 0;                                           // done with this row
     }
     if (kind == 2) {
@@ -544,7 +533,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 #endif
     }
     out_exceed[r] = exceed;
-    out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+    if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
     }
     __syncthreads();                                        // s_pre / s_acc are reused by the next chunk
     }   // chunk loop
@@ -980,7 +969,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
             for (int o = 32; o > 0; o >>= 1) exceed += __shfl_xor(exceed, o);
             if (lane == 0) {
                 out_exceed[r] = exceed;
-                out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+                if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
             }
             continue;
         }
@@ -1164,7 +1153,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
         for (int o = 32; o > 0; o >>= 1) exceed += __shfl_xor(exceed, o);
         if (lane == 0) {
             out_exceed[r] = exceed;
-            out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+            if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
         }
     }   // rows of the batch
     }   // batch loop
@@ -1204,9 +1193,13 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
     // take the queued rows from a shared counter
     // (LGMI_PERM_WPC: one-wave workgroups per CU, for occupancy experiments — tools/abl_perm.sh; 16 = four per SIMD)
     // as many as the LDS of a CU holds, 16 at most (12 or 8 run the loop as fast as 16: profiles/r03_perm_general_occupancy.txt)
-    const int fit = (int)((160u * 1024u) / (FIRST_MAX * 4u + (GUIDE_N + 1u) * 2u + XRING * 2u + 64u));
-    const int dflt = fit < 16 ? (fit < 1 ? 1 : fit) : 16;
-    static const int wpc = [dflt] { const char* e = getenv("LGMI_PERM_WPC"); const int v = e ? atoi(e) : dflt; return v >= 1 && v <= 32 ? v : dflt; }();
+    static const int wpc = [] {
+        const int fit = (int)((160u * 1024u) / (FIRST_MAX * 4u + (GUIDE_N + 1u) * 2u + XRING * 2u + 64u));
+        const int dflt = fit < 16 ? (fit < 1 ? 1 : fit) : 16;
+        const char* e = getenv("LGMI_PERM_WPC");
+        const int v = e ? atoi(e) : dflt;
+        return v >= 1 && v <= 32 ? v : dflt;
+    }();
     hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, a);
 }
 

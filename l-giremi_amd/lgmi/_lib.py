@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LGMI_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'liblgmi.so'))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, E_ARG, E_OOM, E_HIP, E_RCCL, E_NODEV, E_STATE, E_DOMAIN = 0, -1, -2, -3, -4, -5, -6, -7
 TYPE_MISMATCH, TYPE_SNP, TYPE_HET_SNP = 0, 1, 2
 UNIQUE_ID_BYTES = 128
@@ -31,13 +31,14 @@ class Batch(C.Structure):
 class Params(C.Structure):
     _fields_ = [('min_common', C.c_uint32), ('n_shuffles', C.c_uint32), ('seed', C.c_uint64),
                 ('het_only', C.c_uint8), ('emit_counts', C.c_uint8), ('exact_2x2', C.c_uint8),
-                ('reserved0', C.c_uint8), ('shard_rank', C.c_uint16), ('shard_world', C.c_uint16)]
+                ('no_row_p', C.c_uint8), ('shard_rank', C.c_uint16), ('shard_world', C.c_uint16)]
 
 
 class Result(C.Structure):
     _fields_ = [('n_rows', C.c_uint64), ('n_sites', C.c_uint64), ('row_i', u32p), ('row_j', u32p),
                 ('row_mi', f64p), ('row_p', f64p), ('row_exceed', u32p), ('row_counts', u32p),
-                ('site_mean_mi', f64p), ('site_n_pairs', u32p), ('owner_', C.c_void_p)]
+                ('site_mean_mi', f64p), ('site_n_pairs', u32p), ('owner_', C.c_void_p),
+                ('n_shuffles', C.c_uint32), ('row_p_derived', C.c_uint32)]
 
 
 class RunInfo(C.Structure):
@@ -49,7 +50,7 @@ class RunInfo(C.Structure):
                 ('mfma_dtype', C.c_uint32), ('reserved', C.c_uint32),
                 ('n_examined_total', C.c_uint64), ('n_general_rows', C.c_uint64),
                 ('ms_plan_host', C.c_float), ('ms_perm_fast', C.c_float), ('ms_perm_general', C.c_float),
-                ('reserved2', C.c_uint32)]
+                ('n_seq_shards', C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}

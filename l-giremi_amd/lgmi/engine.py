@@ -4,7 +4,6 @@ from __future__ import annotations
 import ctypes as C
 import os
 import weakref
-from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
@@ -13,18 +12,26 @@ from . import _lib
 from .pack import PackedBatch
 
 
-@dataclass
 class MIResult:
-    """rows in reference order; indices are global site indices of the batch"""
-    row_i: np.ndarray
-    row_j: np.ndarray
-    row_mi: np.ndarray
-    row_p: Optional[np.ndarray]
-    row_exceed: Optional[np.ndarray]
-    row_counts: Optional[np.ndarray]     # (n_rows, 3, 3): [class at i][class at j]
-    site_mean_mi: np.ndarray
-    site_n_pairs: np.ndarray
-    info: dict
+    """rows in reference order; indices are global site indices of the batch.
+
+    ``row_p``: the permutation p of every row, or None without p-values.  The library is asked not to make the array
+    when it is a function of ``row_exceed`` (Monte-Carlo estimates: ``(1 + row_exceed) / (n_shuffles + 1)``,
+    lgmi_params.no_row_p) — 8 of 28 bytes per row that need not cross PCIe; it is derived here on first use."""
+
+    def __init__(self, row_i, row_j, row_mi, row_p, row_exceed, row_counts, site_mean_mi, site_n_pairs, info,
+                 n_shuffles=0, p_derived=False):
+        self.row_i, self.row_j, self.row_mi = row_i, row_j, row_mi
+        self._row_p, self.row_exceed = row_p, row_exceed
+        self.row_counts = row_counts             # (n_rows, 3, 3): [class at i][class at j]
+        self.site_mean_mi, self.site_n_pairs, self.info = site_mean_mi, site_n_pairs, info
+        self.n_shuffles, self._p_derived = int(n_shuffles), bool(p_derived)
+
+    @property
+    def row_p(self):
+        if self._row_p is None and self._p_derived and self.row_exceed is not None:
+            self._row_p = (1.0 + self.row_exceed.astype(np.float64)) / (self.n_shuffles + 1.0)   # the kernels' own expression
+        return self._row_p
 
     @property
     def n_rows(self):
@@ -42,22 +49,26 @@ def _copy_result(res: _lib.Result, info: dict) -> MIResult:
         else:
             out = np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
         return out.reshape(shape) if shape else out
-    has_p = bool(res.row_p) or (n == 0 and info.get('has_p', False))
+    has_e = bool(res.row_exceed) or (n == 0 and info.get('has_p', False))
+    derived = bool(res.row_p_derived)
+    has_p = (bool(res.row_p) or (n == 0 and info.get('has_p', False))) and not derived
     has_c = bool(res.row_counts) or (n == 0 and info.get('has_counts', False))
     return MIResult(a(res.row_i, n, np.uint32), a(res.row_j, n, np.uint32), a(res.row_mi, n, np.float64),
-                    a(res.row_p, n, np.float64, present=has_p), a(res.row_exceed, n, np.uint32, present=has_p),
+                    a(res.row_p, n, np.float64, present=has_p), a(res.row_exceed, n, np.uint32, present=has_e),
                     a(res.row_counts, 9 * n, np.uint32, (n, 3, 3), present=has_c),
-                    a(res.site_mean_mi, ns, np.float64), a(res.site_n_pairs, ns, np.uint32), info)
+                    a(res.site_mean_mi, ns, np.float64), a(res.site_n_pairs, ns, np.uint32), info,
+                    n_shuffles=int(res.n_shuffles), p_derived=derived)
 
 
 def make_params(min_common=5, n_shuffles=0, seed=0, het_only=True, emit_counts=False, exact_2x2=False,
-                shard=None) -> _lib.Params:
-    """shard = (rank, world): compute only that contiguous, cost-balanced slice of the result rows"""
+                shard=None, no_row_p=True) -> _lib.Params:
+    """shard = (rank, world): compute only that contiguous, cost-balanced slice of the result rows.
+    no_row_p (default): row_p is not made as an array when it is a function of row_exceed (MIResult.row_p derives it)"""
     if min_common < 0:
         min_common = 0
     rank, world = (0, 0) if shard is None else (int(shard[0]), int(shard[1]))
     return _lib.Params(int(min_common), int(n_shuffles), int(seed) & (2**64 - 1),
-                       1 if het_only else 0, 1 if emit_counts else 0, 1 if exact_2x2 else 0, 0, rank, world)
+                       1 if het_only else 0, 1 if emit_counts else 0, 1 if exact_2x2 else 0, 1 if no_row_p else 0, rank, world)
 
 
 def plan_shard(batch: PackedBatch, het_only=True, shard=(0, 1), n_shuffles=0) -> dict:
@@ -203,9 +214,9 @@ class Engine:
         _lib.check(self.lib.lgmi_ctx_synchronize(self.handle))
 
     def run(self, batch: PackedBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-            emit_counts=False, exact_2x2=False, shard=None) -> MIResult:
+            emit_counts=False, exact_2x2=False, shard=None, no_row_p=True) -> MIResult:
         self._alive()
-        st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard)
+        st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p)
         res, info = _lib.Result(), _lib.RunInfo()
         _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
         try:
@@ -245,11 +256,11 @@ class Engine:
         return self.synth_dense(default_synth_spec(n_sites, n_reads, seed=seed, n_blocks=n_blocks))
 
     def run_device(self, dbatch: DeviceBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-                   emit_counts=False, exact_2x2=False, shard=None, rows_only=False) -> DeviceResult:
+                   emit_counts=False, exact_2x2=False, shard=None, rows_only=False, no_row_p=True) -> DeviceResult:
         """rows_only=True stops when the rows (i, j, mi, tables, per-site means) are final; DeviceResult.permute()
         runs the permutation stage later — a multi-GPU host starts the row gather in between (comm_gather_begin)"""
         self._alive()
-        prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard), C.c_void_p()
+        prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p), C.c_void_p()
         fn = self.lib.lgmi_run_device_rows if rows_only else self.lib.lgmi_run_device
         _lib.check(fn(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
         return DeviceResult(self, h)
@@ -384,8 +395,12 @@ class Engine:
                 if not ptr or n == 0:
                     return np.zeros(0, dt) if (ptr or n == 0) else None
                 return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
-            return {'row_i': a(res.row_i, np.uint32), 'row_j': a(res.row_j, np.uint32),
-                    'row_mi': a(res.row_mi, np.float64), 'row_p': a(res.row_p, np.float64) if res.row_p else None}
+            out = {'row_i': a(res.row_i, np.uint32), 'row_j': a(res.row_j, np.uint32), 'row_mi': a(res.row_mi, np.float64),
+                   'row_exceed': a(res.row_exceed, np.uint32) if res.row_exceed else None,
+                   'row_p': a(res.row_p, np.float64) if res.row_p else None}
+            if out['row_p'] is None and res.row_p_derived and out['row_exceed'] is not None:
+                out['row_p'] = (1.0 + out['row_exceed'].astype(np.float64)) / (int(res.n_shuffles) + 1.0)
+            return out
         finally:
             self.lib.lgmi_result_free(C.byref(res))
 

@@ -551,3 +551,27 @@ def test_mi_log_against_correctly_rounded_values(engine):
     assert np.mean(ulps == 0) > 0.995, np.mean(ulps == 0)
     # the reference's own logarithm (numpy -> libm) differs from the correctly rounded value about as rarely
     assert np.mean(np.log(xs) == want) > 0.99
+
+
+def test_row_p_array_is_optional_and_equal_to_the_derived_one(engine):
+    """lgmi_params.no_row_p: Monte-Carlo p is (1 + exceed) / (S + 1); the library can leave the array out (what the
+    Python host asks for: MIResult.row_p derives it) — with the array, without it and through the two-call form the
+    numbers are the same, and exact_2x2 rows keep their array either way"""
+    pb = random_batch(77, n_blocks=3, P=(4, 60), R=(20, 500), tri_frac=0.3)
+    kw = dict(min_common=3, n_shuffles=40, seed=3, het_only=False)
+    with_arr = engine.run(pb, no_row_p=False, **kw)
+    without = engine.run(pb, no_row_p=True, **kw)
+    assert with_arr._row_p is not None and without._row_p is None and without._p_derived
+    np.testing.assert_array_equal(with_arr.row_exceed, without.row_exceed)
+    np.testing.assert_array_equal(with_arr.row_p, without.row_p)
+    np.testing.assert_array_equal(without.row_p, (1.0 + without.row_exceed) / 41.0)
+    db = engine.upload(pb)
+    dr = engine.run_device(db, rows_only=True, **kw)
+    dr.permute()
+    two = dr.fetch()
+    np.testing.assert_array_equal(two.row_exceed, without.row_exceed)
+    assert two._row_p is None and (two.row_p == without.row_p).all()
+    ex = engine.run(pb, exact_2x2=True, no_row_p=True, **kw)
+    assert ex._row_p is not None and not ex._p_derived            # exact p is not a function of exceed
+    dr.free()
+    db.free()

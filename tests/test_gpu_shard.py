@@ -151,3 +151,38 @@ def test_split_run_and_two_phase_gather(engine):
     np.testing.assert_array_equal(dr.fetch().row_mi, ref.row_mi)
     dr.free()
     db.free()
+
+
+def test_one_call_splits_itself_under_a_small_memory_budget(engine, monkeypatch):
+    """lgmi_run_device / lgmi_run cut a run that does not fit the memory budget into sequential shards on the one GPU
+    (LGMI_MEM_BUDGET_MB forces it here): rows, tables, MI, exceed and the per-site figures are bit-equal to the
+    single-sequence run, the info says how many shards ran"""
+    import lgmi
+    spec = lgmi.default_synth_spec(1500, 9000, seed=33)
+    spec.tri_per_1024 = 100
+    db = engine.synth_dense(spec)
+    kw = dict(min_common=6, het_only=True, n_shuffles=30, seed=5)
+    fields = ('row_i', 'row_j', 'row_mi', 'row_exceed', 'row_p', 'site_n_pairs', 'site_mean_mi')
+    for counts in (False, True):
+        monkeypatch.setenv('LGMI_NO_AUTO_SPLIT', '1')
+        dr = engine.run_device(db, emit_counts=counts, **kw)
+        whole, winfo = dr.fetch(), dr.info()
+        dr.free()
+        assert winfo['n_seq_shards'] == 1
+        monkeypatch.delenv('LGMI_NO_AUTO_SPLIT')
+        monkeypatch.setenv('LGMI_MEM_BUDGET_MB', '40')       # slots + operands alone are ~14 MB here
+        dr = engine.run_device(db, emit_counts=counts, **kw)
+        got, ginfo = dr.fetch(), dr.info()
+        dr.free()
+        assert ginfo['n_seq_shards'] > 1 and ginfo['n_rows'] == winfo['n_rows'] and ginfo['n_examined'] == winfo['n_examined']
+        assert ginfo['n_general_rows'] == winfo['n_general_rows']
+        for f in fields + (('row_counts',) if counts else ()):
+            np.testing.assert_array_equal(getattr(got, f), getattr(whole, f), err_msg=f)
+        # the host-to-host call takes the same way
+        pb = db.download()
+        one = engine.run(pb, emit_counts=counts, **kw)
+        assert one.info['n_seq_shards'] > 1
+        for f in fields:
+            np.testing.assert_array_equal(getattr(one, f), getattr(whole, f), err_msg='lgmi_run ' + f)
+        monkeypatch.delenv('LGMI_MEM_BUDGET_MB')
+    db.free()
