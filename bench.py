@@ -40,6 +40,10 @@ WORKLOADS = {
     'cfg3_22x9091x45455': dict(n_sites=9_091, n_reads=45_455, n_blocks=22),
     # BASELINE.json configs[4]: coverage depth x 4, mi_min_common_read = 6, 10,000 shuffles
     'cfg5_dense_depthx4_S10000': dict(n_sites=9_091, n_reads=181_820, n_blocks=22, shuffles=10_000),
+    # the shape real L-GIREMI input has (src/giremi/footprint.py:6-28, script/giremi.py:32,60-78): 20,000 small
+    # (footprint, strand) blocks, 5-120 sites x 50-3000 reads each (lgmi.synth.footprint_blocks) — not a BASELINE config;
+    # reports blocks/s, the host's planning time and the count tiles' utilisation next to pairs/s
+    'footprints_20k': dict(n_sites=0, n_reads=0, regime='footprints', n_footprints=20_000),
     # twice the north-star's sites in ONE block: 1.8e9 rows, ~160 GB of HBM in use — the headroom case (not a BASELINE config)
     'headroom_dense_100kx200k': dict(n_sites=100_000, n_reads=200_000),
 }
@@ -77,15 +81,18 @@ def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
     from oracle import c_oracle
     n_reads = wl['n_reads']
     cores = c_oracle.load().lgo_num_threads()
-    if wl.get('regime') == 'banded':
-        from lgmi.synth import banded_chromosome
-        pb = banded_chromosome(wl['n_sites'], n_reads, seed=seed)
+    if wl.get('regime') in ('banded', 'footprints'):
+        if wl['regime'] == 'banded':
+            from lgmi.synth import banded_chromosome
+            pb = banded_chromosome(wl['n_sites'], n_reads, seed=seed)
+        else:
+            pb = wl['_host_batch']
         t0 = time.perf_counter()
         out = c_oracle.run(pb, min_common=min_common, het_only=True, n_shuffles=n_shuffles, seed=seed, threads=cores)
         dt = time.perf_counter() - t0
         return {'value': out['n_examined'] / dt, 'unit': 'site-pairs/s', 'cores': cores, 'kind': 'port',
-                'sample': 'the whole banded workload: %d examined pairs, %d emitted, %.1f s wall'
-                          % (out['n_examined'], len(out['row_i']), dt)}
+                'sample': 'the whole %s workload: %d examined pairs, %d emitted, %.1f s wall'
+                          % (wl['regime'], out['n_examined'], len(out['row_i']), dt)}
     # ~2.5e9 pair-words keeps 16 host cores busy for ~10-20 s; the permutation stage of the sample scales with S
     target_pair_words = 2.5e9 * max(1, cores) / 16 / max(1.0, n_shuffles / 1000.0)
     words = (n_reads + 63) // 64
@@ -140,6 +147,16 @@ def main():
 
     import lgmi
     from lgmi.dist import group_from_env
+    wl = WORKLOADS[args.workload]
+    if wl.get('regime') == 'footprints':
+        # built by a pool of forked workers: before anything touches the GPU
+        from lgmi.synth import footprint_blocks
+        t_gen = time.perf_counter()
+        wl = dict(wl, _host_batch=footprint_blocks(wl['n_footprints'], seed=20250810 + (0 if args.scaling == 'strong' or world == 1 else 1000 * rank),
+                                                   cache_dir=os.environ.get('LGMI_BENCH_CACHE', '/tmp')))
+        wl['n_sites'] = wl['_host_batch'].n_sites
+        wl['n_reads'] = int(wl['_host_batch'].block_n_reads.max())
+        print('[bench] %d footprints, %d sites, built in %.1f s' % (wl['n_footprints'], wl['n_sites'], time.perf_counter() - t_gen), file=sys.stderr)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     group = group_from_env()                                   # plain sockets; a no-op object at N = 1
     device = int(os.environ.get('LGMI_BENCH_DEVICE', local_rank))
@@ -149,7 +166,6 @@ def main():
         device %= n_dev.value                                  # a launcher that narrows the visible devices per rank
 
     eng = lgmi.Engine(device)
-    wl = WORKLOADS[args.workload]
     n_shuffles = args.shuffles if args.shuffles is not None else wl.get('shuffles', 1000)
     strong = args.scaling == 'strong' or world == 1
     seed = 20250808 + (0 if strong else 1000 * rank)           # strong: the same chromosome on every rank
@@ -157,12 +173,15 @@ def main():
     if wl.get('regime') == 'banded':
         from lgmi.synth import banded_chromosome
         db = eng.upload(banded_chromosome(wl['n_sites'], wl['n_reads'], seed=seed))
+    elif wl.get('regime') == 'footprints':
+        db = eng.upload(wl['_host_batch'])
+        n_blocks = wl['_host_batch'].n_blocks
     else:
         db = eng.synth_dense(lgmi.default_synth_spec(wl['n_sites'], wl['n_reads'], seed=seed, n_blocks=n_blocks))
     gather_state = {'on': (world > 1 or args.force_gather) and not args.no_gather, 'note': None}
     hung = []
     shard = (rank, world) if (strong and world > 1) else None
-    n_sites_rank = wl['n_sites'] * n_blocks
+    n_sites_rank = wl['n_sites'] * (1 if wl.get('regime') == 'footprints' else n_blocks)
 
     def sync():
         eng.synchronize()
@@ -291,7 +310,13 @@ def main():
             if world > 1 or args.force_gather:
                 out['per_rank'] = per_rank
                 out['verify'] = verify if verify is not None else 'not run (no gather, or weak scaling)'
-            out['rates'] = {'emitted_pairs_per_s': rows_job * args.steps / elapsed}
+            out['rates'] = {'emitted_pairs_per_s': rows_job * args.steps / elapsed,
+                            'blocks_per_s': n_blocks * (world if not strong else 1) * args.steps / elapsed}
+            # how full the count kernels' tiles are: pairs examined / pairs inside the tiles computed (small footprints
+            # fill a fraction of a 64 x 64 tile), and what the host spends planning per step
+            out['tile_utilisation'] = {'n_examined': info['n_examined'], 'n_tile_pairs': info['n_tile_pairs'],
+                                       'frac': info['n_examined'] / info['n_tile_pairs'] if info['n_tile_pairs'] else None,
+                                       'ms_plan_host': sum(i['ms_plan_host'] for i in infos) / len(infos)}
             if n_shuffles:
                 # the permutation stage, priced on what it really draws: a 2 x 2 row costs ONE binomial
                 # variate against its exact tail mass; only the larger tables draw n_shuffles tables each.  VALU issue

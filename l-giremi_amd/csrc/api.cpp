@@ -167,9 +167,32 @@ struct lgmi_ctx {
     std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
 };
 
+// A plan is a function of the resident batch and a few parameters, not of the run: it is kept with the batch, host
+// vectors and device copies, so that a second run on the same batch neither plans nor uploads again.  (Round 3: on 20,000
+// footprint-sized blocks the planner's 29 ms and the 60 MB plan upload were most of a 97 ms step whose kernels take
+// 22 ms; a dense chromosome's plan is 1 - 2 ms.)  A few entries: the sequential shards of a self-splitting run cycle.
+struct PlanCache {
+    bool het_only = false; uint32_t sh_rank = 0, sh_world = 1, n_shuffles_key = 0, xg = 0; int ck = 0;
+    uint64_t stamp = 0;
+    float ms_build = 0.f;
+    Plan pl;
+    bool on_device = false;
+    BlockPlan* d_plans = nullptr; uint32_t* d_xlist = nullptr; uint32_t* d_ylist = nullptr; SiteMap* d_smap = nullptr;
+    Tile* d_tiles = nullptr; Tile* d_mtiles = nullptr; uint2* d_items = nullptr; uint2* d_units = nullptr;
+    OpGroup* d_opgroups = nullptr;
+    void release(Pool& p) {
+        p.release(d_plans); p.release(d_xlist); p.release(d_ylist); p.release(d_smap); p.release(d_tiles);
+        p.release(d_mtiles); p.release(d_items); p.release(d_units); p.release(d_opgroups);
+        d_plans = nullptr; d_xlist = d_ylist = nullptr; d_smap = nullptr; d_tiles = d_mtiles = nullptr;
+        d_items = d_units = nullptr; d_opgroups = nullptr; on_device = false;
+    }
+};
+
 struct lgmi_dbatch {
     lgmi_ctx* ctx = nullptr;
     DevBatch d;
+    mutable std::vector<std::unique_ptr<PlanCache>> plans;   // most recently used plans of this batch (at most PLAN_CACHE_N)
+    mutable uint64_t plan_stamp = 0;
     // host copies of the site metadata (planning happens on the host)
     std::vector<uint64_t> block_site_begin;
     std::vector<uint32_t> block_n_reads;
@@ -337,6 +360,8 @@ extern "C" void lgmi_dbatch_free(lgmi_dbatch* db) {
     if (!db) return;
     (void)hipSetDevice(db->ctx->device);
     (void)hipStreamSynchronize(db->ctx->stream);
+    for (auto& pc : db->plans) pc->release(db->ctx->pool);
+    db->plans.clear();
     free_dbatch_device(db);
     delete db;
 }
@@ -692,6 +717,41 @@ extern "C" void lgmi_dresult_free(lgmi_dresult* r) {
     delete r;
 }
 
+static const size_t PLAN_CACHE_N = 4;
+// the batch's plan for these parameters: cached, or built now (host side only; run_device_impl uploads it on first use)
+static PlanCache* plan_for(lgmi_ctx* ctx, const lgmi_dbatch* db, bool het_only, uint32_t sh_rank, uint32_t sh_world, uint32_t n_shuffles,
+                           bool* fresh) {
+    int ck; uint32_t xg;
+    plan_env(&ck, &xg);
+    if (sh_world == 0) { sh_world = 1; sh_rank = 0; }
+    const uint32_t nkey = sh_world > 1 ? n_shuffles : 0u;        // the shuffle count only prices work items: it moves shard boundaries, nothing else
+    const bool no_cache = getenv("LGMI_NO_PLAN_CACHE") != nullptr;
+    if (!no_cache)
+        for (auto& pc : db->plans)
+            if (pc->het_only == het_only && pc->sh_rank == sh_rank && pc->sh_world == sh_world && pc->n_shuffles_key == nkey &&
+                pc->ck == ck && pc->xg == xg) {
+                pc->stamp = ++db->plan_stamp;
+                if (fresh) *fresh = false;
+                return pc.get();
+            }
+    if (db->plans.size() >= PLAN_CACHE_N || (no_cache && !db->plans.empty())) {        // drop the least recently used one
+        size_t lru = 0;
+        for (size_t k = 1; k < db->plans.size(); ++k) if (db->plans[k]->stamp < db->plans[lru]->stamp) lru = k;
+        (void)hipStreamSynchronize(ctx->stream);                 // nothing in flight reads its device arrays
+        db->plans[lru]->release(ctx->pool);
+        db->plans.erase(db->plans.begin() + (long)lru);
+    }
+    std::unique_ptr<PlanCache> pc(new PlanCache());
+    pc->het_only = het_only; pc->sh_rank = sh_rank; pc->sh_world = sh_world; pc->n_shuffles_key = nkey; pc->ck = ck; pc->xg = xg;
+    pc->stamp = ++db->plan_stamp;
+    const auto t0 = std::chrono::steady_clock::now();
+    build_plan(plan_input(db), het_only, sh_rank, sh_world, ck, xg, n_shuffles, pc->pl);
+    pc->ms_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (fresh) *fresh = true;
+    db->plans.push_back(std::move(pc));
+    return db->plans.back().get();
+}
+
 static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out, bool defer_perm) {
     if (!ctx || !db || !prm || !out) return fail(LGMI_E_ARG, "NULL argument");
     *out = nullptr;
@@ -717,14 +777,10 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if (want_p && (rc = ensure_perm_tables(ctx, std::max(db->max_reads, prm->n_shuffles)))) return rc;   // first use only
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     tr.mark("ev0");
-    const auto t_plan0 = std::chrono::steady_clock::now();
-    Plan pl;
-    {
-        int ck; uint32_t xg;
-        plan_env(&ck, &xg);
-        build_plan(plan_input(db), prm->het_only != 0, sh_rank, sh_world, ck, xg, prm->n_shuffles, pl);
-    }
-    const float ms_plan_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
+    bool plan_fresh = false;
+    PlanCache* pcache = plan_for(ctx, db, prm->het_only != 0, sh_rank, sh_world, prm->n_shuffles, &plan_fresh);
+    Plan& pl = pcache->pl;
+    const float ms_plan_host = plan_fresh ? pcache->ms_build : 0.f;      // 0: the batch's cached plan
     tr.mark("planned");
     const size_t n_items = (size_t)(pl.item_end - pl.item_begin);
     if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull || n_items >= 0x7FFFFFFFull)
@@ -751,22 +807,28 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     } guard{pool, scratch, res};
     auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
 
-    BlockPlan* d_plans; uint32_t* d_xlist; uint32_t* d_ylist; SiteMap* d_smap; Tile* d_tiles; Tile* d_mtiles; uint2* d_items;
     uint4* d_slots; uint32_t* d_rowcnt; uint64_t* d_rowstart; uint32_t* d_cnt;
     int* d_err; unsigned long long* d_wordpairs;
-    if ((rc = salloc((void**)&d_plans, pl.plans.size() * sizeof(BlockPlan)))) return rc;
-    if ((rc = salloc((void**)&d_xlist, pl.xlist.size() * 4))) return rc;
-    if ((rc = salloc((void**)&d_items, std::max<size_t>(n_items, 1) * sizeof(uint2)))) return rc;
-    uint2* d_units = nullptr;
-    if ((rc = salloc((void**)&d_units, std::max<size_t>(pl.units.size(), 1) * sizeof(uint2)))) return rc;
-    if ((rc = salloc((void**)&d_ylist, pl.ylist.size() * 4))) return rc;
-    if ((rc = salloc((void**)&d_smap, pl.smap.size() * sizeof(SiteMap)))) return rc;
-    if ((rc = salloc((void**)&d_tiles, pl.tiles.size() * sizeof(Tile)))) return rc;
-    if ((rc = salloc((void**)&d_mtiles, pl.mtiles.size() * sizeof(Tile)))) return rc;
+    if (!pcache->on_device) {
+        Pool& pp = pool;
+        int e = 0;
+        if (!e) e = pp.alloc((void**)&pcache->d_plans, std::max<size_t>(pl.plans.size(), 1) * sizeof(BlockPlan));
+        if (!e) e = pp.alloc((void**)&pcache->d_xlist, std::max<size_t>(pl.xlist.size(), 1) * 4);
+        if (!e) e = pp.alloc((void**)&pcache->d_items, std::max<size_t>(n_items, 1) * sizeof(uint2));
+        if (!e) e = pp.alloc((void**)&pcache->d_units, std::max<size_t>(pl.units.size(), 1) * sizeof(uint2));
+        if (!e) e = pp.alloc((void**)&pcache->d_ylist, std::max<size_t>(pl.ylist.size(), 1) * 4);
+        if (!e) e = pp.alloc((void**)&pcache->d_smap, std::max<size_t>(pl.smap.size(), 1) * sizeof(SiteMap));
+        if (!e) e = pp.alloc((void**)&pcache->d_tiles, std::max<size_t>(pl.tiles.size(), 1) * sizeof(Tile));
+        if (!e) e = pp.alloc((void**)&pcache->d_mtiles, std::max<size_t>(pl.mtiles.size(), 1) * sizeof(Tile));
+        if (!e) e = pp.alloc((void**)&pcache->d_opgroups, std::max<size_t>(pl.op_groups.size(), 1) * sizeof(OpGroup));
+        if (e) { pcache->release(pool); return e; }
+    }
+    BlockPlan* const d_plans = pcache->d_plans; uint32_t* const d_xlist = pcache->d_xlist; uint32_t* const d_ylist = pcache->d_ylist;
+    SiteMap* const d_smap = pcache->d_smap; Tile* const d_tiles = pcache->d_tiles; Tile* const d_mtiles = pcache->d_mtiles;
+    uint2* const d_items = pcache->d_items; uint2* const d_units = pcache->d_units;
     if ((rc = salloc((void**)&d_slots, pl.total_slots * sizeof(uint4)))) return rc;
-    uint4* d_ops = nullptr; OpGroup* d_opgroups = nullptr;
+    uint4* d_ops = nullptr; OpGroup* const d_opgroups = pcache->d_opgroups;
     if ((rc = salloc((void**)&d_ops, std::max<uint64_t>(pl.op_total, 1) * sizeof(uint4)))) return rc;
-    if ((rc = salloc((void**)&d_opgroups, std::max<size_t>(pl.op_groups.size(), 1) * sizeof(OpGroup)))) return rc;
     if ((rc = salloc((void**)&d_rowcnt, std::max<size_t>(n_items, 1) * 4))) return rc;
     if ((rc = salloc((void**)&d_rowstart, (n_items + 1) * 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
@@ -796,7 +858,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         {d_opgroups, pl.op_groups.data(), pl.op_groups.size() * sizeof(OpGroup)},
     };
     size_t up_total = 0;
-    for (const Up& u : ups) up_total += (u.n + 255) & ~size_t(255);
+    if (!pcache->on_device) for (const Up& u : ups) up_total += (u.n + 255) & ~size_t(255);
     struct Staging {                       // back to the pool once the stream no longer reads it
         std::shared_ptr<PinnedPool> pool; hipStream_t st; void* p = nullptr; size_t got = 0;
         ~Staging() { if (p) { (void)hipStreamSynchronize(st); pool->give(p, got); } }
@@ -812,6 +874,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
             off += (u.n + 255) & ~size_t(255);
         }
     }
+    pcache->on_device = true;
     tr.mark("uploaded");
     if (ns) HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 16, st));
@@ -840,9 +903,13 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     ea.n_items = (uint32_t)n_items; ea.items = d_items;
     ea.n_units = (uint32_t)pl.units.size(); ea.units = d_units;
     ea.row_cnt = d_rowcnt; ea.row_start = d_rowstart;
-    ea.site_sum = d_sum; ea.site_cnt = d_cnt; ea.err_flag = d_err; ea.word_pairs = d_wordpairs;
+    unsigned long long* d_unitwords = nullptr; uint64_t* d_scantmp = nullptr;
+    if ((rc = salloc((void**)&d_unitwords, std::max<size_t>(pl.units.size(), 1) * 8))) return rc;
+    if ((rc = salloc((void**)&d_scantmp, scan_tmp_words((uint32_t)n_items) * 8))) return rc;
+    ea.site_sum = d_sum; ea.site_cnt = d_cnt; ea.err_flag = d_err; ea.unit_words = d_unitwords;
     launch_emit_count(st, ea);
-    launch_scan(st, d_rowcnt, d_rowstart, (uint32_t)n_items);
+    launch_scan(st, d_rowcnt, d_rowstart, (uint32_t)n_items, d_scantmp);
+    launch_sum_u64(st, d_unitwords, (uint32_t)pl.units.size(), d_wordpairs);
     HIPCHK(hipGetLastError());
     // Row arrays: the number of rows is only known on the device here.  When the upper bound (every examined pair
     // is emitted — what a dense block does) fits a third of the device memory the arrays are sized by it and the
@@ -1059,10 +1126,7 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
 
 extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out) {
     if (ctx && db && prm && out && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
-        Plan pl;
-        int ck; uint32_t xg;
-        plan_env(&ck, &xg);
-        build_plan(plan_input(db), prm->het_only != 0, 0, 1, ck, xg, prm->n_shuffles, pl);
+        const Plan& pl = plan_for(ctx, db, prm->het_only != 0, 0, 1, prm->n_shuffles, nullptr)->pl;   // (the one the run itself uses)
         const int k = split_count(ctx, db, prm, pl);
         if (k > 1) return run_device_split(ctx, db, prm, k, pl.n_examined, out);
     }
@@ -1209,12 +1273,10 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
     bool split = false;
     if (prm && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
         // more than one launch sequence holds: sequential shards (lgmi_run_device), no overlap of fetch and permutation
-        Plan pl;
-        int ck; uint32_t xg;
-        plan_env(&ck, &xg);
-        build_plan(plan_input(db), prm->het_only != 0, 0, 1, ck, xg, prm->n_shuffles, pl);
+        const Plan& pl = plan_for(ctx, db, prm->het_only != 0, 0, 1, prm->n_shuffles, nullptr)->pl;
         const int k = split_count(ctx, db, prm, pl);
-        if (k > 1) { split = true; rc = run_device_split(ctx, db, prm, k, pl.n_examined, &dr); }
+        const uint64_t bound = pl.n_examined;               // (before the shards' plans may evict this one)
+        if (k > 1) { split = true; rc = run_device_split(ctx, db, prm, k, bound, &dr); }
     }
     if (!split) rc = run_device_impl(ctx, db, prm, &dr, true);
     if (!rc) {

@@ -141,11 +141,13 @@ struct EmitArgs {
     int counts_sparse;        // out_counts is scratch for the permutation stage only: tables of kind-3 rows, nothing else
     unsigned long long* site_sum; uint32_t* site_cnt;  // [n_sites] fixed-point sums
     int* err_flag;            // set to 1 when a pair with N == 0 reaches the MI
-    unsigned long long* word_pairs;  // pass 1: sum over examined pairs of overlapping words
+    unsigned long long* unit_words;  // [n_units] pass 1: per unit, the sum over its examined pairs of overlapping words
 };
 static const uint32_t EMIT_SEG = LGMI_EMIT_SEG;   // multiple of 64
 void launch_emit_count(hipStream_t st, const EmitArgs& a);
-void launch_scan(hipStream_t st, const uint32_t* cnt, uint64_t* start, uint32_t n);
+size_t scan_tmp_words(uint32_t n);
+void launch_scan(hipStream_t st, const uint32_t* cnt, uint64_t* start, uint32_t n, uint64_t* tmp);
+void launch_sum_u64(hipStream_t st, const unsigned long long* v, uint32_t n, unsigned long long* out);
 void launch_emit_write(hipStream_t st, const EmitArgs& a);
 void launch_site_mean(hipStream_t st, uint32_t n_sites, const unsigned long long* sum,
                       const uint32_t* cnt, double* mean);

@@ -1,6 +1,8 @@
 """Full-size GPU checks (BASELINE.json sizes) through properties that do not need a CPU
 recomputation of every pair: a random sample of rows against numpy popcounts on the
 downloaded planes, ordering, margins, mean-MI consistency, p-value laws."""
+import os
+
 import numpy as np
 import pytest
 
@@ -214,3 +216,39 @@ def test_north_star_banded_full_size_against_the_oracle(engine):
     np.testing.assert_array_equal(res.site_n_pairs, ora['site_n_pairs'])
     m = ora['site_n_pairs'] > 0
     assert np.max(np.abs(res.site_mean_mi[m] - ora['site_mean_mi'][m])) <= 1e-6
+
+
+def test_footprint_shaped_batch_against_the_c_oracle(engine):
+    """the many-small-blocks regime real data lives in (bench.py --workload footprints_20k; the reference's unit of work
+    is the footprint: src/giremi/footprint.py:6-28, script/giremi.py:32,60-78), at its full size of 20,000 blocks:
+    rows, tables, MI, per-site means and 1000-shuffle exceed counts against the C oracle, bit for bit (the pairs are
+    cheap, so the CPU does all of them)"""
+    import subprocess
+    import sys
+    import tempfile
+    from lgmi.synth import footprint_blocks
+    from oracle import c_oracle
+    # the generator forks a pool of numpy workers: run it in a child of its own (this process holds a HIP context) and
+    # pick the packed batch up from the cache file
+    cache = tempfile.mkdtemp(prefix='lgmi_fp_')
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'l-giremi_amd')
+    subprocess.run([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); from lgmi.synth import footprint_blocks; '
+                    'footprint_blocks(20000, seed=20250810, cache_dir=%r)' % (pkg, cache)], check=True, timeout=900)
+    pb = footprint_blocks(20_000, seed=20250810, cache_dir=cache)              # the cached arrays
+    import shutil
+    shutil.rmtree(cache, ignore_errors=True)
+    assert pb.n_blocks == 20_000
+    kw = dict(min_common=6, het_only=True, n_shuffles=1000, seed=20250810)
+    res = engine.run(pb, emit_counts=True, **kw)
+    ora = c_oracle.run(pb, **kw)
+    assert res.n_rows == len(ora['row_i']) > 1_000_000
+    np.testing.assert_array_equal(res.row_i, ora['row_i'])
+    np.testing.assert_array_equal(res.row_j, ora['row_j'])
+    np.testing.assert_array_equal(res.row_counts, ora['row_counts'])
+    np.testing.assert_array_equal(res.row_exceed, ora['row_exceed'])
+    assert np.max(np.abs(res.row_mi - ora['row_mi'])) <= 1e-6
+    np.testing.assert_array_equal(res.row_mi == 0.0, ora['row_mi'] == 0.0)       # the same rows are exactly 0.0
+    np.testing.assert_array_equal(res.site_n_pairs, ora['site_n_pairs'])
+    m = res.site_n_pairs > 0
+    assert np.max(np.abs(res.site_mean_mi[m] - ora['site_mean_mi'][m])) <= 1e-6
+    assert res.info['n_examined'] == ora['n_examined']
