@@ -329,8 +329,19 @@ def main():
                       'table_draws': draws, 'ms_general': ms_gen, 'ms_fast': ms_fast,
                       'table_draws_per_s': draws / (ms_gen * 1e-3) if ms_gen > 0 else None,
                       'two_by_two_rows_per_s': (info['n_rows'] - general_job) / (ms_fast * 1e-3) if ms_fast > 0 else None,
-                      'bound': 'valu_issue', 'unit': 'wave64 VALU instructions/s',
-                      'peak': VALU_WAVE_INSTR_PEAK, 'counters': sq.get('_file') or committed_profile('pmc_sq_perm').get('_file')}
+                      'bound': 'L1 (TCP) rate of scattered 8-byte table look-ups for k_perm_general (DESIGN.md §8 round 3); '
+                               'VALU issue for k_perm_fast',
+                      'unit': 'wave64 VALU instructions/s', 'peak': VALU_WAVE_INSTR_PEAK,
+                      'counters': sq.get('_file') or committed_profile('pmc_sq_perm').get('_file'),
+                      'source': 'the counter-derived fields below come from the committed profile named in `counters` '
+                                '(separate rocprofv3 --pmc passes of this workload), NOT from this run; times and rates are this run\'s'}
+                l1 = committed_profile('pmc_perm_general')
+                if l1.get('derived') and args.workload == 'north_star_dense_50kx200k':
+                    dd = l1['derived']
+                    pr['k_perm_general_l1'] = {k: dd.get(k) for k in ('lookups_per_table_draw', 'l1_accesses_per_lookup_instruction',
+                                                                      'l1_accesses_per_cu_cycle', 'l1_miss_frac', 'l2_hit_frac',
+                                                                      'l1_tagconflict_stall_frac_of_cycles', 'instructions_per_table_draw_wave')}
+                    pr['k_perm_general_l1']['source'] = 'committed profile %s (the kernel before the per-row LDS cache), not this run' % l1.get('_file')
                 for k in ('k_perm_general', 'k_perm_fast'):
                     c = sq.get(k)
                     if c and c.get('valu_insts') and c.get('ms'):
@@ -350,11 +361,12 @@ def main():
                                         'active_lane_frac': sq_e.get('active_lanes', 0) / 64.0,
                                         'valu_insts_per_row': sq_e['valu_insts'] * 64.0 / info['n_rows'],
                                         'peak': VALU_WAVE_INSTR_PEAK, 'unit': 'wave64 VALU instructions/s',
-                                        'counters': committed_profile('pmc_sq_perm').get('_file')}
+                                        'counters': committed_profile('pmc_sq_perm').get('_file'),
+                                        'source': 'valu_* and active_lane_frac: committed profile, not this run'}
             traffic = committed_profile('pmc_k_count').get(args.workload + ('_mfma' if mfma else ''), {}).get('hbm_bytes')
             hbm = {'kernel': 'count', 'bound': 'hbm', 'algorithmic_bytes': alg_bytes, 'achieved': alg_bytes / secs / 1e9,
                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_bytes / secs / 1e9 / HBM_PEAK_GBS,
-                   'traffic': traffic,
+                   'traffic': traffic, 'traffic_source': 'committed profile (separate --pmc passes), not this run',
                    'note': 'bytes per launch; the count kernel is compute-bound, not HBM-bound.  traffic = L2-miss bytes '
                            '(FETCH_SIZE x2 + WRITE_SIZE, newest profiles/rNN_pmc_k_count.json)'}
             valu = {'kernel': 'k_count', 'bound': 'valu_popcount', 'achieved': word_ops / secs / 1e12,
@@ -369,6 +381,7 @@ def main():
                                    'achieved': ops / secs / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                                    'op_kind': ('fp4 (e2m1)' if fp4 else 'int8') + ' multiply-add ops (tera-ops/s), dense MFMA peak',
                                    'frac': ops / secs / 1e12 / peak, 'traffic': traffic,
+                                   'traffic_source': 'committed profile (separate --pmc passes), not this run',
                                    'algorithmic_ops': ops, 'ms_kernel': ms_count,
                                    'note': 'algorithmic ops = 512 x examined pair-words (4 counts x 64 reads x 2) of this '
                                            'rank\'s shard; '
@@ -401,8 +414,17 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)
             return out
 
+    def degrade(line, tag, text):
+        """the gather could not be measured: the line says so where a machine reads it — `degraded`, no `value` (the
+        kernel-only figure moves to `kernel_only_value`) — and the process exits non-zero"""
+        line['config']['gather'] = text
+        line['degraded'] = tag
+        line['kernel_only_value'] = line['value']
+        line['value'] = None
+
     multi = gather_state['on']
     out = None
+    exit_code = 0
     if not multi:
         infos, elapsed, per_rank = measure()
         if rank == 0:
@@ -437,8 +459,9 @@ def main():
             hung.append(th)
         states = group.allgather(box.get('err') or ('ok' if box.get('ok') else 'timeout'))
         if any(st != 'ok' for st in states):
+            exit_code = 4                                       # the metric (gather included) was NOT measured
             if rank == 0:
-                fallback['config']['gather'] = 'RCCL communicator not available (%s): rows were NOT gathered' % states
+                degrade(fallback, 'rccl_init_failed', 'RCCL communicator not available (%s): rows were NOT gathered' % states)
                 out = fallback
         else:
             # (3) the measurement proper, gather inside the timed region, under a watchdog: if it does not finish, every
@@ -447,19 +470,21 @@ def main():
 
             def give_up():
                 if rank == 0:
-                    fallback['config']['gather'] = 'the RCCL gather did not finish within %.0f s: rows were NOT gathered' % limit
+                    degrade(fallback, 'gather_hang', 'the RCCL gather did not finish within %.0f s: rows were NOT gathered' % limit)
                     os.write(json_fd, (json.dumps(fallback) + '\n').encode())
-                os._exit(0 if rank == 0 else 3)
+                os._exit(4 if rank == 0 else 3)                 # never 0: the requested measurement did not happen
             dog = threading.Timer(limit, give_up)
             dog.daemon = True
             dog.start()
             gather_state.update(on=True, note=None)
+            rccl = eng.comm_info()                              # what RCCL itself says: version, library, ncclCommCount
             infos, elapsed, per_rank = measure()
             verify = run_verify() if (strong and not os.environ.get('LGMI_BENCH_NO_VERIFY')) else None
             dog.cancel()
             simple = None
             if rank == 0:
                 simple = make_out(infos, elapsed, per_rank, verify)
+                simple['rccl'] = rccl
                 simple['kernel_only'] = {'value': fallback['value'], 'ms_per_step': fallback['ms_per_step'],
                                          'note': 'the same steps without the gather (measured first)'}
                 simple['config']['gather'] += ' after the permutation stage'
@@ -471,8 +496,9 @@ def main():
                 def keep_simple():
                     if rank == 0:
                         simple['overlapped_gather'] = 'did not finish within %.0f s' % limit
+                        simple['degraded'] = 'overlapped_gather_hang (the reported line is the gather-after-permutation measurement, which completed)'
                         os.write(json_fd, (json.dumps(simple) + '\n').encode())
-                    os._exit(0 if rank == 0 else 3)
+                    os._exit(5 if rank == 0 else 3)             # a rank is stuck in a collective: say so with the exit code
                 dog = threading.Timer(limit, keep_simple)
                 dog.daemon = True
                 dog.start()
@@ -490,6 +516,7 @@ def main():
                         simple['overlapped_gather'] = 'failed: %s' % [st for st in states2 if st]
                     else:
                         over = make_out(infos2, elapsed2, per_rank2, verify2)
+                        over['rccl'] = rccl
                         over['config']['gather'] += ' under the permutation stage (lgmi_run_device_rows, lgmi_comm_gather_begin, lgmi_dresult_permute, lgmi_comm_gather_finish)'
                         ok2 = verify2 is None or verify2.get('equal_to_unsharded')
                         summary = {'value': over['value'], 'ms_per_step': over['ms_per_step'], 'verify': verify2}
@@ -500,6 +527,12 @@ def main():
                             out = over
                         else:
                             simple['overlapped_gather'] = summary
+    if hung:
+        # a thread is still inside ncclCommInitRank with the context: nothing of it is touched (no free, no close — that
+        # would race with the thread), the line goes out and the process leaves with a non-zero code
+        if out is not None:
+            os.write(json_fd, (json.dumps(out) + '\n').encode())
+        os._exit(exit_code or 4)
     db.free()
     if world > 1:
         group.barrier()
@@ -507,8 +540,8 @@ def main():
     group.close()
     if out is not None:
         os.write(json_fd, (json.dumps(out) + '\n').encode())
-    if hung:                                                   # a thread still inside ncclCommInitRank: do not wait for it
-        os._exit(0)
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == '__main__':

@@ -75,3 +75,37 @@ def test_stand_in_is_refused_without_the_explicit_switch(fake_rccl):
     env.pop('LGMI_ALLOW_RCCL_STANDIN', None)
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert r.stdout.strip().splitlines()[-1] == 'REFUSED', (r.stdout, r.stderr[-2000:])
+
+
+def _bench_two_ranks(extra_env):
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+           '--workload', 'small_dense_2kx20k', '--shuffles', '50']
+    env = dict(os.environ, LGMI_BENCH_DEVICE='0', LGMI_COMM_INIT_TIMEOUT='90', LGMI_GATHER_TIMEOUT='200', **extra_env)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_two_ranks_over_the_stand_in_reports_what_rccl_says(fake_rccl):
+    """the driver's N > 1 launch of bench.py, two ranks on the one GPU through the stand-in: exit code 0, the gathered
+    rows equal the unsharded run, and the line carries the communicator's own account (lgmi_comm_info) — with
+    stand_in = true, so that such a line can never pass for a measurement over RCCL"""
+    r, line = _bench_two_ranks({'LGMI_RCCL_LIB': fake_rccl, 'LGMI_ALLOW_RCCL_STANDIN': '1'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line and line['n_gpus'] == 2 and line['value'] and 'degraded' not in line
+    assert line['rccl']['stand_in'] is True and line['rccl']['nranks'] == 2 and line['rccl']['initialised']
+    ver = line.get('verify') or line.get('gather_after_permutation', {}).get('verify')
+    assert ver and ver['equal_to_unsharded'] is True
+
+
+def test_bench_two_ranks_without_a_communicator_is_not_a_success():
+    """two ranks on ONE device over the real librccl: the communicator cannot come up (RCCL refuses the duplicate
+    device).  The kernel-only figure is still printed, but as `kernel_only_value` of a line marked `degraded` with no
+    `value`, and the exit code is not 0 (a driver must not record this as an N-GPU result)"""
+    env = {k: v for k, v in {'LGMI_RCCL_LIB': ''}.items()}
+    r, line = _bench_two_ranks(env)
+    assert r.returncode != 0
+    assert line and line['degraded'] == 'rccl_init_failed' and line['value'] is None and line['kernel_only_value'] > 0
+    assert 'NOT gathered' in line['config']['gather']
