@@ -66,6 +66,7 @@ def parse_args(argv=None):
     p.add_argument('--n_shuffles', type=int, default=0, help='permutation shuffles per pair (0: no p_perm column)')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--device', type=int, default=None, help='GPU index (default: LGMI_DEVICE / LOCAL_RANK / 0)')
+    p.add_argument('--timing_json', type=str, default=None, help='write the wall time of every stage of the run to this file')
     p.add_argument('--version', action='version', version='lgmi %s' % __version__)
     return p.parse_args(argv)
 
@@ -136,6 +137,9 @@ def main(argv=None):
     if not args.genome_fasta:
         sys.exit('--genome_fasta is required')
 
+    import time
+    timing = {}
+    t_all = t0 = time.perf_counter()
     from .engine import Engine
     from .region import regions_mismatch_analysis
     sam = open_alignment(args.bam_file)
@@ -145,6 +149,9 @@ def main(argv=None):
 
     logging.info('Get regions that are covered by enough reads.')
     footprints = get_footprints(sam, args.chromosomes, args.min_total_depth)
+    timing['open_and_footprints_s'] = time.perf_counter() - t0
+    timing['n_footprints'] = len(footprints)
+    t0 = time.perf_counter()
     logging.info('Calculate mismatches in each region.')
     jobs = []
     for chrom, start, end, _n in footprints:
@@ -153,6 +160,7 @@ def main(argv=None):
         reps = [[a, b] for a, b in repeats.get(chrom, []) if a > end or b < start]
         jobs.append({'chromosome': chrom, 'start': start, 'end': end, 'snp_positions': snps,
                      'simple_repeat_intervals': reps, 'read_strand_dict': None})
+    timing['footprint_inputs_s'] = time.perf_counter() - t0
     made = []
 
     def make_engine():                      # after the worker pool is gone: a HIP context does not survive fork()
@@ -160,7 +168,7 @@ def main(argv=None):
         return made[0]
     df_sites, df_mi, df_removed = regions_mismatch_analysis(
         jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
-        engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta),
+        engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta), timing=timing,
         keep_non_spliced_read=args.keep_non_spliced_read,
         min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
         min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
@@ -168,12 +176,20 @@ def main(argv=None):
         max_het_snp_ratio=args.max_het_snp_ratio, mismatch_window_size=args.mismatch_window_size,
         max_window_mismatch=args.max_window_mismatch, max_window_mismatch_type=args.max_window_mismatch_type,
         mode=args.mode)
+    t0 = time.perf_counter()
     strand_df = pd.DataFrame.from_records([], columns=['read_name', 'original_read_strand', 'corrected_read_strand'])
     strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
     df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
     df_removed.to_csv(args.output_prefix + '.removed.txt', sep='\t', index=False)
+    timing['write_s'] = time.perf_counter() - t0
     for e in made:
         e.close()
+    timing['total_s'] = time.perf_counter() - t_all
+    timing['mi_rows'], timing['site_rows'] = len(df_mi), len(df_sites)
+    if args.timing_json:
+        import json
+        with open(args.timing_json, 'w') as f:
+            json.dump({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timing.items()}, f)
     logging.info('All done!')
     return df_sites, df_mi, df_removed
 

@@ -66,21 +66,13 @@ def mean_mismatch_pair_mutual_info(mismatch_pair_mi, engine: Optional[Engine] = 
     return [[pos, float(mean[k])] for pos, k in index.items()]
 
 
-def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None):
-    """The MI block (mismatch.py:384-418) of MANY footprints in ONE launch sequence.
-
-    ``regions`` is a sequence of ``(mismatches_by_strand, chromosome)``; every (footprint, strand) becomes one
-    block of a single batch, so thousands of small footprints cost one upload, one count launch and one
-    fetch instead of thousands.  Returns one ``(records, mean_mi, p_values)`` triple per region, each exactly
-    what ``region_pair_mi`` returns for that region alone."""
-    strands = ('+', '-')
-    regions = list(regions)
-    out = [([], {'+': {}, '-': {}}, ([] if n_shuffles else None)) for _ in regions]
+def _run_regions(regions, min_common_reads, n_shuffles, seed, engine):
+    """pack every (footprint, strand) of `regions` as one batch and run it -> (batch, result) or (None, None)"""
     blocks = []
     for mm, _chrom in regions:
-        blocks.extend(mm.get(s, {}) for s in strands)
+        blocks.extend(mm.get(s, {}) for s in ('+', '-'))
     if not any(len(b) > 1 for b in blocks):
-        return out
+        return None, None
     eng = engine or default_engine()
     batch = pack_blocks(blocks)
     res = eng.run(batch, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True)
@@ -92,6 +84,35 @@ def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: O
         chk = eng.run(batch, min_common=_min_common(min_common_reads), het_only=False)
         if chk.n_rows and (batch.bad_sites[chk.row_i].any() or batch.bad_sites[chk.row_j].any()):
             raise IndexError('list index out of range')
+    return batch, res
+
+
+def _site_means(batch, res, n_regions):
+    """per region {'+': {pos: mean}, '-': {pos: mean}} from the batch's per-site figures"""
+    strands = ('+', '-')
+    out = [{'+': {}, '-': {}} for _ in range(n_regions)]
+    bsb = batch.block_site_begin.astype(np.int64)
+    pos = batch.site_pos.tolist()
+    npairs, mean = res.site_n_pairs, res.site_mean_mi
+    hit = np.nonzero(npairs)[0]
+    for s, b in zip(hit.tolist(), (np.searchsorted(bsb, hit, side='right') - 1).tolist()):
+        out[b >> 1][strands[b & 1]][pos[s]] = float(mean[s])
+    return out
+
+
+def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None):
+    """The MI block (mismatch.py:384-418) of MANY footprints in ONE launch sequence.
+
+    ``regions`` is a sequence of ``(mismatches_by_strand, chromosome)``; every (footprint, strand) becomes one
+    block of a single batch, so thousands of small footprints cost one upload, one count launch and one
+    fetch instead of thousands.  Returns one ``(records, mean_mi, p_values)`` triple per region, each exactly
+    what ``region_pair_mi`` returns for that region alone."""
+    strands = ('+', '-')
+    regions = list(regions)
+    out = [([], {'+': {}, '-': {}}, ([] if n_shuffles else None)) for _ in regions]
+    batch, res = _run_regions(regions, min_common_reads, n_shuffles, seed, engine)
+    if batch is None:
+        return out
     bsb = batch.block_site_begin.astype(np.int64)
     pos, names = batch.site_pos.tolist(), batch.type_names
     # rows come sorted by block: one slice per block instead of a Python step per row
@@ -108,11 +129,39 @@ def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: O
                        for i, j, m in zip(ri[r0:r1], rj[r0:r1], rmi[r0:r1]))
         if pvals is not None:
             pvals.extend(rp[r0:r1])
-    npairs, mean = res.site_n_pairs, res.site_mean_mi
-    hit = np.nonzero(npairs)[0]
-    for s, b in zip(hit.tolist(), (np.searchsorted(bsb, hit, side='right') - 1).tolist()):
-        out[b >> 1][1][strands[b & 1]][pos[s]] = float(mean[s])
+    for k, m in enumerate(_site_means(batch, res, len(regions))):
+        out[k][1].update(m)
     return out
+
+
+def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None):
+    """The same launch, returned the way a whole run consumes it: ONE table of all regions' pair rows in the
+    reference's order (script/giremi.py:381-394 concatenates the per-footprint frames of mismatch.py:407-418) built
+    column by column from the result arrays — no Python object per row, which is what 10^7 rows of tens of
+    thousands of footprints need — plus the per-region ``mean_mi`` dictionaries.
+    -> (DataFrame[chromosome, strand, site1_pos, site1_type, site2_pos, site2_type, mi (, p_perm)], [mean_mi])"""
+    import pandas as pd
+    regions = list(regions)
+    cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
+    batch, res = _run_regions(regions, min_common_reads, n_shuffles, seed, engine)
+    if batch is None or res.n_rows == 0:
+        df = pd.DataFrame({c: [] for c in cols})
+        if n_shuffles:
+            df['p_perm'] = []
+        return df, ([{'+': {}, '-': {}} for _ in regions] if batch is None else _site_means(batch, res, len(regions)))
+    bsb = batch.block_site_begin.astype(np.int64)
+    block = np.searchsorted(bsb, res.row_i.astype(np.int64), side='right') - 1          # the block of every row
+    chrom_of_region = np.array([c for _mm, c in regions], dtype=object)
+    names = np.array(batch.type_names, dtype=object)
+    pos = batch.site_pos
+    df = pd.DataFrame({'chromosome': chrom_of_region[block >> 1],
+                       'strand': np.array(['+', '-'], dtype=object)[block & 1],
+                       'site1_pos': pos[res.row_i], 'site1_type': names[res.row_i],
+                       'site2_pos': pos[res.row_j], 'site2_type': names[res.row_j],
+                       'mi': res.row_mi}, columns=cols)
+    if n_shuffles:
+        df['p_perm'] = res.row_p
+    return df, _site_means(batch, res, len(regions))
 
 
 def region_pair_mi(mismatches_by_strand: dict, chromosome: str, min_common_reads=5, n_shuffles=0, seed=0,

@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import pandas as pd
 
-from .mutual_information import region_pair_mi, regions_pair_mi
+from .mutual_information import region_pair_mi, regions_pair_mi, regions_pair_mi_table
 
 _CS_TOKEN = re.compile(r'([:*+\-~])([0-9a-z]+)')
 _COMPLEMENT = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N'}
@@ -151,20 +151,36 @@ def get_region_mismatches_with_filters(chromosome, start_pos, end_pos, sam, geno
         # ---- 4. too many substitutions of too many kinds in the window (:211-240)
         half = round(mismatch_window_size / 2)
         snapshot = sorted(sites.keys())
+        # What a site adds to its neighbours' counts: one change string per non-reference allele of its depth dict.  Most
+        # sites of a footprint are the empty ones the pile-up loop created (one per covered position) and add nothing:
+        # only the contributing positions are visited (round 3: with every position of the window visited this loop was
+        # 80 % of the site extraction on a 2,000-gene BAM).  Same counts, same insertion order, same side effects: a site
+        # removed earlier in the loop contributes nothing and is re-created empty by the look-up (mismatch.py:214-222).
+        contrib = {}
+        for q in snapshot:
+            ref = sites[q]['ref']
+            alts = [a for a in sites[q]['depth'] if a != ref]
+            if alts:
+                contrib[q] = ['%s>%s' % (ref, nt) if strand == '+' else '%s>%s' % (_COMP4[ref], _COMP4[nt]) for nt in alts]
+        cpos = sorted(contrib)
+        removed_here, dead = [], set()                   # removed in this loop, in increasing position
         for pos in snapshot:
-            # the snapshot is sorted: the window is a slice (the reference filters the whole list for every site, :211-220)
-            around = [q for q in snapshot[bisect_left(snapshot, pos - half):bisect_left(snapshot, pos + half)] if q != pos]
-            if not around:
+            lo, hi = pos - half, pos + half
+            if bisect_left(snapshot, hi) - bisect_left(snapshot, lo) < 2:      # nobody but pos itself in the window
                 continue
-            for q in around:
-                ref = sites[q]['ref']                    # a site removed earlier in this loop comes back empty
-                for nt in [a for a in sites[q]['depth'] if a != ref]:
-                    change = '%s>%s' % (ref, nt) if strand == '+' else '%s>%s' % (_COMP4[ref], _COMP4[nt])
-                    sites[pos]['neighbor'][change] += 1
-            if sum(sites[pos]['neighbor'].values()) > max_window_mismatch and \
-                    len(sites[pos]['neighbor']) > max_window_mismatch_type:
+            for q in removed_here[bisect_left(removed_here, lo):bisect_left(removed_here, hi)]:
+                sites[q]['ref']                          # a site removed earlier in this loop comes back empty
+            neighbor = sites[pos]['neighbor']
+            for q in cpos[bisect_left(cpos, lo):bisect_left(cpos, hi)]:
+                if q == pos or q in dead:
+                    continue
+                for change in contrib[q]:
+                    neighbor[change] += 1
+            if sum(neighbor.values()) > max_window_mismatch and len(neighbor) > max_window_mismatch_type:
                 gone[pos] = sites.pop(pos)
                 gone[pos]['removed'] = 'too many window mismatches'
+                removed_here.append(pos)
+                dead.add(pos)
         # ---- 5. shallow alleles, rare alleles (the depth dict keeps every allele: :243-266)
         for pos in sorted(sites.keys()):
             for nt in list(sites[pos]['nt'].keys()):
@@ -238,9 +254,32 @@ def region_mismatch_analysis(chromosome, start_pos, end_pos, sam, genome,
     return _frames(chromosome, sites, gone, records, mean_mi, pvals)
 
 
+def _compact_gone(gone):
+    """the removed-site table of one footprint as arrays: {strand: (positions int64, reason codes uint8)} + the reason
+    strings — a footprint auto-creates an (empty, later "removed") site for every covered position (mismatch.py:29-62,
+    :166), so a whole run's removed table is millions of rows: they must not travel, or be assembled, as Python dicts"""
+    reasons, code = [], {}
+    out = {}
+    for strand in '+-':
+        d = gone[strand]
+        pos = np.fromiter(d.keys(), np.int64, len(d))
+        codes = np.empty(len(d), np.uint8)
+        for k, site in enumerate(d.values()):
+            r = site['removed']
+            c = code.get(r)
+            if c is None:
+                c = code[r] = len(reasons)
+                reasons.append(r)
+            codes[k] = c
+        out[strand] = (pos, codes)
+    return out, reasons
+
+
 def _extract_chunk(job, sam=None, genome=None):
-    """site extraction + filters for a list of footprints -> [(chromosome, sites, gone)] (pool worker and serial path)"""
-    reopen, footprints, filter_kwargs = job
+    """site extraction + filters for a list of footprints -> [(chromosome, sites, gone)] (pool worker and serial path);
+    with job[3] (compact) `gone` is the array form of _compact_gone"""
+    reopen, footprints, filter_kwargs = job[:3]
+    compact = len(job) > 3 and job[3]
     if reopen is not None:
         sam, genome = reopen()
     out = []
@@ -249,15 +288,18 @@ def _extract_chunk(job, sam=None, genome=None):
             chromosome=fp['chromosome'], start_pos=fp['start'], end_pos=fp['end'], sam=sam, genome=genome,
             snp_positions=fp.get('snp_positions', []), simple_repeat_intervals=fp.get('simple_repeat_intervals', []),
             read_strand_dict=fp.get('read_strand_dict'), **filter_kwargs)
+        if compact:
+            gone = _compact_gone(gone)
         if reopen is not None:              # results cross a process boundary: plain dicts (the site factory does not pickle)
             sites = {strand: dict(d) for strand, d in sites.items()}
-            gone = {strand: dict(d) for strand, d in gone.items()}
+            if not compact:
+                gone = {strand: dict(d) for strand, d in gone.items()}
         out.append((fp['chromosome'], sites, gone))
     return out
 
 
 def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
-                              concat=False, threads=1, reopen=None, **filter_kwargs):
+                              concat=False, threads=1, reopen=None, timing=None, **filter_kwargs):
     """``region_mismatch_analysis`` over many footprints with ONE GPU batch for all their MI blocks — the shape the
     reference's per-chunk loop (src/giremi/script/giremi.py:32-88) takes when the MI step is a device call.
 
@@ -267,6 +309,8 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     or with ``concat=True`` the three frames concatenated the way script/giremi.py:79-88 concatenates them.
     ``threads`` > 1 with ``reopen`` (a picklable callable returning fresh ``(sam, genome)`` objects) runs the host-side
     extraction in a process pool; ``engine`` may then be a callable that creates the engine AFTER the pool has finished."""
+    import time
+    t0 = time.perf_counter()
     footprints = list(footprints)
     staged = None
     if threads and threads > 1 and len(footprints) > 1 and reopen is not None:
@@ -276,30 +320,54 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
         # (`reopen()` -> (sam, genome)); the pool must be done before the parent creates its HIP context (fork).
         import multiprocessing as mp
         chunk = max(1, -(-len(footprints) // (4 * threads)))
-        jobs = [(reopen, footprints[k:k + chunk], filter_kwargs) for k in range(0, len(footprints), chunk)]
+        jobs = [(reopen, footprints[k:k + chunk], filter_kwargs, bool(concat)) for k in range(0, len(footprints), chunk)]
         with mp.get_context('fork').Pool(threads) as pool:
             staged = [x for part in pool.map(_extract_chunk, jobs) for x in part]
     if staged is None:
-        staged = _extract_chunk((None, footprints, filter_kwargs), sam, genome)
+        staged = _extract_chunk((None, footprints, filter_kwargs, bool(concat)), sam, genome)
     if callable(engine) and not hasattr(engine, 'run'):
         engine = engine()
+    if timing is not None:
+        timing['extract_s'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+    if concat:
+        # a whole run: the pair table column by column from the result arrays, the two site tables from one row list each
+        # (a DataFrame per footprint and a concat of thousands of them was most of the host time on 2,000 footprints)
+        df_pairs, means = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in staged], min_common_reads,
+                                                n_shuffles=n_shuffles, seed=seed, engine=engine)
+        if timing is not None:
+            timing['pack_gpu_table_s'] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+        site_rows = []
+        g_chrom, g_strand, g_pos, g_reason = [], [], [], []
+        for (chrom, sites, (gone, reasons)), mean_mi in zip(staged, means):
+            site_rows.extend(_site_rows(chrom, sites, mean_mi))
+            table = np.array(reasons, dtype=object)
+            for strand in '+-':
+                pos, codes = gone[strand]
+                if len(pos):
+                    g_chrom.append(np.full(len(pos), chrom, dtype=object))
+                    g_strand.append(np.full(len(pos), strand, dtype=object))
+                    g_pos.append(pos)
+                    g_reason.append(table[codes])
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+        out = (pd.DataFrame.from_records(site_rows, columns=_SITE_COLS), df_pairs,
+               pd.DataFrame({'chromosome': cat(g_chrom, object), 'strand': cat(g_strand, object), 'pos': cat(g_pos, np.int64),
+                             'removed': cat(g_reason, object)}, columns=['chromosome', 'strand', 'pos', 'removed']))
+        if timing is not None:
+            timing['site_tables_s'] = time.perf_counter() - t0
+        return out
     blocks = regions_pair_mi([(sites, chrom) for chrom, sites, _gone in staged], min_common_reads,
                              n_shuffles=n_shuffles, seed=seed, engine=engine)
-    frames = [_frames(chrom, sites, gone, *blk) for (chrom, sites, gone), blk in zip(staged, blocks)]
-    if not concat:
-        return frames
-    if not frames:
-        return _frames('', {'+': {}, '-': {}}, {'+': {}, '-': {}}, [], {'+': {}, '-': {}}, [] if n_shuffles else None)
-    return tuple(pd.concat([f[k] for f in frames], axis=0) for k in range(3))
+    return [_frames(chrom, sites, gone, *blk) for (chrom, sites, gone), blk in zip(staged, blocks)]
 
 
-def _frames(chromosome, sites, gone, records, mean_mi, pvals):
-    """the three DataFrames of mismatch.py:406-509 from the filtered sites and the MI block's output"""
-    pair_cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
-    df_pairs = pd.DataFrame.from_records(records, columns=pair_cols)
-    if pvals is not None:
-        df_pairs['p_perm'] = pvals
+_SITE_COLS = ['type', 'chromosome', 'strand', 'pos', 'ref', 'change_type', 'ratio', 'allelic_ratio_diff',
+              'depth', 'A:C:T:G', 'up_seq', 'down_seq', 'mean_mi']
 
+
+def _site_rows(chromosome, sites, mean_mi):
+    """rows of the mismatch table (mismatch.py:419-495) of one footprint"""
     rows = []
     for strand in '+-':
         means = mean_mi[strand]
@@ -326,9 +394,17 @@ def _frames(chromosome, sites, gone, records, mean_mi, pvals):
             acgt = '%s:%s:%s:%s' % tuple(depth.get(nt, 0) for nt in 'ACTG')     # A:C:T:G, defaultdict zeros
             rows.append([site['type'], chromosome, strand, pos, ref, change, ratio, ratio - regional, total,
                          acgt, up, down, means.get(pos, np.nan)])
-    df_sites = pd.DataFrame.from_records(
-        rows, columns=['type', 'chromosome', 'strand', 'pos', 'ref', 'change_type', 'ratio', 'allelic_ratio_diff',
-                       'depth', 'A:C:T:G', 'up_seq', 'down_seq', 'mean_mi'])
+    return rows
+
+
+def _frames(chromosome, sites, gone, records, mean_mi, pvals):
+    """the three DataFrames of mismatch.py:406-509 from the filtered sites and the MI block's output"""
+    pair_cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
+    df_pairs = pd.DataFrame.from_records(records, columns=pair_cols)
+    if pvals is not None:
+        df_pairs['p_perm'] = pvals
+
+    df_sites = pd.DataFrame.from_records(_site_rows(chromosome, sites, mean_mi), columns=_SITE_COLS)
     df_removed = pd.DataFrame.from_records(
         [[chromosome, s, pos, gone[s][pos]['removed']] for s in '+-' for pos in gone[s]],
         columns=['chromosome', 'strand', 'pos', 'removed'])

@@ -142,7 +142,13 @@ def test_cli_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None):
+        blocks = oracle_blocks(regions, mc)
+        cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
+        return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),
+                [m for _r, m, _p in blocks])
     monkeypatch.setattr(region, 'regions_pair_mi', oracle_blocks)
+    monkeypatch.setattr(region, 'regions_pair_mi_table', oracle_table)
     monkeypatch.setattr(lgmi.engine, 'Engine', NoEngine)
     run_cli_and_compare(tmp_path)
     # -t 2: the site extraction of the two footprints in a process pool (the reference's -t), same files out
@@ -210,7 +216,13 @@ def test_cli_cfg1_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None):
+        blocks = oracle_blocks(regions, mc)
+        cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
+        return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),
+                [m for _r, m, _p in blocks])
     monkeypatch.setattr(region, 'regions_pair_mi', oracle_blocks)
+    monkeypatch.setattr(region, 'regions_pair_mi_table', oracle_table)
     monkeypatch.setattr(lgmi.engine, 'Engine', NoEngine)
     gold, bam, fa, vcf = cfg1_inputs(tmp_path)
     from lgmi import cli

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the l-giremi-compatible CLI on a synthetic multi-gene BAM (the footprint-shaped regime real data
+lives in: src/giremi/footprint.py:6-28, script/giremi.py:32,60-78).
+
+    python tools/cli_e2e.py --genes 2000 --reads 1000000 --threads 1 8 32 [--workdir DIR] [--n_shuffles 0]
+
+1. writes (once per workdir) a genome FASTA, a VCF of het SNPs and a coordinate-sorted, indexed BAM with cs tags:
+   `genes` three-exon genes 6 kb apart on one contig, spliced long reads with a haplotype, 4-8 haplotype-linked het
+   SNPs and 3-6 independent mismatch sites per gene, 0.03 % sequencing errors (HiFi-like: the reference's window filter, mismatch.py:211-220, counts every position where any read differs, so a noisier error model removes nearly every site);
+2. runs `python -m lgmi.cli --mi_calculation_only --skip_strand_correction -t T --timing_json ...` once per T in a fresh
+   process and prints the wall time of every stage (BAM/BAI + footprints, per-footprint inputs, site extraction with its
+   filters, pack + GPU + pair table, site tables, writing) as one JSON line per T.
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'l-giremi_amd'))
+
+SEQ_CODE = np.full(256, 15, np.uint8)
+for k, c in enumerate('=ACMGRSVTWYHKDBN'):
+    SEQ_CODE[ord(c)] = k
+BASES = np.frombuffer(b'ACGT', np.uint8)
+LOWER = {65: 'a', 67: 'c', 71: 'g', 84: 't'}
+
+
+def reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def bgzf_blocks(data: bytes) -> bytes:
+    out = []
+    for k in range(0, len(data), 60000):
+        payload = data[k:k + 60000]
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = comp.compress(payload) + comp.flush()
+        out.append(b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', 12 + 6 + len(body) + 8 - 1) + body +
+                   struct.pack('<II', zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+    return b''.join(out)
+
+
+def gene_layout(rng, g):
+    start = 10_000 + 6_000 * g
+    exons, p = [], start
+    for _ in range(3):
+        ln = int(rng.integers(150, 401))
+        exons.append((p, p + ln))
+        p += ln + int(rng.integers(300, 801))
+    return exons
+
+
+def make_gene(job):
+    """-> (compressed BGZF blocks of the gene's records, [snp positions])"""
+    g, n_reads, seed, genome = job
+    rng = np.random.Generator(np.random.PCG64([seed, g]))
+    exons = gene_layout(rng, g)
+    ex_pos = np.concatenate([np.arange(a, b) for a, b in exons])
+    n_snp, n_mm = int(rng.integers(4, 9)), int(rng.integers(3, 7))
+    sites = rng.choice(ex_pos, n_snp + n_mm, replace=False)
+    snps, mms = np.sort(sites[:n_snp]), np.sort(sites[n_snp:])
+    alt = {}
+    for p in sites.tolist():
+        ref = genome[p]
+        alt[p] = int(rng.choice([b for b in BASES if b != ref]))
+    mm_rate = {int(p): float(rng.uniform(0.05, 0.5)) for p in mms}
+    reverse = bool(g & 1)
+    recs = []
+    first = rng.integers(0, 2, n_reads)                      # first exon of the read: 0 or 1 (at least two exons: spliced)
+    last = np.maximum(first + 1, rng.integers(1, 3, n_reads))
+    off_a = rng.random(n_reads)
+    off_b = rng.random(n_reads)
+    hap = rng.integers(0, 2, n_reads)
+    starts = np.array([exons[f][0] + int(o * 0.5 * (exons[f][1] - exons[f][0])) for f, o in zip(first.tolist(), off_a.tolist())])
+    order = np.argsort(starts, kind='stable')
+    for r in order.tolist():
+        f, l = int(first[r]), int(last[r])
+        a = int(starts[r])
+        b = exons[l][1] - int(off_b[r] * 0.5 * (exons[l][1] - exons[l][0]))
+        segs = []
+        for e in range(f, l + 1):
+            s0 = a if e == f else exons[e][0]
+            s1 = b if e == l else exons[e][1]
+            segs.append((s0, s1))
+        seq_parts, cs, cigar = [], [], []
+        for k, (s0, s1) in enumerate(segs):
+            if k:
+                i0, i1 = segs[k - 1][1], s0
+                cs.append('~%s%s%d%s%s' % (LOWER[genome[i0]], LOWER[genome[i0 + 1]], i1 - i0, LOWER[genome[i1 - 2]], LOWER[genome[i1 - 1]]))
+                cigar.append((3, i1 - i0))
+            ref = genome[s0:s1]
+            rd = ref.copy()
+            for p in snps[(snps >= s0) & (snps < s1)].tolist():
+                if bool(hap[r]) != bool(rng.random() < 0.02):
+                    rd[p - s0] = alt[p]
+            for p in mms[(mms >= s0) & (mms < s1)].tolist():
+                if rng.random() < mm_rate[p]:
+                    rd[p - s0] = alt[p]
+            err = np.nonzero(rng.random(s1 - s0) < 0.0003)[0]
+            for x in err.tolist():
+                if rd[x] == ref[x]:
+                    rd[x] = int(rng.choice([c for c in BASES if c != ref[x]]))
+            diff = np.nonzero(rd != ref)[0].tolist()
+            prev = 0
+            for x in diff:
+                if x > prev:
+                    cs.append(':%d' % (x - prev))
+                cs.append('*%s%s' % (LOWER[int(ref[x])], LOWER[int(rd[x])]))
+                prev = x + 1
+            if s1 - s0 > prev:
+                cs.append(':%d' % (s1 - s0 - prev))
+            seq_parts.append(rd)
+            cigar.append((0, s1 - s0))
+        seq = np.concatenate(seq_parts)
+        n = len(seq)
+        code = SEQ_CODE[seq]
+        if n & 1:
+            code = np.append(code, 0)
+        packed = ((code[0::2] << 4) | code[1::2]).astype(np.uint8).tobytes()
+        name = ('g%dr%d' % (g, r)).encode()
+        cig = b''.join(struct.pack('<I', (ln << 4) | op) for op, ln in cigar)
+        core = struct.pack('<iiBBHHHiiii', 0, a, len(name) + 1, 60, reg2bin(a, b), len(cigar), 16 if reverse else 0, n, -1, -1, 0)
+        rec = core + name + b'\0' + cig + packed + b'\x28' * n + b'csZ' + ''.join(cs).encode() + b'\0'
+        recs.append(struct.pack('<i', len(rec)) + rec)
+    return bgzf_blocks(b''.join(recs)), snps.tolist()
+
+
+def build_inputs(workdir, genes, reads, seed):
+    os.makedirs(workdir, exist_ok=True)
+    bam, fa, vcf = (os.path.join(workdir, n) for n in ('e2e.bam', 'e2e.fa', 'e2e.vcf'))
+    meta = os.path.join(workdir, 'e2e.json')
+    want = {'genes': genes, 'reads': reads, 'seed': seed}
+    if os.path.exists(meta) and json.load(open(meta)) == want and all(os.path.exists(p) for p in (bam, fa, vcf, bam + '.bai')):
+        return bam, fa, vcf
+    t0 = time.time()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    length = 10_000 + 6_000 * genes + 10_000
+    genome = BASES[rng.integers(0, 4, length)]
+    with open(fa, 'w') as f:
+        f.write('>chrS synthetic\n')
+        txt = genome.tobytes().decode()
+        for k in range(0, length, 60):
+            f.write(txt[k:k + 60] + '\n')
+    per_gene = np.maximum(20, rng.poisson(reads / genes, genes))
+    import multiprocessing as mp
+    jobs = [(g, int(per_gene[g]), seed, genome) for g in range(genes)]
+    with mp.get_context('fork').Pool(min(32, os.cpu_count() or 1)) as pool:
+        parts = pool.map(make_gene, jobs, chunksize=8)
+    text = '@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrS\tLN:%d\n' % length
+    head = b'BAM\1' + struct.pack('<i', len(text)) + text.encode() + struct.pack('<i', 1) + struct.pack('<i', 5) + b'chrS\0' + struct.pack('<i', length)
+    with open(bam, 'wb') as f:
+        f.write(bgzf_blocks(head))
+        for blocks, _s in parts:
+            f.write(blocks)
+        f.write(bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000'))
+    with open(vcf, 'w') as v:
+        v.write('##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n')
+        for _b, snps in parts:
+            for p in snps:
+                v.write('chrS\t%d\t.\t%s\tN\t.\t.\t.\n' % (p + 1, chr(genome[p])))
+    from lgmi.io import BamReader
+    BamReader.build_index(bam)
+    json.dump(want, open(meta, 'w'))
+    print('[cli_e2e] inputs: %d genes, %d reads, BAM %.0f MB, built in %.1f s' % (genes, int(per_gene.sum()), os.path.getsize(bam) / 1e6,
+                                                                                   time.time() - t0), file=sys.stderr)
+    return bam, fa, vcf
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--genes', type=int, default=2000)
+    ap.add_argument('--reads', type=int, default=1_000_000)
+    ap.add_argument('--threads', type=int, nargs='*', default=[1, 8, 32])
+    ap.add_argument('--workdir', default='/tmp/lgmi_cli_e2e')
+    ap.add_argument('--seed', type=int, default=20250811)
+    ap.add_argument('--n_shuffles', type=int, default=0)
+    ap.add_argument('--build_only', action='store_true')
+    args = ap.parse_args()
+    bam, fa, vcf = build_inputs(args.workdir, args.genes, args.reads, args.seed)
+    if args.build_only:
+        return
+    for t in args.threads:
+        prefix = os.path.join(args.workdir, 'out_t%d' % t)
+        tj = prefix + '.timing.json'
+        cmd = [sys.executable, '-m', 'lgmi.cli', '-b', bam, '-c', 'chrS', '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
+               '--mi_calculation_only', '--skip_strand_correction', '-t', str(t), '--timing_json', tj,
+               '--n_shuffles', str(args.n_shuffles)]
+        env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'l-giremi_amd') + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        t0 = time.time()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        wall = time.time() - t0
+        if r.returncode != 0:
+            print(json.dumps({'threads': t, 'error': r.stderr[-2000:]}))
+            continue
+        line = json.load(open(tj))
+        line.update(threads=t, process_wall_s=round(wall, 3), mi_rows=sum(1 for _ in open(prefix + '.mi.txt')) - 1,
+                    removed_rows=sum(1 for _ in open(prefix + '.removed.txt')) - 1)
+        print(json.dumps(line))
+        sys.stdout.flush()
+
+
+if __name__ == '__main__':
+    main()
