@@ -119,6 +119,12 @@ typedef struct lgmi_params {
      * order gives exactly the unsharded rows.  0/0 or x/1 = unsharded. */
     uint16_t shard_rank;
     uint16_t shard_world;
+    /* added to both site indices of a pair in the Philox counters of its permutation draws (the counters are keyed by
+     * the pair, so that shards and launch geometry never change a draw).  A multi-GPU host whose ranks run DIFFERENT
+     * batches (footprints dealt to ranks, lgmi.cli --gpus) passes each rank's site base — the same number it passes to
+     * lgmi_comm_gather — and gets, pair for pair, the draws of the single batch that holds all the footprints.  0 else. */
+    uint32_t stream_site_base;
+    uint32_t reserved1;    /* must be 0 */
 } lgmi_params;
 #define LGMI_EXCEED_EXACT 0xFFFFFFFFu
 

@@ -758,6 +758,8 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HostTrace tr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
     if (prm->no_row_p > 1) return fail(LGMI_E_ARG, "lgmi_params.no_row_p must be 0 or 1");
+    if (prm->reserved1) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
+    if ((uint64_t)prm->stream_site_base + db->d.n_sites >= 0xFFFFFFF0ull) return fail(LGMI_E_ARG, "stream_site_base + sites overflows 32 bits");
     if (prm->exact_2x2 > 1) return fail(LGMI_E_ARG, "exact_2x2 must be 0 or 1");
     if (prm->n_shuffles > (1u << 24)) return fail(LGMI_E_ARG, "n_shuffles must be <= 2^24");
     uint32_t sh_world = prm->shard_world, sh_rank = prm->shard_rank;
@@ -952,7 +954,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         PermArgs pa{};
         pa.n_rows_dev = d_rowstart + n_items; pa.max_rows = cap_rows;
         pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.rec = res->d_rec; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
-        pa.n_shuffles = prm->n_shuffles; pa.seed = prm->seed; pa.exact_2x2 = prm->exact_2x2;
+        pa.n_shuffles = prm->n_shuffles; pa.seed = prm->seed; pa.exact_2x2 = prm->exact_2x2; pa.site_base = prm->stream_site_base;
         pa.out_p = res->d_p; pa.out_exceed = res->d_exceed; pa.gen_list = d_genlist; pa.gen_count = d_gencount;
         launch_perm_fast(st, pa);
         HIPCHK(hipGetLastError());
@@ -1158,7 +1160,7 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
         PermArgs pa{};
         pa.n_rows_dev = res->d_nrows; pa.max_rows = res->cap_rows;
         pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.rec = res->d_rec; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
-        pa.n_shuffles = res->prm.n_shuffles; pa.seed = res->prm.seed; pa.exact_2x2 = res->prm.exact_2x2;
+        pa.n_shuffles = res->prm.n_shuffles; pa.seed = res->prm.seed; pa.exact_2x2 = res->prm.exact_2x2; pa.site_base = res->prm.stream_site_base;
         pa.out_p = res->d_p; pa.out_exceed = res->d_exceed; pa.gen_list = d_genlist; pa.gen_count = d_gencount;
         launch_perm_fast(st, pa);
         HIPCHK(hipGetLastError());

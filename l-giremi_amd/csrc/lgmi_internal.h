@@ -164,6 +164,7 @@ struct PermArgs {
     const uint4* rec;             // per row (N, K, n, kind << 30 | k_obs), written by k_emit<2> (EmitArgs::out_rec)
     const long long* G; const double* LF;
     uint32_t n_shuffles; uint64_t seed;
+    uint32_t site_base;           // added to row_i / row_j in the Philox counters (lgmi_params.stream_site_base)
     int exact_2x2;                // rows with at most 2 x 2 non-empty classes get the exact p, not a binomial draw
     double* out_p; uint32_t* out_exceed;   // out_p may be NULL (lgmi_params.no_row_p: p is a function of exceed)
     uint32_t* gen_list; unsigned int* gen_count;   // gen_count[0] rows queued by k_perm_fast, [1] next row of k_perm_general (both zero at launch)

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 #if LGMI_PABL & 128
         exceed = (uint32_t)(thr >> 24);
 #else
-        exceed = binom_draw(LF, n_shuffles, thr, row_i[r], row_j[r], (uint32_t)seed, (uint32_t)(seed >> 32));
+        exceed = binom_draw(LF, n_shuffles, thr, row_i[r] + pa.site_base, row_j[r] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
 #endif
     }
     out_exceed[r] = exceed;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
     for (uint32_t qk = 0; qk < batch && qk < n_gen - q0; ++qk) {
         const uint32_t q = q0 + qk;
         const uint32_t r = gen_list[q];
-        const uint32_t ci = row_i[r], cj = row_j[r];
+        const uint32_t ci = row_i[r] + pa.site_base, cj = row_j[r] + pa.site_base;
         uint32_t T[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) T[k] = counts[9ull * r + k];

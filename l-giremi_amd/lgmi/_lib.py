@@ -31,7 +31,8 @@ class Batch(C.Structure):
 class Params(C.Structure):
     _fields_ = [('min_common', C.c_uint32), ('n_shuffles', C.c_uint32), ('seed', C.c_uint64),
                 ('het_only', C.c_uint8), ('emit_counts', C.c_uint8), ('exact_2x2', C.c_uint8),
-                ('no_row_p', C.c_uint8), ('shard_rank', C.c_uint16), ('shard_world', C.c_uint16)]
+                ('no_row_p', C.c_uint8), ('shard_rank', C.c_uint16), ('shard_world', C.c_uint16),
+                ('stream_site_base', C.c_uint32), ('reserved1', C.c_uint32)]
 
 
 class Result(C.Structure):

@@ -67,6 +67,10 @@ def parse_args(argv=None):
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--device', type=int, default=None, help='GPU index (default: LGMI_DEVICE / LOCAL_RANK / 0)')
     p.add_argument('--timing_json', type=str, default=None, help='write the wall time of every stage of the run to this file')
+    p.add_argument('--gpus', type=int, default=None,
+                   help='ranks of a multi-GPU run (launch with python -m torch.distributed.run --nproc-per-node N -m lgmi.cli ... ; '
+                        'default WORLD_SIZE): footprints are dealt to the ranks in contiguous, read-balanced runs, every rank '
+                        'extracts and computes its own, the pair rows are gathered over RCCL onto rank 0, which writes')
     p.add_argument('--version', action='version', version='lgmi %s' % __version__)
     return p.parse_args(argv)
 
@@ -140,8 +144,18 @@ def main(argv=None):
     import time
     timing = {}
     t_all = t0 = time.perf_counter()
+    import os
     from .engine import Engine
     from .region import regions_mismatch_analysis
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if args.gpus is not None and args.gpus != world:
+        sys.exit('--gpus %d: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d -m lgmi.cli ...); '
+                 'WORLD_SIZE is %d' % (args.gpus, args.gpus, world))
+    group = None
+    if world > 1:
+        from .dist import group_from_env
+        group = group_from_env()                         # plain sockets: the RCCL id, barriers, small gathers
     sam = open_alignment(args.bam_file)
     genome = open_fasta(args.genome_fasta)
     vcf = open_variants(args.snp_bcf) if args.snp_bcf else None
@@ -149,6 +163,14 @@ def main(argv=None):
 
     logging.info('Get regions that are covered by enough reads.')
     footprints = get_footprints(sam, args.chromosomes, args.min_total_depth)
+    if world > 1:
+        # contiguous runs of footprints balanced by read count (the reference cuts the footprint list into contiguous
+        # chunks too, script/giremi.py:367-370): rank order stays footprint order, which is the output order
+        import numpy as np
+        cum = np.cumsum([f[3] for f in footprints]) if footprints else np.zeros(0)
+        total = float(cum[-1]) if len(cum) else 0.0
+        cuts = [int(np.searchsorted(cum, total * r / world, side='left')) for r in range(world)] + [len(footprints)]
+        footprints = footprints[cuts[rank]:cuts[rank + 1]]
     timing['open_and_footprints_s'] = time.perf_counter() - t0
     timing['n_footprints'] = len(footprints)
     t0 = time.perf_counter()
@@ -164,11 +186,22 @@ def main(argv=None):
     made = []
 
     def make_engine():                      # after the worker pool is gone: a HIP context does not survive fork()
-        made.append(Engine(args.device))
+        device = args.device
+        if device is None and world > 1:
+            import ctypes
+            from . import _lib
+            n_dev = ctypes.c_int(0)
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+            if _lib.load().lgmi_device_count(ctypes.byref(n_dev)) == 0 and n_dev.value > 0:
+                device %= n_dev.value
+        made.append(Engine(device))
+        if group is not None:
+            made[0].comm_init_group(group)
         return made[0]
     df_sites, df_mi, df_removed = regions_mismatch_analysis(
         jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
         engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta), timing=timing,
+        group=group,
         keep_non_spliced_read=args.keep_non_spliced_read,
         min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
         min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
@@ -178,15 +211,36 @@ def main(argv=None):
         mode=args.mode)
     t0 = time.perf_counter()
     strand_df = pd.DataFrame.from_records([], columns=['read_name', 'original_read_strand', 'corrected_read_strand'])
-    strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
-    df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
-    df_removed.to_csv(args.output_prefix + '.removed.txt', sep='\t', index=False)
+    if world > 1:
+        # every rank writes its part of the removed-site table next to the output; rank 0 stitches the parts in rank
+        # order (= footprint order) once all are there, and writes the gathered pair table
+        part = '%s.removed.txt.rank%d' % (args.output_prefix, rank)
+        df_removed.to_csv(part, sep='\t', index=False, header=(rank == 0))
+        group.barrier()
+        if rank == 0:
+            import shutil
+            with open(args.output_prefix + '.removed.txt', 'wb') as out:
+                for r in range(world):
+                    with open('%s.removed.txt.rank%d' % (args.output_prefix, r), 'rb') as f:
+                        shutil.copyfileobj(f, out)
+            for r in range(world):
+                os.remove('%s.removed.txt.rank%d' % (args.output_prefix, r))
+            strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
+            df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
+        group.barrier()
+    else:
+        strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
+        df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
+        df_removed.to_csv(args.output_prefix + '.removed.txt', sep='\t', index=False)
     timing['write_s'] = time.perf_counter() - t0
     for e in made:
         e.close()
     timing['total_s'] = time.perf_counter() - t_all
-    timing['mi_rows'], timing['site_rows'] = len(df_mi), len(df_sites)
-    if args.timing_json:
+    timing['mi_rows'], timing['site_rows'] = (len(df_mi) if df_mi is not None else 0), len(df_sites)
+    timing['rank'], timing['world'] = rank, world
+    if group is not None:
+        group.close()
+    if args.timing_json and rank == 0:
         import json
         with open(args.timing_json, 'w') as f:
             json.dump({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timing.items()}, f)

@@ -61,14 +61,15 @@ def _copy_result(res: _lib.Result, info: dict) -> MIResult:
 
 
 def make_params(min_common=5, n_shuffles=0, seed=0, het_only=True, emit_counts=False, exact_2x2=False,
-                shard=None, no_row_p=True) -> _lib.Params:
+                shard=None, no_row_p=True, stream_site_base=0) -> _lib.Params:
     """shard = (rank, world): compute only that contiguous, cost-balanced slice of the result rows.
     no_row_p (default): row_p is not made as an array when it is a function of row_exceed (MIResult.row_p derives it)"""
     if min_common < 0:
         min_common = 0
     rank, world = (0, 0) if shard is None else (int(shard[0]), int(shard[1]))
     return _lib.Params(int(min_common), int(n_shuffles), int(seed) & (2**64 - 1),
-                       1 if het_only else 0, 1 if emit_counts else 0, 1 if exact_2x2 else 0, 1 if no_row_p else 0, rank, world)
+                       1 if het_only else 0, 1 if emit_counts else 0, 1 if exact_2x2 else 0, 1 if no_row_p else 0, rank, world,
+                       int(stream_site_base), 0)
 
 
 def plan_shard(batch: PackedBatch, het_only=True, shard=(0, 1), n_shuffles=0) -> dict:
@@ -256,11 +257,12 @@ class Engine:
         return self.synth_dense(default_synth_spec(n_sites, n_reads, seed=seed, n_blocks=n_blocks))
 
     def run_device(self, dbatch: DeviceBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-                   emit_counts=False, exact_2x2=False, shard=None, rows_only=False, no_row_p=True) -> DeviceResult:
+                   emit_counts=False, exact_2x2=False, shard=None, rows_only=False, no_row_p=True,
+                   stream_site_base=0) -> DeviceResult:
         """rows_only=True stops when the rows (i, j, mi, tables, per-site means) are final; DeviceResult.permute()
         runs the permutation stage later — a multi-GPU host starts the row gather in between (comm_gather_begin)"""
         self._alive()
-        prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p), C.c_void_p()
+        prm, h = make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p, stream_site_base), C.c_void_p()
         fn = self.lib.lgmi_run_device_rows if rows_only else self.lib.lgmi_run_device
         _lib.check(fn(self.handle, dbatch.handle, C.byref(prm), C.byref(h)))
         return DeviceResult(self, h)

@@ -164,6 +164,65 @@ def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, eng
     return df, _site_means(batch, res, len(regions))
 
 
+def regions_pair_mi_table_dist(regions, group, engine: Engine, min_common_reads=5, n_shuffles=0, seed=0, root=0):
+    """regions_pair_mi_table when the footprints of a run were dealt to several ranks (one process per GPU; the
+    reference's analogue is the chunked Pool.map over footprints, src/giremi/script/giremi.py:367-394): every rank
+    packs and runs ITS regions, the pair rows of all ranks travel HBM-to-HBM onto `root` in rank order
+    (lgmi_comm_gather: RCCL, site indices shifted by each rank's site base), the site metadata the table needs
+    (positions, types, block boundaries, chromosome of every region) over the host-side group.  Ranks hold contiguous
+    runs of footprints, so rank order is footprint order.  -> (table on root / None elsewhere, this rank's [mean_mi])"""
+    import pandas as pd
+    from .pack import PackedBatch
+    regions = list(regions)
+    rank, world = group.get_rank(), group.get_world_size()
+    blocks = []
+    for mm, _chrom in regions:
+        blocks.extend(mm.get(s, {}) for s in ('+', '-'))
+    batch = pack_blocks(blocks) if blocks else pack_blocks([{}])
+    n_sites = len(batch.site_pos)
+    counts = group.allgather(int(n_sites))
+    base = int(sum(counts[:rank]))
+    db = engine.upload(batch)
+    dr = engine.run_device(db, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True,
+                           stream_site_base=base)       # pair for pair the permutation draws of the one batch holding every footprint
+    local = dr.fetch()                                   # per-site means of this rank's own footprints (small)
+    gathered, _begins = engine.comm_gather(dr, root=root, site_base=base, same_batch=False)
+    meta = group.gather({'pos': batch.site_pos, 'types': list(batch.type_names),
+                         'bsb': batch.block_site_begin.astype(np.int64), 'chroms': [c for _mm, c in regions]}, root)
+    means = _site_means(batch, local, len(regions)) if blocks else []
+    table = None
+    if rank == root:
+        g = gathered.fetch()
+        gathered.free()
+        pos = np.concatenate([np.asarray(m['pos'], np.int64) for m in meta]) if meta else np.zeros(0, np.int64)
+        names = np.array([t for m in meta for t in m['types']], dtype=object)
+        # global block boundaries and the chromosome of every region, in rank order
+        bsb, chroms, off = [np.zeros(1, np.int64)], [], 0
+        for m in meta:
+            b = np.asarray(m['bsb'], np.int64)
+            if len(m['chroms']):
+                bsb.append(b[1:] + off)
+                chroms.extend(m['chroms'])
+            off += len(m['pos'])
+        bsb = np.concatenate(bsb)
+        cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
+        if g.n_rows:
+            block = np.searchsorted(bsb, g.row_i.astype(np.int64), side='right') - 1
+            table = pd.DataFrame({'chromosome': np.array(chroms, dtype=object)[block >> 1],
+                                  'strand': np.array(['+', '-'], dtype=object)[block & 1],
+                                  'site1_pos': pos[g.row_i], 'site1_type': names[g.row_i],
+                                  'site2_pos': pos[g.row_j], 'site2_type': names[g.row_j], 'mi': g.row_mi}, columns=cols)
+            if n_shuffles:
+                table['p_perm'] = g.row_p
+        else:
+            table = pd.DataFrame({c: [] for c in cols})
+            if n_shuffles:
+                table['p_perm'] = []
+    dr.free()
+    db.free()
+    return table, means
+
+
 def region_pair_mi(mismatches_by_strand: dict, chromosome: str, min_common_reads=5, n_shuffles=0, seed=0,
                    engine: Optional[Engine] = None):
     """Batched MI block of ``region_mismatch_analysis`` (mismatch.py:384-418) for one footprint.

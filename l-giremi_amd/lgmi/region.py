@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import pandas as pd
 
-from .mutual_information import region_pair_mi, regions_pair_mi, regions_pair_mi_table
+from .mutual_information import region_pair_mi, regions_pair_mi, regions_pair_mi_table, regions_pair_mi_table_dist
 
 _CS_TOKEN = re.compile(r'([:*+\-~])([0-9a-z]+)')
 _COMPLEMENT = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N'}
@@ -299,7 +299,7 @@ def _extract_chunk(job, sam=None, genome=None):
 
 
 def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
-                              concat=False, threads=1, reopen=None, timing=None, **filter_kwargs):
+                              concat=False, threads=1, reopen=None, timing=None, group=None, **filter_kwargs):
     """``region_mismatch_analysis`` over many footprints with ONE GPU batch for all their MI blocks — the shape the
     reference's per-chunk loop (src/giremi/script/giremi.py:32-88) takes when the MI step is a device call.
 
@@ -333,8 +333,14 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     if concat:
         # a whole run: the pair table column by column from the result arrays, the two site tables from one row list each
         # (a DataFrame per footprint and a concat of thousands of them was most of the host time on 2,000 footprints)
-        df_pairs, means = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in staged], min_common_reads,
-                                                n_shuffles=n_shuffles, seed=seed, engine=engine)
+        if group is not None and group.get_world_size() > 1:
+            # several ranks, each with its own contiguous run of footprints: the pair rows are gathered over RCCL onto
+            # rank 0 (df_pairs is None elsewhere); the two site tables stay per rank (the caller concatenates them)
+            df_pairs, means = regions_pair_mi_table_dist([(sites, chrom) for chrom, sites, _gone in staged], group, engine,
+                                                         min_common_reads, n_shuffles=n_shuffles, seed=seed)
+        else:
+            df_pairs, means = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in staged], min_common_reads,
+                                                    n_shuffles=n_shuffles, seed=seed, engine=engine)
         if timing is not None:
             timing['pack_gpu_table_s'] = time.perf_counter() - t0
             t0 = time.perf_counter()

@@ -107,6 +107,13 @@ def run_cli_and_compare(tmp_path, extra=()):
     prefix = str(tmp_path / 'out')
     cli.main(['-b', bam, '-c', 'chrA', 'chrB', '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
               '--mi_calculation_only', '--skip_strand_correction'] + list(extra))
+    return compare_cli_outputs(prefix)
+
+
+def compare_cli_outputs(prefix):
+    """PREFIX.mi.txt / .removed.txt / .strand.txt of a run on regions_fixture() against tests/golden/cli.json"""
+    from conftest import load_golden
+    gold = load_golden('cli.json')['cases']
     mi = pd.read_table(prefix + '.mi.txt')
     removed = pd.read_table(prefix + '.removed.txt')
     strand = pd.read_table(prefix + '.strand.txt')

@@ -109,3 +109,34 @@ def test_bench_two_ranks_without_a_communicator_is_not_a_success():
     assert r.returncode != 0
     assert line and line['degraded'] == 'rccl_init_failed' and line['value'] is None and line['kernel_only_value'] > 0
     assert 'NOT gathered' in line['config']['gather']
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_cli_on_several_ranks_writes_the_reference_tables(fake_rccl, tmp_path, world):
+    """lgmi.cli under torch.distributed.run (--gpus N): footprints dealt to the ranks in contiguous runs, every rank
+    extracts and computes its own, the pair rows gathered over the communicator onto rank 0 (here the stand-in, all
+    ranks on the one GPU; world 3 leaves a rank without footprints) — the files rank 0 writes are the single-process
+    ones, i.e. what the reference's footprint_bulk_calculation computes (tests/golden/cli.json)"""
+    sys.path.insert(0, HERE)
+    from test_cli import compare_cli_outputs, regions_fixture, write_inputs
+    root = os.path.dirname(HERE)
+    bam, fa, vcf = write_inputs(tmp_path, regions_fixture())
+    prefix = str(tmp_path / 'out')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), '-m', 'lgmi.cli', '-b', bam, '-c', 'chrA', 'chrB', '-o', prefix, '--genome_fasta', fa,
+           '--snp_bcf', vcf, '--mi_calculation_only', '--skip_strand_correction', '--gpus', str(world), '--device', '0',
+           '--n_shuffles', '20', '--seed', '4']
+    env = dict(os.environ, LGMI_RCCL_LIB=fake_rccl, LGMI_ALLOW_RCCL_STANDIN='1',
+               PYTHONPATH=os.path.join(root, 'l-giremi_amd') + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    mi = compare_cli_outputs(prefix)
+    assert list(mi.columns)[7:] == ['p_perm'] and ((mi['p_perm'] > 0) & (mi['p_perm'] <= 1)).all()
+    assert not [f for f in os.listdir(tmp_path) if '.rank' in f]          # the per-rank parts are gone
+    # the same p-values as one process computes (the Philox streams are keyed by the pair, not by the rank)
+    from lgmi import cli
+    one = str(tmp_path / 'one')
+    cli.main(['-b', bam, '-c', 'chrA', 'chrB', '-o', one, '--genome_fasta', fa, '--snp_bcf', vcf, '--mi_calculation_only',
+              '--skip_strand_correction', '--n_shuffles', '20', '--seed', '4'])
+    import pandas as pd
+    pd.testing.assert_frame_equal(pd.read_table(one + '.mi.txt'), pd.read_table(prefix + '.mi.txt'))

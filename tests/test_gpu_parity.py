@@ -575,3 +575,23 @@ def test_row_p_array_is_optional_and_equal_to_the_derived_one(engine):
     assert ex._row_p is not None and not ex._p_derived            # exact p is not a function of exceed
     dr.free()
     db.free()
+
+
+def test_stream_site_base_shifts_the_philox_counters(engine):
+    """lgmi_params.stream_site_base: the permutation draws of a pair are keyed by its two site indices PLUS the base, so a
+    rank that runs footprints k.. of a run as a batch of its own reproduces the draws of the one batch that holds them
+    all — checked against the CPU specification fed the shifted indices"""
+    from oracle import c_oracle
+    pb = random_batch(4242, n_blocks=3, P=(4, 50), R=(30, 600), tri_frac=0.3)
+    kw = dict(min_common=3, n_shuffles=60, seed=11, het_only=True, emit_counts=True)
+    db = engine.upload(pb)
+    base = 12345
+    plain = engine.run_device(db, **kw)
+    shifted = engine.run_device(db, stream_site_base=base, **kw)
+    a, b = plain.fetch(), shifted.fetch()
+    plain.free(); shifted.free(); db.free()
+    np.testing.assert_array_equal(a.row_i, b.row_i)
+    np.testing.assert_array_equal(a.row_counts, b.row_counts)
+    _p, want = c_oracle.perm_rows(b.row_i + np.uint32(base), b.row_j + np.uint32(base), b.row_counts, 60, 11)
+    np.testing.assert_array_equal(b.row_exceed, want)
+    assert (a.row_exceed != b.row_exceed).any()
