@@ -99,6 +99,15 @@ int  lgio_bam_build_index(const char* bam_path, const char* bai_path_or_null);
 int  lgio_bam_fetch(lgio_bam* bam, int tid, int64_t start, int64_t end, uint32_t what, lgio_reads* out);
 void lgio_reads_free(lgio_reads* reads);
 
+/* Where this pile-up differs from pysam's AlignmentFile.pileup(contig, start, stop) with its defaults, which is what
+ * the reference calls (src/giremi/mismatch.py:161) — none of it can show on the single-end long reads L-GIREMI is made
+ * for, all of it would on paired short reads:
+ *   - overlapping mates: htslib (ignore_overlaps=True) zeroes one mate's base quality where the two overlap, so that
+ *     base is dropped; here both mates are emitted;
+ *   - deletion / reference-skip entries are not subject to min_base_quality (htslib tests the quality at the query
+ *     position next to them);
+ *   - max_depth caps each column after filtering; htslib caps the reads entering the pile-up.
+ * No entry point lets an exception out: allocation failures come back as LGIO_E_OOM. */
 int  lgio_bam_pileup(lgio_bam* bam, int tid, int64_t start, int64_t end, int min_base_quality, int max_depth,
                      lgio_pileup* out);
 void lgio_pileup_free(lgio_pileup* pile);

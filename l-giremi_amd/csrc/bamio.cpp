@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <stdexcept>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -225,6 +227,7 @@ int read_header(lgio_bam* b) {
     if (memcmp(magic, "BAM\1", 4) != 0) return fail(LGIO_E_FORMAT, "%s is not a BAM file", b->path.c_str());
     if ((rc = b->z.read(w, 4))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
     const uint32_t l_text = le32(w);
+    if (l_text > (1u << 30)) return fail(LGIO_E_FORMAT, "header text of %u bytes refused", l_text);
     b->header_text.resize(l_text);
     if (l_text && (rc = b->z.read(&b->header_text[0], l_text))) return rc < 0 ? rc : fail(LGIO_E_FORMAT, "truncated header");
     while (!b->header_text.empty() && b->header_text.back() == '\0') b->header_text.pop_back();
@@ -450,25 +453,38 @@ int for_each_overlap(lgio_bam* b, int tid, int64_t beg, int64_t end, F fn) {
 extern "C" int lgio_abi_version(void) { return LGIO_ABI_VERSION; }
 extern "C" const char* lgio_last_error(void) { return g_err.c_str(); }
 
-extern "C" int lgio_bam_open(const char* path, lgio_bam** out) {
+static int bam_open_impl(const char* path, lgio_bam** out) {
     if (!path || !out) return fail(LGIO_E_ARG, "NULL argument");
     *out = nullptr;
     lgio_bam* b = new lgio_bam();
+    struct Drop { lgio_bam* p; ~Drop() { delete p; } } drop{b};     // (also on an exception)
     b->path = path;
     b->z.f = fopen(path, "rb");
-    if (!b->z.f) { delete b; return fail(LGIO_E_IO, "cannot open %s", path); }
+    if (!b->z.f) return fail(LGIO_E_IO, "cannot open %s", path);
     int rc = read_header(b);
-    if (rc) { delete b; return rc; }
+    if (rc) return rc;
     std::string stem = b->path;
     if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".bam") == 0) stem.resize(stem.size() - 4);
     rc = load_bai(b->path + ".bai", b->ref_names.size(), b->index);
     if (rc == 1) rc = load_bai(stem + ".bai", b->ref_names.size(), b->index);
-    if (rc < 0) { delete b; return rc; }
+    if (rc < 0) return rc;
     b->index_from_file = (rc == 0);
-    if (rc == 1 && (rc = scan_index(b, b->index))) { delete b; return rc; }
+    if (rc == 1 && (rc = scan_index(b, b->index))) return rc;
+    drop.p = nullptr;
     *out = b;
     return LGIO_OK;
 }
+
+// No exception crosses the C boundary (ctypes cannot unwind one): allocation failures of the header text, the record
+// buffer, the pile-up's span-sized arrays come back as LGIO_E_OOM, anything else as LGIO_E_FORMAT
+template <class F> static int guarded(F f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(LGIO_E_OOM, "out of memory"); }
+    catch (const std::length_error&) { return fail(LGIO_E_OOM, "out of memory (length)"); }
+    catch (const std::exception& e) { return fail(LGIO_E_FORMAT, "%s", e.what()); }
+    catch (...) { return fail(LGIO_E_FORMAT, "unknown error"); }
+}
+extern "C" int lgio_bam_open(const char* path, lgio_bam** out) { return guarded([&] { return bam_open_impl(path, out); }); }
 
 extern "C" void lgio_bam_close(lgio_bam* b) { delete b; }
 extern "C" int lgio_bam_n_refs(const lgio_bam* b) { return b ? (int)b->ref_names.size() : 0; }
@@ -482,7 +498,7 @@ extern "C" const char* lgio_bam_header_text(const lgio_bam* b) { return b ? b->h
 extern "C" int lgio_bam_has_index_file(const lgio_bam* b) { return b && b->index_from_file ? 1 : 0; }
 extern "C" uint64_t lgio_bam_bytes_read(const lgio_bam* b) { return b ? b->z.bytes_read : 0; }
 
-extern "C" int lgio_bam_build_index(const char* bam_path, const char* bai_path) {
+static int build_index_impl(const char* bam_path, const char* bai_path) {
     if (!bam_path) return fail(LGIO_E_ARG, "NULL argument");
     lgio_bam b;
     b.path = bam_path;
@@ -494,6 +510,9 @@ extern "C" int lgio_bam_build_index(const char* bam_path, const char* bai_path) 
     if ((rc = scan_index(&b, idx))) return rc;
     return write_bai(bai_path ? std::string(bai_path) : b.path + ".bai", idx);
 }
+extern "C" int lgio_bam_build_index(const char* bam_path, const char* bai_path) {
+    return guarded([&] { return build_index_impl(bam_path, bai_path); });
+}
 
 extern "C" void lgio_reads_free(lgio_reads* r) {
     if (!r) return;
@@ -501,14 +520,19 @@ extern "C" void lgio_reads_free(lgio_reads* r) {
     memset(r, 0, sizeof *r);
 }
 
-extern "C" int lgio_bam_fetch(lgio_bam* b, int tid, int64_t start, int64_t end, uint32_t what, lgio_reads* out) {
+static int fetch_impl(lgio_bam* b, int tid, int64_t start, int64_t end, uint32_t what, lgio_reads* out) {
     if (!b || !out) return fail(LGIO_E_ARG, "NULL argument");
     memset(out, 0, sizeof *out);
     ReadsOwner* o = new ReadsOwner();
+    struct Drop { ReadsOwner* p; ~Drop() { delete p; } } drop{o};
     const int rc = for_each_overlap(b, tid, start, end, [&](const Record& r) { o->add(r, what); });
-    if (rc) { delete o; return rc; }
+    if (rc) return rc;
     o->view(out);
+    drop.p = nullptr;
     return LGIO_OK;
+}
+extern "C" int lgio_bam_fetch(lgio_bam* b, int tid, int64_t start, int64_t end, uint32_t what, lgio_reads* out) {
+    return guarded([&] { return fetch_impl(b, tid, start, end, what, out); });
 }
 
 namespace {
@@ -521,11 +545,12 @@ extern "C" void lgio_pileup_free(lgio_pileup* p) {
     memset(p, 0, sizeof *p);
 }
 
-extern "C" int lgio_bam_pileup(lgio_bam* b, int tid, int64_t start, int64_t end, int min_bq, int max_depth, lgio_pileup* out) {
+static int pileup_impl(lgio_bam* b, int tid, int64_t start, int64_t end, int min_bq, int max_depth, lgio_pileup* out) {
     if (!b || !out) return fail(LGIO_E_ARG, "NULL argument");
     memset(out, 0, sizeof *out);
     if (max_depth <= 0) max_depth = 8000;
     PileOwner* o = new PileOwner();
+    struct Drop { PileOwner* p; ~Drop() { delete p; } } drop{o};
     // pass 1: the reads (records kept whole: the second pass walks their CIGARs)
     std::vector<Record> recs;
     int rc = for_each_overlap(b, tid, start, end, [&](const Record& r) {
@@ -533,10 +558,13 @@ extern "C" int lgio_bam_pileup(lgio_bam* b, int tid, int64_t start, int64_t end,
         if ((r.flag & 1) && !(r.flag & 2)) return;              // orphan of a paired read
         recs.push_back(r);
     });
-    if (rc) { delete o; return rc; }
+    if (rc) return rc;
     if (!recs.empty()) {
         int64_t lo = recs[0].pos, hi = recs[0].end;
         for (const Record& r : recs) { lo = std::min(lo, r.pos); hi = std::max(hi, r.end); }
+        // three arrays of this length are made below: a region's reads spanning more than 2^31 positions is not a
+        // footprint any caller of this path produces (a chromosome is < 2^28), and not something to try to allocate
+        if (hi - lo > (int64_t)1 << 31) return fail(LGIO_E_ARG, "pile-up over %lld reference positions refused", (long long)(hi - lo));
         const size_t span = (size_t)(hi - lo);
         // columns are not truncated to [start, end): every position any of the reads aligns to
         std::vector<uint32_t> depth(span, 0);
@@ -580,5 +608,9 @@ extern "C" int lgio_bam_pileup(lgio_bam* b, int tid, int64_t start, int64_t end,
     out->n_cols = o->pos.size();
     out->pos = o->pos.data(); out->col_off = o->col_off.data(); out->read = o->read.data(); out->base = o->base.data();
     out->owner_ = o;
+    drop.p = nullptr;
     return LGIO_OK;
+}
+extern "C" int lgio_bam_pileup(lgio_bam* b, int tid, int64_t start, int64_t end, int min_bq, int max_depth, lgio_pileup* out) {
+    return guarded([&] { return pileup_impl(b, tid, start, end, min_bq, max_depth, out); });
 }

@@ -20,7 +20,18 @@ __global__ void k_ecdf_eval(uint64_t n_query, const double* __restrict__ query, 
         const uint32_t mid = (lo + hi) >> 1;
         if (sorted[mid] < v) lo = mid + 1; else hi = mid;
     }
-    out[q] = (double)lo / (double)m;
+    // the reference does not divide: y = concatenate([0], linspace(1/n, 1, n)) and returns y[idx] (stat.py:19,26-27).
+    // numpy's linspace is start + arange(n) * step with step = (stop - start) / (n - 1), the last element set to stop:
+    // the same three roundings here (no contraction: -ffp-contract=off), so the value is the reference's bit for bit
+    double y;
+    if (lo == 0u) y = 0.0;
+    else if (lo == m) y = 1.0;
+    else {
+        const double start = 1.0 / (double)m;
+        const double step = (1.0 - start) / (double)(m - 1u);
+        y = (double)(lo - 1u) * step + start;
+    }
+    out[q] = y;
 }
 
 size_t ecdf_sort_temp_bytes(uint32_t n) {

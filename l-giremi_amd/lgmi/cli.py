@@ -24,6 +24,7 @@ import logging
 import sys
 from collections import defaultdict
 
+import numpy as np
 import pandas as pd
 
 from . import __version__
@@ -67,6 +68,10 @@ def parse_args(argv=None):
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--device', type=int, default=None, help='GPU index (default: LGMI_DEVICE / LOCAL_RANK / 0)')
     p.add_argument('--timing_json', type=str, default=None, help='write the wall time of every stage of the run to this file')
+    p.add_argument('--mip_table', action='store_true',
+                   help='also write PREFIX.mismatch_mip.txt: the mismatch table with mean_mi and the reference\'s own p-value '
+                        'column mip (ECDF of the het-SNP mean MI, script/giremi.py:415-429) — the table the reference hands to '
+                        'its GLM, which is not part of lgmi; works with or without --mi_calculation_only')
     p.add_argument('--gpus', type=int, default=None,
                    help='ranks of a multi-GPU run (launch with python -m torch.distributed.run --nproc-per-node N -m lgmi.cli ... ; '
                         'default WORLD_SIZE): footprints are dealt to the ranks in contiguous, read-balanced runs, every rank '
@@ -134,8 +139,9 @@ def read_repeats(path):
 def main(argv=None):
     args = parse_args(argv)
     logging.basicConfig(format='%(asctime)s %(levelname)s %(message)s', level=logging.INFO)
-    if not args.mi_calculation_only:
-        sys.exit('lgmi covers the MI step: run with --mi_calculation_only (GLM scoring, stat.py:32-143, is not part of it)')
+    if not args.mi_calculation_only and not args.mip_table:
+        sys.exit('lgmi covers the MI step: run with --mi_calculation_only, or with --mip_table for the mismatch table with mean_mi '
+                 'and mip that the reference builds before its GLM (GLM scoring, stat.py:32-143, is not part of lgmi)')
     if not args.skip_strand_correction:
         sys.exit('GTF-based strand correction (strand.py) is not part of lgmi: run with --skip_strand_correction')
     if not args.genome_fasta:
@@ -166,7 +172,6 @@ def main(argv=None):
     if world > 1:
         # contiguous runs of footprints balanced by read count (the reference cuts the footprint list into contiguous
         # chunks too, script/giremi.py:367-370): rank order stays footprint order, which is the output order
-        import numpy as np
         cum = np.cumsum([f[3] for f in footprints]) if footprints else np.zeros(0)
         total = float(cum[-1]) if len(cum) else 0.0
         cuts = [int(np.searchsorted(cum, total * r / world, side='left')) for r in range(world)] + [len(footprints)]
@@ -232,6 +237,24 @@ def main(argv=None):
         strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
         df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
         df_removed.to_csv(args.output_prefix + '.removed.txt', sep='\t', index=False)
+    if args.mip_table:
+        # script/giremi.py:415-429: mip = ECDF of the het-SNP rows' mean_mi (those that have one) at every row's mean_mi.
+        # Several ranks: the ECDF needs every rank's het-SNP means — the site tables go to rank 0 through the socket group.
+        from .stat import mean_mi_to_mip
+        table = df_sites
+        if world > 1:
+            parts = group.gather({c: (df_sites[c].to_numpy(np.float64) if df_sites[c].dtype.kind in 'fiu' else df_sites[c].astype(str).tolist())
+                                  for c in df_sites.columns})
+            if rank == 0:
+                table = pd.concat([pd.DataFrame(p_, columns=df_sites.columns) for p_ in parts], axis=0, ignore_index=True)
+                for c in ('pos', 'depth'):
+                    table[c] = table[c].astype(np.int64)
+        if rank == 0:
+            table = table.copy()
+            eng = made[0] if made else None
+            table['mip'] = mean_mi_to_mip(table['mean_mi'].to_numpy(np.float64), table['type'].to_numpy(), engine=eng) \
+                if len(table) else np.zeros(0)
+            table.to_csv(args.output_prefix + '.mismatch_mip.txt', sep='\t', index=False)
     timing['write_s'] = time.perf_counter() - t0
     for e in made:
         e.close()

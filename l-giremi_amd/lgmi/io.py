@@ -281,6 +281,9 @@ class BamReader:
             yield BamRead(t, k)
 
     def pileup(self, contig=None, start=None, stop=None, min_base_quality=13, max_depth=8000):
+        """columns as pysam's pileup(contig, start, stop) yields them for single-end (long) reads.  Paired short reads
+        would differ: overlapping mates are both emitted (htslib drops one), deletion / reference-skip entries bypass
+        min_base_quality, max_depth caps columns rather than incoming reads — include/lgmi_io.h lists the three."""
         tid = self._tid.get(contig)
         if tid is None:
             return

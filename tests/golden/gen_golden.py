@@ -417,6 +417,38 @@ def cli_cases():
     return out
 
 
+def cli_mip_cases(with_cfg1=True):
+    """the mismatch table with the reference's own p-value column `mip` as script/giremi.py:415-429 builds it just before
+    the GLM: region_mismatch_analysis per footprint, frames concatenated in footprint order (:79-88, :381-394), then
+    miecdf = stat.ecdf(mean_mi of the het_snp rows that have one) applied to every row's mean_mi (NaN stays NaN).
+    The ten lines of main() that do this cannot be imported (script/giremi.py needs pysam): they are restated here
+    around the reference's OWN stat.ecdf and mismatch.region_mismatch_analysis.  Round 3."""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from fakes import FakeGenome, FakeSamSkips, simulate_region
+    ref_mm = load_ref_mismatch()
+
+    def run(regions):
+        frames = []
+        for contig, sim_kw in regions:
+            reads, genome, snps, _ = simulate_region(**sim_kw)
+            lo, hi = min(r.reference_start for r in reads), max(r.reference_end for r in reads)
+            snp_in = sorted(p for p in snps if lo <= p < hi)
+            dfs = ref_mm.region_mismatch_analysis(contig, lo, hi, FakeSamSkips(reads), FakeGenome(genome),
+                                                  simple_repeat_intervals=[], snp_positions=snp_in, **CLI_KWARGS)
+            frames.append(dfs[0])
+        df = pd.concat(frames, axis=0)
+        df.loc[:, 'mip'] = np.nan
+        if df['mean_mi'].notna().sum() > 0:
+            miecdf = ref_stat.ecdf(df.loc[df['mean_mi'].notna() & (df['type'] == 'het_snp'), 'mean_mi'])
+            df.loc[:, 'mip'] = df.apply(lambda a: miecdf(a['mean_mi']) if not np.isnan(a['mean_mi']) else np.nan, axis=1)
+        return frame_json(df)
+    out = {'cli': {'regions': [c for c, _k in CLI_REGIONS], 'mismatch_mip': run(CLI_REGIONS)}}
+    if with_cfg1:
+        out['cfg1'] = {'regions': [CFG1_REGION[0]], 'mismatch_mip': run([CFG1_REGION])}
+    return out
+
+
 def splice_tables(seed, n_reads, n_sites, n_splice, dup=False):
     """synthetic read-site / read-splice tables for calculate_site_splice_mi.py"""
     import pandas as pd
@@ -479,6 +511,10 @@ def main():
     if '--only-cli-cfg1' in sys.argv:   # added in round 2 (several minutes: the reference examines ~1e5 pairs at depth 2,000)
         with open(os.path.join(HERE, 'cli_cfg1.json'), 'w') as f:
             json.dump({'meta': meta, 'case': cli_cfg1_case()}, f)
+        return
+    if '--only-cli-mip' in sys.argv:    # added in round 3 (the cfg1 part takes the reference several minutes)
+        with open(os.path.join(HERE, 'cli_mip.json'), 'w') as f:
+            json.dump({'meta': meta, 'cases': cli_mip_cases('--no-cfg1' not in sys.argv)}, f)
         return
     if '--only-cli' in sys.argv:        # added in round 2: leaves the round-1 fixtures byte-for-byte as they are
         with open(os.path.join(HERE, 'cli.json'), 'w') as f:

@@ -250,3 +250,66 @@ def test_cli_cfg1_mi_calculation_only(tmp_path):
               '--mi_calculation_only', '--skip_strand_correction', '--n_shuffles', '100', '--seed', '5'])
     mi = check_cfg1(prefix, gold)
     assert ((mi['p_perm'] >= 1 / 101 - 1e-12) & (mi['p_perm'] <= 1)).all()          # (read back from text)
+
+
+def _compare_mip_table(path, gold):
+    """PREFIX.mismatch_mip.txt against the reference's mismatch table + mip (tests/golden/cli_mip.json: the reference's
+    region_mismatch_analysis and stat.ecdf, put together as script/giremi.py:415-429 does)"""
+    got = pd.read_table(path, keep_default_na=False, na_values=[''])
+    exp = pd.DataFrame(gold['data'], columns=gold['columns'])
+    assert list(got.columns) == gold['columns'] and len(got) == len(exp) > 0
+    for c in gold['columns']:
+        if c in ('ratio', 'allelic_ratio_diff', 'mean_mi', 'mip'):
+            a, b = got[c].to_numpy(np.float64), exp[c].to_numpy(np.float64)
+            assert (np.isnan(a) == np.isnan(b)).all(), c
+            bad = np.nonzero(~np.isclose(a, b, atol=1e-6, rtol=0, equal_nan=True))[0]
+            if c == 'mip' and len(bad):
+                # mip is a RANK among the het-SNP means: a row may differ from the reference by steps of 1/n only where
+                # het-SNP means lie within the MI tolerance of its own mean_mi (here: 1e-9) and so may swap ranks
+                het = exp.loc[(exp['type'] == 'het_snp') & exp['mean_mi'].notna(), 'mean_mi'].to_numpy(np.float64)
+                for k in bad:
+                    near = int((np.abs(het - exp['mean_mi'][k]) <= 1e-9).sum())
+                    assert near >= 1 and abs(a[k] - b[k]) <= (near + 0.5) / len(het), (int(k), a[k], b[k], near)
+                assert len(bad) <= 0.05 * len(a)
+            else:
+                assert len(bad) == 0, (c, bad[:5])
+        else:
+            assert got[c].astype(str).tolist() == exp[c].astype(str).tolist(), c
+    # mip is the reference's own arithmetic (numpy linspace values picked by rank, stat.py:19-27; lgmi_ecdf restates it):
+    # the written column equals the reference's, written the same way (pandas prints 16 significant digits), exactly —
+    # unless two mean_mi that differ within the MI tolerance swap ranks
+    import io
+    buf = io.StringIO()
+    exp[['mip']].to_csv(buf, sep='\t', index=False)
+    want = pd.read_table(io.StringIO(buf.getvalue()))['mip'].to_numpy(np.float64)
+    m = ~np.isnan(want)
+    assert m.any() and np.mean(got['mip'].to_numpy(np.float64)[m] == want[m]) > 0.94
+
+
+@pytest.mark.gpu
+def test_cli_mip_table(tmp_path):
+    """--mip_table: the reference's own p-value end to end — mean MI per site from the GPU, ECDF of the het-SNP means
+    (lgmi_ecdf), the table the reference hands to its GLM"""
+    from conftest import load_golden
+    from lgmi import cli
+    gold = load_golden('cli_mip.json')['cases']['cli']['mismatch_mip']
+    bam, fa, vcf = write_inputs(tmp_path, regions_fixture())
+    prefix = str(tmp_path / 'out')
+    cli.main(['-b', bam, '-c', 'chrA', 'chrB', '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
+              '--skip_strand_correction', '--mip_table'])                       # without --mi_calculation_only: allowed with --mip_table
+    compare_cli_outputs(prefix)
+    _compare_mip_table(prefix + '.mismatch_mip.txt', gold)
+
+
+@pytest.mark.gpu
+def test_cli_cfg1_mip_table(tmp_path):
+    from conftest import load_golden
+    cases = load_golden('cli_mip.json')['cases']
+    if 'cfg1' not in cases:
+        pytest.skip('cfg1 part of tests/golden/cli_mip.json not generated')
+    from lgmi import cli
+    gold, bam, fa, vcf = cfg1_inputs(tmp_path)
+    prefix = str(tmp_path / 'cfg1')
+    cli.main(['-b', bam, '-c', gold['contig'], '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
+              '--mi_calculation_only', '--skip_strand_correction', '--mip_table'])
+    _compare_mip_table(prefix + '.mismatch_mip.txt', cases['cfg1']['mismatch_mip'])

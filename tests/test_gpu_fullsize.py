@@ -82,6 +82,17 @@ def test_full_size_properties(engine, n_sites, n_reads, n_shuffles):
         assert abs(mi_numpy(tab) - res.row_mi[r]) <= 1e-6
     # MI is symmetric in the two sites and bounded by ln 3
     assert res.row_mi.min() >= 0.0 and res.row_mi.max() <= np.log(3) + 1e-12
+    # the pattern of EXACT zeros (scikit-learn returns exactly 0.0 for a one-class side, zeroes terms below eps and
+    # clips at 0; the kernel's table-driven logarithm must not move which rows land there): every degenerate table is
+    # exactly 0.0, and every other exactly-zero row as well as the sampled rows agree with the C oracle's value of the
+    # same table — zero where it is zero, within 1e-12 elsewhere
+    from oracle import c_oracle
+    zero = res.row_mi == 0.0
+    degen = ((res.row_counts.sum(axis=2) > 0).sum(axis=1) <= 1) | ((res.row_counts.sum(axis=1) > 0).sum(axis=1) <= 1)
+    assert zero[degen].all()
+    for r in np.concatenate([np.nonzero(zero & ~degen)[0][:5000], sample]):
+        o = c_oracle.mi_from_table(res.row_counts[r])
+        assert (o == 0.0) == (res.row_mi[r] == 0.0) and abs(o - res.row_mi[r]) <= 1e-12, (int(r), o, res.row_mi[r])
     # per-site mean MI equals the mean over the rows touching the site
     sums = np.bincount(i, res.row_mi, P) + np.bincount(j, res.row_mi, P)
     cnts = np.bincount(i, minlength=P) + np.bincount(j, minlength=P)

@@ -387,8 +387,8 @@ def test_ecdf_matches_reference_vectors(engine):
     for c in load_golden('ecdf.json')['cases']:
         f = lgmi.ecdf(c['sample'], engine=engine)
         got = f(np.array(c['query']))
-        assert np.max(np.abs(got - np.array(c['value']))) <= 1e-12
-        assert abs(f(c['query'][0]) - c['value'][0]) <= 1e-12          # scalar call
+        np.testing.assert_array_equal(got, np.array(c['value']))      # the reference's linspace arithmetic, bit for bit
+        assert f(c['query'][0]) == c['value'][0]                       # scalar call
     with pytest.raises(ZeroDivisionError):
         lgmi.ecdf([], engine=engine)
 
