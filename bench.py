@@ -46,6 +46,9 @@ WORKLOADS = {
     'footprints_20k': dict(n_sites=0, n_reads=0, regime='footprints', n_footprints=20_000),
     # twice the north-star's sites in ONE block: 1.8e9 rows, ~160 GB of HBM in use — the headroom case (not a BASELINE config)
     'headroom_dense_100kx200k': dict(n_sites=100_000, n_reads=200_000),
+    # three times the sites: 4.05e9 candidate rows — more than the permutation kernels' 32-bit row numbers and more than one
+    # launch sequence's row arrays fit: lgmi_run_device cuts it into sequential shards by itself (lgmi_run_info.n_seq_shards)
+    'headroom_dense_150kx200k': dict(n_sites=150_000, n_reads=200_000),
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # non-packed VALU: one wave64 instruction per 4 cycles per SIMD (MI355X_MICROARCH.md 'vector-instruction ISSUE
@@ -306,6 +309,7 @@ def main():
                 'stage_ms': {k: sum(i.get(k, 0.0) for i in infos) / len(infos)
                              for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
                                        'ms_perm_general', 'ms_mean', 'ms_gather')},
+                'n_seq_shards': info.get('n_seq_shards', 1),   # > 1: lgmi_run_device split the run to fit its memory budget
             }
             if world > 1 or args.force_gather:
                 out['per_rank'] = per_rank

@@ -408,6 +408,9 @@ static int dev_copy_new(T** dptr, const T* h, size_t n, hipStream_t st) {
     return LGMI_OK;
 }
 
+// (Round 3 tried a staged upload of the bit planes — threads copying 32-MB pieces into pinned buffers ahead of the DMA
+//  engine — against the plain hipMemcpyAsync from the caller's pageable array: 700 ms host-to-host against 495 ms on the
+//  same box, gpurun_out/exp_upload.txt; the runtime's own path moves the 2.5 GB at ~50 GB/s.  Not kept.)
 extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch** out) {
     if (!ctx || !out) return fail(LGMI_E_ARG, "ctx/out is NULL");
     *out = nullptr;
@@ -1039,9 +1042,13 @@ static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* 
     const double rows_final = (double)pl.n_examined * (double)row_bytes_final(want_p, keep_p, want_counts);
     int k = 1;
     if (fixed + rows_work > budget) {
-        const double room = budget - fixed - rows_final;
+        // what is left for a shard's own row arrays once the slot matrix, the operands and the final rows are in;
+        // when those three alone exceed the budget (they are floors: the slot matrix keeps its full addressing and the
+        // final rows are what the caller asked for) the shards are sized to a quarter of it
+        double room = budget - fixed - rows_final;
+        if (room < 0.25 * budget) room = 0.25 * budget;
         // shards are balanced by cost, not by row count: leave a third of slack on the estimate
-        k = room > 0.0 ? (int)std::ceil(1.35 * rows_work / room) : 64;
+        k = (int)std::ceil(1.35 * rows_work / room);
     }
     if (want_p && pl.n_examined >= 0xFFFFFFFFull)
         k = std::max<int>(k, (int)(pl.n_examined / 0xC0000000ull) + 1);
