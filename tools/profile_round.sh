@@ -3,8 +3,8 @@
 # MI355X box:   bash tools/profile_round.sh r02 [workload]
 set -eu
 R=${1:-r02}; WL=${2:-north_star_dense_50kx200k}
-ROOT=$PWD; OUT=$ROOT/gpurun_out/prof_$R
-mkdir -p $OUT $ROOT/profiles
+ROOT=$PWD; OUT=$ROOT/gpurun_out/prof_${R}_$WL
+rm -rf $OUT; mkdir -p $OUT $ROOT/profiles $ROOT/gpurun_out/profiles_$R
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --workload $WL --no-cpu-baseline --no-host-to-host"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.json 2> $OUT/trace.log
@@ -19,4 +19,6 @@ DRAWS=$(python3 -c "import json; d=json.load(open('$OUT/sq.json')); print(d['per
 ROWS=$(python3 -c "import json; d=json.load(open('$OUT/sq.json')); print(d['perm_roofline']['two_by_two_rows'])")
 python3 tools/pmc_summary.py sq $WL $OUT/sq $DRAWS $ROWS profiles/${R}_pmc_sq_perm.json
 cp $OUT/trace.json profiles/${R}_bench_under_rocprof_${WL}.json
+# gpurun merges only gpurun_out/ back: the summaries travel there (copy them into profiles/ and commit)
+cp profiles/${R}_${WL}_kernel_stats.csv profiles/${R}_pmc_k_count.json profiles/${R}_pmc_sq_perm.json profiles/${R}_bench_under_rocprof_${WL}.json gpurun_out/profiles_$R/
 echo "profiles written:"; ls -la profiles | grep $R
