@@ -39,18 +39,20 @@
 //    8 threshold-table draw replaced by a cheap hash      16 general rows not queued (k_perm_fast alone)
 //   32 exact-tail sums skipped      64 bisection skipped      128 binomial draw skipped
 // 1024 statistic look-ups skipped      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
+// 16384 lock-step loop: no squeeze (every in-range candidate looks its four log-factorials up; same results)
 // 2048 lock-step loop: every LF / G look-up replaced by arithmetic (no vector-memory instruction; with 131072's hash)
 // 131072 lock-step loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
 // (262144, 524288 belonged to round 2's streamlined 3x2 loop — capped table search, fixed-stride shuffles; their
 //  measurements are in DESIGN.md §8 — and went with it when the lock-step streams came.)
-// Every surviving bit keeps all table indices inside the range the normal path uses and keeps every rejection
-// loop's acceptance probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the
-// acceptance test unsatisfiable, so k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536,
-// one of which indexed LF[] with set-up values it had skipped (GPU memory fault).  They are gone for good.
+// Every bit keeps all table indices inside the range the normal path uses and keeps every rejection loop's acceptance
+// probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the acceptance test unsatisfiable, so
+// k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536, one of which indexed LF[] with set-up
+// values it had skipped (GPU memory fault).  Those meanings are gone for good; 2048 and 16384 were given the new,
+// safe meanings above in round 3 (they only replace values or skip a shortcut, no index is derived from them).
 #endif
-#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 2048 | 4096 | 8192 | 131072)
+#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 2048 | 4096 | 8192 | 16384 | 131072)
 #if LGMI_PABL & ~LGMI_PABL_KNOWN
-#error "LGMI_PABL: unknown ablation bit (see the list above; 256, 2048, 16384, 32768, 65536 were removed: they hang or fault)"
+#error "LGMI_PABL: unknown ablation bit (see the list above; 256, 32768, 65536 were removed: they hang or fault)"
 #endif
 
 namespace lgmi {
@@ -615,6 +617,10 @@ static const uint32_t FIRST_MAX = LGMI_FIRST_MAX;
 #define LGMI_GUIDE_BITS 8
 #endif
 static const uint32_t GUIDE_SH = 32u - LGMI_GUIDE_BITS, GUIDE_N = 1u << LGMI_GUIDE_BITS;
+#ifndef LGMI_SQUEEZE_MIN_N
+#define LGMI_SQUEEZE_MIN_N 65536
+#endif
+static const uint32_t SQUEEZE_MIN_N = LGMI_SQUEEZE_MIN_N;      // lock-step rows with at least this many common reads take the squeeze
 static const uint32_t XRING = 512;
 // Lock-step rows: what the set-up of a second draw looks up depends on the first result x0 alone — the log-weight at the
 // mode (four LF) and the G of the two cells x0 fixes — and the first results of a row pile up around their mode.  The
@@ -852,7 +858,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
             const double d8 = HRUA_D1 * d7max + HRUA_D2, lim16 = 16.0 * d7max;   // the row's hat (no square root per shuffle)
             uint32_t filled = 0u, next = 0u, total = 0u;             // wave-uniform
             uint32_t exceed = 0u;
-            uint32_t m = 0u, mn = 0u, mxm = 0u;                     // mxm = mx - m
+            uint32_t m = 0u, mn = 0u, mxm = 0u, d9 = 0u;            // mxm = mx - m; d9 = the second draw's mode
+            double c0 = 0.0;                                         // A - B d9 (squeeze, below); usable iff -B <= c0 < 0
+            const double Bd = (double)pop2 + 2.0;
+            const bool use_squeeze = N >= SQUEEZE_MIN_N;             // wave-uniform
             long long gx = 0;                                        // G of the two cells that depend on x0 only
             double d6 = 0.0, d10 = 0.0, d11 = 0.0;
             // 256 more first draws: lane l makes call filled / 4 + l and writes X[4 c .. 4 c + 3] as offsets into the
@@ -901,12 +910,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 const double cap = (double)((m < mn ? m : mn) + 1u);
                 const double lim = floor(d6 + lim16);
                 d11 = cap < lim ? cap : lim;
+                d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
+                c0 = ((double)mn * (double)m - (double)mxm - 1.0) - Bd * (double)d9;    // integers below 2^53: exact
                 if (!fill && e - c_lo < c_n) {
                     const ulonglong2 v = cache[e - c_lo];
                     d10 = __longlong_as_double((long long)v.x);
                     gx = (long long)v.y;
                 } else {
-                    const uint32_t d9 = (uint32_t)floor((double)(m + 1u) * hb.c9);
                     const long long ga = G.ls(x0), gb = G.ls((nr == 3 ? R0 : C0) - x0);
                     const double a3 = LF.ls(mxm + d9), a2 = LF.ls(m - d9), a1 = LF.ls(mn - d9), a0 = LF.ls(d9);
                     d10 = a0 + a1 + a2 + a3;                     // the specification's order
@@ -933,10 +943,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 uint32_t zc = 0u;
                 if (!(w < 0.0 || w >= d11)) {
                     zc = (uint32_t)floor(w);
-                    const double l3 = LF.ls(mxm + zc), l2 = LF.ls(m - zc), l1 = LF.ls(mn - zc), l0 = LF.ls(zc);
-                    const double tt = d10 - (l0 + l1 + l2 + l3);
-                    const double x = u * 2.3283064365386963e-10;
-                    acc = le_exp(x * x, tt);                     // 2 ln x <= tt
+                    // ---- squeeze (round 3): the test 2 ln x <= t(zc), t = ln f(zc) / f(d9), decided from closed-form
+                    // bounds of t for all but a few per cent of the candidates, so that their four log-factorial look-ups
+                    // are never made (the kernel is bound by the L1's rate of scattered look-ups).  With
+                    // r(k) = f(k+1)/f(k) = (mn-k)(m-k) / D_k, D_k = (k+1)(mx-m+k+1), one has r(k) - 1 = (A - B k) / D_k,
+                    // A = mn m - (mx-m) - 1, B = pop + 2, and d9 = floor(A/B) + 1, i.e. c0 = A - B d9 in [-B, 0): every
+                    // term of t = sum ln r(k) has the same sign on either side of d9.  ln(1+s) <= s and
+                    // ln(1+s) >= s / (1+s), D_k increasing and r(k) decreasing in k give, for zc = d9 + d (d >= 1),
+                    //     S1 D_{zc-1} / (D_{d9} num_r(zc-1)) <= t <= S1 / D_{zc-1},   S1 = d c0 - B d(d-1)/2 <= 0,
+                    // and for zc = d9 - d,   -S2 / D_zc <= t <= -S2 D_zc / (D_{d9-1} num_r(zc)),   S2 = d c0 + B d(d+1)/2 >= 0
+                    // (num_r(k) = (mn-k)(m-k)).  Compared by cross-multiplication (every denominator is positive): no
+                    // division.  2 ln x comes from the hardware's f32 log, widened by 2e-4 either way: a candidate is only
+                    // decided here when it is that far from both bounds, so the decision is the exact test's — which the
+                    // undecided ones still take.  Nothing changes in the specification or in any result.
+                    // Row-level switch: the ~35 vector instructions of the bounds buy L1 accesses, which only bind when the
+                    // tables' footprint is large — measured: with the squeeze north-star (160k common reads) 245 -> 232 ms,
+                    // cfg5 (145k) 1,443 -> 1,254 ms, but cfg3 / cfg2 (36k - 40k) 142 -> 161 and 7.4 -> 8.3 ms.
+                    bool decided = false;
+#if !(LGMI_PABL & 16384)
+                    const int dd = (int)zc - (int)d9;
+                    if (!use_squeeze) { }
+                    else if (dd == 0) { acc = true; decided = true; }        // t = 0 exactly and x < 1
+                    else if (c0 < 0.0 && c0 >= -Bd) {
+                        const double lx = 2.0 * (double)(__logf((float)u) - 22.18070977791825f);     // x = u 2^-32
+                        const double lx_hi = lx + 2e-4, lx_lo = lx - 2e-4;
+                        const double dz = (double)zc, dm = (double)mxm, d9d = (double)d9;
+                        if (dd > 0) {
+                            const double d = (double)dd;
+                            const double S1 = d * c0 - Bd * (0.5 * d * (d - 1.0));
+                            const double Dz1 = dz * (dm + dz);                                          // D_{zc-1}
+                            const double nr1 = ((double)mn - dz + 1.0) * ((double)m - dz + 1.0);      // num_r(zc-1)
+                            const double Dd9 = (d9d + 1.0) * (dm + d9d + 1.0);
+                            if (lx_hi * Dd9 * nr1 <= S1 * Dz1) { acc = true; decided = true; }
+                            else if (lx_lo * Dz1 > S1) decided = true;                                  // rejected
+                        } else {
+                            const double d = (double)(-dd);
+                            const double S2 = d * c0 + Bd * (0.5 * d * (d + 1.0));
+                            const double Dz = (dz + 1.0) * (dm + dz + 1.0);                             // D_zc
+                            const double nrz = ((double)mn - dz) * ((double)m - dz);                  // num_r(zc)
+                            const double Dd9m = d9d * (dm + d9d);                                       // D_{d9-1}
+                            if (lx_hi * Dz <= -S2) { acc = true; decided = true; }
+                            else if (lx_lo * Dd9m * nrz > -S2 * Dz) decided = true;                     // rejected
+                        }
+                    }
+#endif
+                    if (!decided) {
+                        const double l3 = LF.ls(mxm + zc), l2 = LF.ls(m - zc), l1 = LF.ls(mn - zc), l0 = LF.ls(zc);
+                        const double tt = d10 - (l0 + l1 + l2 + l3);
+                        const double x = u * 2.3283064365386963e-10;
+                        acc = le_exp(x * x, tt);                     // 2 ln x <= tt
+                    }
 #if LGMI_PABL & (131072 | 2048)
                     exceed += acc; acc = (wy & 0xFFu) < 184u;
 #endif
