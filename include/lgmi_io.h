@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGIO_ABI_VERSION 1
+#define LGIO_ABI_VERSION 2
 #define LGIO_OK        0
 #define LGIO_E_ARG    -1
 #define LGIO_E_IO     -2   /* open / read / seek failed                     */
@@ -111,6 +111,60 @@ void lgio_reads_free(lgio_reads* reads);
 int  lgio_bam_pileup(lgio_bam* bam, int tid, int64_t start, int64_t end, int min_base_quality, int max_depth,
                      lgio_pileup* out);
 void lgio_pileup_free(lgio_pileup* pile);
+
+
+/* ---- round 3: the site extraction of one footprint, natively -------------------------------------------------
+ * What get_region_mismatches_with_filters does with the alignment file (src/giremi/mismatch.py:29-290): the cs-tag
+ * walk of every read (:69-149), the pile-up's reference-allele reads (:160-190), allele depths (:203-208), the
+ * window filter (:211-240), the allele depth / ratio filters (:243-266) and the site depth / allele-count filters
+ * (:268-290) — everything that needs only the BAM.  The homopolymer, simple-repeat and SNP steps (:292-340) need the
+ * genome and the caller's lists and stay with the caller; they see only the few surviving sites.  Same quirks as the
+ * Python path in lgmi/region.py, which remains the specification (tests/test_region_fast.py compares the two):
+ * every covered position becomes an (empty, later removed) site, a site removed by the window filter comes back
+ * empty when a later window looks at it, allele and site order are first-seen order.
+ * Inputs this routine does not cover come back with fallback = 1 and nothing else filled (the caller then runs the
+ * Python path, which treats them — or raises — the way the reference does): a read without a cs tag, a cs string
+ * that is not minimap2's short form, a substitution that involves a base other than a/c/g/t. */
+typedef struct lgio_site_params {
+    int32_t keep_non_spliced_read;      /* mismatch.py:11 keep_non_spliced_read                                   */
+    int32_t min_base_quality;           /* pile-up: pysam's default 13                                            */
+    int32_t max_depth;                  /* pile-up: pysam's default 8000                                          */
+    int32_t reserved;
+    int64_t min_dist_from_splice;
+    int64_t half_window;                /* round(mismatch_window_size / 2), rounded by the caller                 */
+    double  min_allele_depth, min_allele_ratio, min_total_depth;
+    double  max_window_mismatch, max_window_mismatch_type;
+} lgio_site_params;
+
+#define LGIO_REMOVED_WINDOW   0   /* 'too many window mismatches'           */
+#define LGIO_REMOVED_DEPTH    1   /* 'too few usable reads after filters'   */
+#define LGIO_REMOVED_ALLELES  2   /* 'not enough allele after filters'      */
+
+typedef struct lgio_sites {
+    int32_t fallback;                   /* 1: not covered here (see above)                                        */
+    int32_t reserved;
+    uint64_t n_sites;                   /* surviving sites: '+' strand first, each strand in first-seen order     */
+    const uint8_t*  strand;             /* [n_sites] 0 '+', 1 '-'                                                 */
+    const int64_t*  pos;                /* [n_sites]                                                              */
+    const char*     ref;                /* [n_sites] upper case                                                   */
+    const uint32_t* neighbor;           /* [n_sites * 16] window counts by change, index 4*ref + alt over "ACGT"
+                                           (the bases as aligned: the caller complements them for '-')           */
+    const uint64_t* allele_off;         /* [n_sites + 1] into allele_nt / reads_off                               */
+    const char*     allele_nt;          /* surviving alleles, in first-seen order (reference allele last)         */
+    const uint64_t* reads_off;          /* [n_alleles + 1] into reads                                             */
+    const uint32_t* reads;              /* read ids: indexes of name_off                                          */
+    uint64_t n_removed[2];              /* removed sites per strand, in the order the reference's dict holds them */
+    const int64_t*  removed_pos[2];
+    const uint8_t*  removed_code[2];    /* LGIO_REMOVED_*                                                         */
+    uint64_t n_reads;                   /* every read fetch(start, end) returns, in file order                    */
+    const uint64_t* name_off;           /* [n_reads + 1] into names                                               */
+    const char*     names;
+    void* owner_;
+} lgio_sites;
+
+int  lgio_bam_region_sites(lgio_bam* bam, int tid, int64_t start, int64_t end, const lgio_site_params* params,
+                           lgio_sites* out);
+void lgio_sites_free(lgio_sites* sites);
 
 /* bytes of compressed file read so far through this handle (tests use it to show that a region query does not
  * read the whole file) */

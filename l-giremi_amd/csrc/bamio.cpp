@@ -363,6 +363,34 @@ void query_chunks(const RefIndex& ri, int64_t beg, int64_t end, std::vector<Chun
     out.resize(k);
 }
 
+// the text of the first cs:Z auxiliary field (tag[2] type value ...), if any
+bool find_cs(const Record& r, const uint8_t** text, size_t* text_len) {
+    const uint8_t* a = r.aux();
+    const size_t n = r.aux_len();
+    size_t p = 0;
+    while (p + 3 <= n) {
+        const uint8_t t0 = a[p], t1 = a[p + 1], ty = a[p + 2];
+        p += 3;
+        size_t len = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+        else if (ty == 's' || ty == 'S') len = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+        else if (ty == 'Z' || ty == 'H') {
+            while (p + len < n && a[p + len]) ++len;
+            if (t0 == 'c' && t1 == 's' && ty == 'Z') { *text = a + p; *text_len = len; return true; }
+            ++len;
+        } else if (ty == 'B') {
+            if (p + 5 > n) break;
+            const uint8_t sub = a[p];
+            const uint32_t cnt = le32(a + p + 1);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            len = 5 + es * cnt;
+        } else break;
+        p += len;
+    }
+    return false;
+}
+
 struct ReadsOwner {
     std::vector<int32_t> tid; std::vector<int64_t> start, end; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, has_cs;
     std::vector<uint64_t> name_off{0}, cigar_off{0}, seq_off{0}, cs_off{0}, aux_off{0};
@@ -382,28 +410,8 @@ struct ReadsOwner {
         seq_off.push_back(seq.size());
         uint8_t found = 0;
         if (what & LGIO_CS) {
-            // auxiliary fields: tag[2] type value...; the cs tag is a 'Z' string
-            const uint8_t* a = r.aux();
-            const size_t n = r.aux_len();
-            size_t p = 0;
-            while (p + 3 <= n) {
-                const uint8_t t0 = a[p], t1 = a[p + 1], ty = a[p + 2];
-                p += 3;
-                size_t len = 0;
-                if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
-                else if (ty == 's' || ty == 'S') len = 2;
-                else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
-                else if (ty == 'Z' || ty == 'H') { while (p + len < n && a[p + len]) ++len; if (t0 == 'c' && t1 == 's' && ty == 'Z') { cs.insert(cs.end(), a + p, a + p + len); found = 1; } ++len; }
-                else if (ty == 'B') {
-                    if (p + 5 > n) break;
-                    const uint8_t sub = a[p];
-                    const uint32_t cnt = le32(a + p + 1);
-                    const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                    len = 5 + es * cnt;
-                } else break;
-                p += len;
-                if (found) break;
-            }
+            const uint8_t* text; size_t len;
+            if (find_cs(r, &text, &len)) { cs.insert(cs.end(), text, text + len); found = 1; }
         }
         has_cs.push_back(found);
         cs_off.push_back(cs.size());
@@ -613,4 +621,332 @@ static int pileup_impl(lgio_bam* b, int tid, int64_t start, int64_t end, int min
 }
 extern "C" int lgio_bam_pileup(lgio_bam* b, int tid, int64_t start, int64_t end, int min_bq, int max_depth, lgio_pileup* out) {
     return guarded([&] { return pileup_impl(b, tid, start, end, min_bq, max_depth, out); });
+}
+
+// ---------------------------------------------------------------- site extraction of one footprint (lgmi_io.h, round 3)
+// The specification is lgmi/region.py's get_region_mismatches_with_filters (steps 1-6 there, mismatch.py:29-290 of
+// the reference); the comments name its steps.  Anything that routine would treat in a way this one does not
+// reproduce comes back as fallback = 1.
+namespace {
+
+struct SiteAllele { char nt; bool kept = true; std::vector<uint32_t> reads; };
+struct Site {
+    int64_t pos; char ref = 0; std::vector<SiteAllele> alleles; uint32_t neighbor[16] = {};
+    bool gone = false;
+    SiteAllele& allele(char nt) {
+        for (SiteAllele& a : alleles) if (a.nt == nt) return a;
+        alleles.push_back(SiteAllele{nt, true, {}});
+        return alleles.back();
+    }
+};
+struct StrandSites {
+    std::vector<Site> sites;                        // first-seen order
+    std::map<int64_t, size_t> at;                   // position -> index in sites
+    Site& site(int64_t pos) {
+        auto it = at.find(pos);
+        if (it != at.end()) return sites[it->second];
+        at.emplace(pos, sites.size());
+        sites.push_back(Site{pos});
+        return sites.back();
+    }
+};
+struct SitesOwner {
+    std::vector<uint8_t> strand; std::vector<int64_t> pos; std::vector<char> ref; std::vector<uint32_t> neighbor;
+    std::vector<uint64_t> allele_off{0}; std::vector<char> allele_nt; std::vector<uint64_t> reads_off{0}; std::vector<uint32_t> reads;
+    std::vector<int64_t> removed_pos[2]; std::vector<uint8_t> removed_code[2];
+    std::vector<uint64_t> name_off{0}; std::vector<char> names;
+};
+struct Sub { int64_t pos; char ref, alt; };
+
+inline int base_index(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+inline bool is_op(char c) { return c == ':' || c == '*' || c == '+' || c == '-' || c == '~'; }
+
+// minimap2's short cs form only: ':'n  '*'xy  '+'seq  '-'seq  '~'xxNyy, lower-case bases; false = let the caller decide
+bool parse_cs(const uint8_t* s, size_t n, int64_t origin, std::vector<Sub>& subs, std::vector<int64_t>& junctions) {
+    int64_t at = 0;
+    size_t i = 0;
+    auto lower = [](uint8_t c) { return c >= 'a' && c <= 'z'; };
+    auto digit = [](uint8_t c) { return c >= '0' && c <= '9'; };
+    while (i < n) {
+        const char op = (char)s[i++];
+        size_t j = i;
+        if (op == ':') {
+            int64_t v = 0;
+            while (j < n && digit(s[j])) { v = v * 10 + (s[j] - '0'); if (v > ((int64_t)1 << 40)) return false; ++j; }
+            if (j == i) return false;
+            at += v;
+        } else if (op == '*') {
+            if (i + 2 > n) return false;
+            const char r = (char)s[i], a = (char)s[i + 1];
+            auto acgt = [](char c) { return c == 'a' || c == 'c' || c == 'g' || c == 't'; };
+            if (!acgt(r) || !acgt(a)) return false;
+            subs.push_back(Sub{origin + at, (char)(r - 32), (char)(a - 32)});
+            at += 1;
+            j = i + 2;
+        } else if (op == '+' || op == '-') {
+            while (j < n && lower(s[j])) ++j;
+            if (j == i) return false;
+            if (op == '-') at += (int64_t)(j - i);
+        } else if (op == '~') {
+            if (i + 2 > n || !lower(s[i]) || !lower(s[i + 1])) return false;
+            j = i + 2;
+            int64_t v = 0;
+            const size_t d0 = j;
+            while (j < n && digit(s[j])) { v = v * 10 + (s[j] - '0'); if (v > ((int64_t)1 << 40)) return false; ++j; }
+            if (j == d0 || j + 2 > n || !lower(s[j]) || !lower(s[j + 1])) return false;
+            j += 2;
+            junctions.push_back(origin + at);
+            junctions.push_back(origin + at + v);
+            at += v;
+        } else {
+            return false;
+        }
+        if (j < n && !is_op((char)s[j])) return false;      // the value ends where the next operation starts
+        i = j;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" void lgio_sites_free(lgio_sites* s) {
+    if (!s) return;
+    delete static_cast<SitesOwner*>(s->owner_);
+    memset(s, 0, sizeof *s);
+}
+
+static int region_sites_impl(lgio_bam* b, int tid, int64_t start, int64_t end, const lgio_site_params* P, lgio_sites* out) {
+    if (!b || !out || !P) return fail(LGIO_E_ARG, "NULL argument");
+    memset(out, 0, sizeof *out);
+    if (start < 0 || end < start) return fail(LGIO_E_ARG, "region_sites needs 0 <= start <= end");
+    const int max_depth = P->max_depth > 0 ? P->max_depth : 8000;
+    std::vector<Record> recs;
+    int rc = for_each_overlap(b, tid, start, end, [&](const Record& r) { recs.push_back(r); });
+    if (rc) return rc;
+    SitesOwner* o = new SitesOwner();
+    struct Drop { SitesOwner* p; ~Drop() { delete p; } } drop{o};
+    auto finish = [&](int fallback) {
+        out->fallback = fallback;
+        out->n_sites = o->pos.size();
+        out->strand = o->strand.data(); out->pos = o->pos.data(); out->ref = o->ref.data(); out->neighbor = o->neighbor.data();
+        out->allele_off = o->allele_off.data(); out->allele_nt = o->allele_nt.data();
+        out->reads_off = o->reads_off.data(); out->reads = o->reads.data();
+        for (int s = 0; s < 2; ++s) {
+            out->n_removed[s] = o->removed_pos[s].size();
+            out->removed_pos[s] = o->removed_pos[s].data(); out->removed_code[s] = o->removed_code[s].data();
+        }
+        out->n_reads = o->name_off.size() - 1;
+        out->name_off = o->name_off.data(); out->names = o->names.data();
+        out->owner_ = o;
+        drop.p = nullptr;
+        return LGIO_OK;
+    };
+
+    // ---- 1. the strand of a read NAME is that of its first record (read_strand_dict, :77-81); substitutions of the
+    //         spliced reads, minus those next to a junction (:69-149)
+    std::vector<uint8_t> strand(recs.size());
+    {
+        std::map<std::string, uint8_t> by_name;
+        for (size_t ri = 0; ri < recs.size(); ++ri) {
+            const Record& r = recs[ri];
+            std::string name((const char*)r.name(), r.l_name - 1);
+            o->names.insert(o->names.end(), name.begin(), name.end());
+            o->name_off.push_back(o->names.size());
+            auto ins = by_name.emplace(std::move(name), (uint8_t)((r.flag & 16) ? 1 : 0));
+            strand[ri] = ins.first->second;
+        }
+    }
+    StrandSites S[2];
+    std::vector<Sub> subs;
+    std::vector<int64_t> junctions;
+    for (size_t ri = 0; ri < recs.size(); ++ri) {
+        const uint8_t* text; size_t len;
+        if (!find_cs(recs[ri], &text, &len)) return finish(1);
+        subs.clear(); junctions.clear();
+        if (!parse_cs(text, len, recs[ri].pos, subs, junctions)) return finish(1);
+        if (!P->keep_non_spliced_read && junctions.empty()) continue;
+        const int64_t d = P->min_dist_from_splice;
+        for (const Sub& sb : subs) {
+            bool close = false;
+            if (d > 0) for (int64_t j : junctions) if (j - d <= sb.pos && sb.pos < j + d) { close = true; break; }
+            if (close) continue;
+            Site& site = S[strand[ri]].site(sb.pos);
+            site.ref = sb.ref;
+            site.allele(sb.alt).reads.push_back((uint32_t)ri);
+        }
+    }
+
+    // ---- 2. the pile-up (pysam defaults, as lgio_bam_pileup): which positions have a column, and at the candidate
+    //         sites the reads of the site's strand that show the reference base (:160-190)
+    int64_t lo = 0, hi = 0;
+    for (size_t ri = 0; ri < recs.size(); ++ri) {
+        lo = ri ? std::min(lo, recs[ri].pos) : recs[ri].pos;
+        hi = ri ? std::max(hi, recs[ri].end) : recs[ri].end;
+    }
+    if (hi - lo > (int64_t)1 << 31) return fail(LGIO_E_ARG, "pile-up over %lld reference positions refused", (long long)(hi - lo));
+    const size_t span = (size_t)(hi - lo);
+    std::vector<uint32_t> depth(span, 0);
+    std::vector<int32_t> slot[2];
+    size_t n_known[2];
+    for (int s = 0; s < 2; ++s) {
+        n_known[s] = S[s].sites.size();
+        if (!n_known[s]) continue;
+        slot[s].assign(span, -1);
+        for (size_t k = 0; k < n_known[s]; ++k) {
+            const int64_t p = S[s].sites[k].pos;
+            if (p >= lo && p < hi) slot[s][(size_t)(p - lo)] = (int32_t)k;
+        }
+    }
+    {
+        static const char code[] = "=ACMGRSVTWYHKDBN";
+        for (size_t ri = 0; ri < recs.size(); ++ri) {
+            const Record& r = recs[ri];
+            if (r.flag & (4 | 256 | 512 | 1024)) continue;
+            if ((r.flag & 1) && !(r.flag & 2)) continue;
+            int64_t ref = r.pos; uint32_t q = 0;
+            const uint8_t *c = r.cigar(), *sq = r.seq(), *ql = r.qual();
+            auto emit = [&](int64_t p, char base) {
+                const size_t k = (size_t)(p - lo);
+                if (depth[k] >= (uint32_t)max_depth) return;
+                ++depth[k];
+                const int s = strand[ri];
+                if (!slot[s].empty() && slot[s][k] >= 0) {
+                    Site& site = S[s].sites[(size_t)slot[s][k]];
+                    if (base == site.ref) site.allele(site.ref).reads.push_back((uint32_t)ri);
+                }
+            };
+            for (uint32_t k = 0; k < r.n_cigar; ++k) {
+                const uint32_t v = le32(c + 4 * k), op = v & 0xF, n = v >> 4;
+                if (op == 0 || op == 7 || op == 8) {
+                    for (uint32_t j = 0; j < n; ++j, ++ref, ++q) {
+                        if (q < r.l_seq && ql[q] != 0xFF && ql[q] < (uint32_t)P->min_base_quality) continue;
+                        emit(ref, q < r.l_seq ? code[(sq[q >> 1] >> ((~q & 1) << 2)) & 0xF] : 'N');
+                    }
+                } else if (op == 2 || op == 3) {
+                    for (uint32_t j = 0; j < n; ++j, ++ref) emit(ref, (char)0);
+                } else if (op == 1 || op == 4) q += n;
+            }
+        }
+    }
+    // (a candidate site whose column exists gets the reference allele's key even with no read in it: the depth dict
+    //  then holds a zero for it, which changes nothing below but is what the Python path holds)
+    for (int s = 0; s < 2; ++s)
+        for (size_t k = 0; k < n_known[s]; ++k) {
+            Site& site = S[s].sites[k];
+            const int64_t p = site.pos;
+            if (p >= lo && p < hi && depth[(size_t)(p - lo)]) site.allele(site.ref);
+        }
+
+    for (int s = 0; s < 2; ++s) {
+        if (!n_known[s]) continue;
+        StrandSites& T = S[s];
+        // every position with a column is a site of this strand now (the look-up creates it, :166): the snapshot of step 4
+        std::vector<int64_t> snap;
+        std::vector<int32_t> sidx;                  // index into T.sites, -1 for the empty ones
+        {
+            auto it = T.at.begin();
+            for (size_t k = 0; k < span || it != T.at.end();) {
+                const int64_t pc = k < span ? lo + (int64_t)k : INT64_MAX;
+                if (it != T.at.end() && it->first <= pc) {
+                    snap.push_back(it->first); sidx.push_back((int32_t)it->second);
+                    if (it->first == pc) ++k;
+                    ++it;
+                } else {
+                    if (depth[k]) { snap.push_back(pc); sidx.push_back(-1); }
+                    ++k;
+                }
+            }
+        }
+        const size_t n = snap.size();
+        // ---- 4. the window filter (:211-240).  cpos: the sites that add to their neighbours' counts
+        std::vector<size_t> cpos;
+        for (size_t k = 0; k < n; ++k) {
+            if (sidx[k] < 0) continue;
+            const Site& q = T.sites[(size_t)sidx[k]];
+            for (const SiteAllele& a : q.alleles) if (a.nt != q.ref) { cpos.push_back(k); break; }
+        }
+        std::vector<uint8_t> dead(n, 0), back(n, 0);
+        std::vector<size_t> removed_here;
+        const int64_t half = P->half_window;
+        size_t wa = 0, wb = 0, ca = 0, cb = 0, ra = 0;
+        for (size_t k = 0; k < n; ++k) {
+            const int64_t wl = snap[k] - half, wh = snap[k] + half;
+            while (wa < n && snap[wa] < wl) ++wa;
+            if (wb < wa) wb = wa;
+            while (wb < n && snap[wb] < wh) ++wb;
+            if (wb - wa < 2) continue;
+            while (ra < removed_here.size() && snap[removed_here[ra]] < wl) ++ra;
+            for (size_t x = ra; x < removed_here.size() && snap[removed_here[x]] < wh; ++x) back[removed_here[x]] = 1;
+            while (ca < cpos.size() && snap[cpos[ca]] < wl) ++ca;
+            if (cb < ca) cb = ca;
+            while (cb < cpos.size() && snap[cpos[cb]] < wh) ++cb;
+            uint32_t cnt[16] = {};
+            for (size_t x = ca; x < cb; ++x) {
+                const size_t qk = cpos[x];
+                if (qk == k || dead[qk]) continue;
+                const Site& q = T.sites[(size_t)sidx[qk]];
+                const int rb = base_index(q.ref);
+                for (const SiteAllele& a : q.alleles) if (a.nt != q.ref) ++cnt[4 * rb + base_index(a.nt)];
+            }
+            uint64_t total = 0; int kinds = 0;
+            for (int t = 0; t < 16; ++t) { total += cnt[t]; kinds += cnt[t] != 0; }
+            if (sidx[k] >= 0) memcpy(T.sites[(size_t)sidx[k]].neighbor, cnt, sizeof cnt);
+            if ((double)total > P->max_window_mismatch && (double)kinds > P->max_window_mismatch_type) {
+                dead[k] = 1;
+                removed_here.push_back(k);
+            }
+        }
+        std::vector<int64_t>& gpos = o->removed_pos[s];
+        std::vector<uint8_t>& gcode = o->removed_code[s];
+        std::vector<size_t> gslot(n, (size_t)-1);
+        for (size_t k : removed_here) { gslot[k] = gpos.size(); gpos.push_back(snap[k]); gcode.push_back(LGIO_REMOVED_WINDOW); }
+        // ---- 5. shallow alleles, rare alleles (:243-266); 6. shallow sites, sites left with one allele (:268-290)
+        std::vector<uint8_t> out_now(n, 0);
+        auto remove = [&](size_t k, uint8_t why) {
+            out_now[k] = 1;
+            if (gslot[k] != (size_t)-1) gcode[gslot[k]] = why;      // a site that came back empty: same dict key, new value
+            else { gpos.push_back(snap[k]); gcode.push_back(why); }
+            if (sidx[k] >= 0) T.sites[(size_t)sidx[k]].gone = true;
+        };
+        for (size_t k = 0; k < n; ++k) {
+            if (dead[k]) {
+                if (sidx[k] >= 0) T.sites[(size_t)sidx[k]].gone = true;
+                if (!back[k]) { out_now[k] = 1; continue; }
+                if (0.0 < P->min_total_depth) remove(k, LGIO_REMOVED_DEPTH);
+                continue;
+            }
+            uint64_t total = 0;
+            if (sidx[k] >= 0) {
+                Site& site = T.sites[(size_t)sidx[k]];
+                for (SiteAllele& a : site.alleles) total += a.reads.size();
+                for (SiteAllele& a : site.alleles) if ((double)a.reads.size() < P->min_allele_depth) a.kept = false;
+                for (SiteAllele& a : site.alleles)
+                    if (a.kept && (double)a.reads.size() / (double)total < P->min_allele_ratio) a.kept = false;
+            }
+            if ((double)total < P->min_total_depth) remove(k, LGIO_REMOVED_DEPTH);
+        }
+        for (size_t k = 0; k < n; ++k) {
+            if (out_now[k]) continue;
+            size_t kept = 0;
+            if (sidx[k] >= 0 && !dead[k]) for (const SiteAllele& a : T.sites[(size_t)sidx[k]].alleles) kept += a.kept;
+            if (kept < 2) remove(k, LGIO_REMOVED_ALLELES);
+        }
+        // the survivors, in the order the reads first showed them
+        for (const Site& site : T.sites) {
+            if (site.gone) continue;
+            o->strand.push_back((uint8_t)s); o->pos.push_back(site.pos); o->ref.push_back(site.ref);
+            o->neighbor.insert(o->neighbor.end(), site.neighbor, site.neighbor + 16);
+            for (const SiteAllele& a : site.alleles) {
+                if (!a.kept) continue;
+                o->allele_nt.push_back(a.nt);
+                o->reads.insert(o->reads.end(), a.reads.begin(), a.reads.end());
+                o->reads_off.push_back(o->reads.size());
+            }
+            o->allele_off.push_back(o->allele_nt.size());
+        }
+    }
+    return finish(0);
+}
+extern "C" int lgio_bam_region_sites(lgio_bam* b, int tid, int64_t start, int64_t end, const lgio_site_params* P, lgio_sites* out) {
+    return guarded([&] { return region_sites_impl(b, tid, start, end, P, out); });
 }

@@ -260,7 +260,10 @@ __device__ Tail22 bounds22(TabG G, const HG22& h, uint32_t kobs) {
 // (N <- N num, Q <- Q den, P <- fma(P, den, N); then sum += t P / Q, t <- t N / Q), truncated to the fixed-point
 // grid.  The mass of a range is the INTEGER sum of its units: it does not depend on which lane sums which unit
 // or on the order of the additions (CPU specification: unit_mass / range_mass in oracle/lgmi_perm_oracle.c).
-static const uint32_t UNIT = 64, SUB = 16;
+#ifndef LGMI_UNIT
+#define LGMI_UNIT 64
+#endif
+static const uint32_t UNIT = LGMI_UNIT, SUB = 16;
 static const uint32_t QBATCH = 4;     // rows a wave of k_perm_general takes from the shared counter at a time
 
 __device__ __forceinline__ unsigned long long unit_mass(TabLF LF, const HG22& h, uint32_t k0, uint32_t len) {

@@ -55,6 +55,23 @@ class _Pileup(C.Structure):      # lgio_pileup
                 ('reads', _Reads), ('owner_', C.c_void_p)]
 
 
+class SiteParams(C.Structure):   # lgio_site_params
+    _fields_ = [('keep_non_spliced_read', C.c_int32), ('min_base_quality', C.c_int32), ('max_depth', C.c_int32),
+                ('reserved', C.c_int32), ('min_dist_from_splice', C.c_int64), ('half_window', C.c_int64),
+                ('min_allele_depth', C.c_double), ('min_allele_ratio', C.c_double), ('min_total_depth', C.c_double),
+                ('max_window_mismatch', C.c_double), ('max_window_mismatch_type', C.c_double)]
+
+
+class _Sites(C.Structure):       # lgio_sites
+    _fields_ = [('fallback', C.c_int32), ('reserved', C.c_int32), ('n_sites', C.c_uint64), ('strand', _u8p), ('pos', _i64p),
+                ('ref', C.c_void_p), ('neighbor', _u32p), ('allele_off', _u64p), ('allele_nt', C.c_void_p),
+                ('reads_off', _u64p), ('reads', _u32p), ('n_removed', C.c_uint64 * 2), ('removed_pos', _i64p * 2),
+                ('removed_code', _u8p * 2), ('n_reads', C.c_uint64), ('name_off', _u64p), ('names', C.c_void_p),
+                ('owner_', C.c_void_p)]
+
+
+REMOVED_REASONS = ('too many window mismatches', 'too few usable reads after filters', 'not enough allele after filters')
+
 IO_SYMBOLS = {
     'lgio_abi_version': (C.c_int, []),
     'lgio_last_error': (C.c_char_p, []),
@@ -71,6 +88,8 @@ IO_SYMBOLS = {
     'lgio_bam_pileup': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(_Pileup)]),
     'lgio_pileup_free': (None, [C.POINTER(_Pileup)]),
     'lgio_bam_bytes_read': (C.c_uint64, [C.c_void_p]),
+    'lgio_bam_region_sites': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(SiteParams), C.POINTER(_Sites)]),
+    'lgio_sites_free': (None, [C.POINTER(_Sites)]),
 }
 _iolib = None
 
@@ -280,6 +299,35 @@ class BamReader:
         for k in range(t.n if t is not None else 0):
             yield BamRead(t, k)
 
+    def region_sites(self, contig, start, stop, params: SiteParams):
+        """lgio_bam_region_sites: the BAM-only steps of the site extraction of one footprint (lgmi.region uses it).
+        -> None when the library leaves the footprint to the Python path, else a dict of arrays:
+        strand/pos/ref/neighbor/allele_off/allele_nt/reads_off/reads (surviving sites), removed = [(pos, code)] per
+        strand (codes index REMOVED_REASONS), names = the read names the read ids refer to"""
+        tid = self._tid.get(contig)
+        if tid is None:
+            return None
+        st = _Sites()
+        _check(self._lib.lgio_bam_region_sites(self._h, tid, int(start), int(stop), C.byref(params), C.byref(st)))
+        try:
+            if st.fallback:
+                return None
+            n = int(st.n_sites)
+            aoff = _arr(st.allele_off, n + 1, np.int64)
+            na = int(aoff[-1]) if n else 0
+            roff = _arr(st.reads_off, na + 1, np.int64)
+            nr = int(st.n_reads)
+            noff = _arr(st.name_off, nr + 1, np.int64)
+            return {'strand': _arr(st.strand, n, np.uint8), 'pos': _arr(st.pos, n, np.int64), 'ref': _pool(st.ref, n),
+                    'neighbor': _arr(st.neighbor, 16 * n, np.int64).reshape(n, 16), 'allele_off': aoff,
+                    'allele_nt': _pool(st.allele_nt, na), 'reads_off': roff,
+                    'reads': _arr(st.reads, int(roff[-1]) if na else 0, np.int64),
+                    'removed': [(_arr(st.removed_pos[k], int(st.n_removed[k]), np.int64),
+                                 _arr(st.removed_code[k], int(st.n_removed[k]), np.uint8)) for k in range(2)],
+                    'name_off': noff, 'names': _pool(st.names, int(noff[-1]) if nr else 0)}
+        finally:
+            self._lib.lgio_sites_free(C.byref(st))
+
     def pileup(self, contig=None, start=None, stop=None, min_base_quality=13, max_depth=8000):
         """columns as pysam's pileup(contig, start, stop) yields them for single-end (long) reads.  Paired short reads
         would differ: overlapping mates are both emitted (htslib drops one), deletion / reference-skip entries bypass
@@ -342,8 +390,9 @@ class BamWriter:
             self._buf += struct.pack('<i', len(name) + 1) + name.encode() + b'\0' + struct.pack('<i', ln)
 
     def write(self, contig: str, start: int, name: str, is_reverse: bool, cigartuples, sequence: str, cs: str,
-              mapq: int = 60, quality=40, flag: int = 0):
-        """quality: one phred value for every base, or a sequence of per-base values; flag: extra SAM flag bits"""
+              mapq: int = 60, quality=40, flag: int = 0, cs_tag: bool = True):
+        """quality: one phred value for every base, or a sequence of per-base values; flag: extra SAM flag bits;
+        cs_tag=False writes the record without a cs tag (an NM:i tag instead)"""
         code = {c: k for k, c in enumerate(_SEQ)}
         seq = sequence.upper()
         packed = bytearray()
@@ -352,7 +401,7 @@ class BamWriter:
             lo = code.get(seq[k + 1], 15) if k + 1 < len(seq) else 0
             packed.append((hi << 4) | lo)
         cig = b''.join(struct.pack('<I', (n << 4) | op) for op, n in cigartuples)
-        tags = b'csZ' + cs.encode() + b'\0'
+        tags = b'csZ' + cs.encode() + b'\0' if cs_tag else b'NMC\x00'
         end = start + sum(n for op, n in cigartuples if op in (0, 2, 3, 7, 8))
         core = struct.pack('<iiBBHHHiiii', self._ids[contig], start, len(name) + 1, mapq, _reg2bin(start, end),
                            len(cigartuples), (16 if is_reverse else 0) | flag, len(seq), -1, -1, 0)

@@ -15,6 +15,7 @@ of the reference (src/giremi/cs.py:110-363) is not part of this path.
 """
 from __future__ import annotations
 
+import os
 import re
 from bisect import bisect_left
 from collections import defaultdict
@@ -82,6 +83,39 @@ def _new_site(with_removed=False):
     if with_removed:
         site['removed'] = ''
     return site
+
+
+def _context_steps(sites, gone, chromosome, genome, homopoly_length, simple_repeat_intervals, snp_positions,
+                   min_het_snp_ratio, max_het_snp_ratio):
+    """steps 7-9 of the site extraction on the sites of one strand that survived the BAM-only steps: they need the
+    genome and the caller's lists, and see only a handful of sites (mismatch.py:292-340)"""
+    # ---- 7. homopolymer context; flanking bases (:292-312)
+    k = int(homopoly_length / 2)
+    for pos in sorted(sites.keys()):
+        left = genome.fetch(chromosome, pos - homopoly_length, pos).upper()
+        right = genome.fetch(chromosome, pos + 1, pos + homopoly_length + 1).upper()
+        sites[pos]['up'] = left[-1].upper()
+        sites[pos]['down'] = right[0].upper()
+        if len(set(left)) == 1 or len(set(right)) == 1 or len(set(left[-k:] + right[0:k])) == 1:
+            gone[pos] = sites.pop(pos)
+            gone[pos]['removed'] = 'in homopoly regions'
+    # ---- 8. simple repeats (:314-323)
+    here = sorted(sites.keys())
+    for pos, hit in zip(here, _inside(here, simple_repeat_intervals)):
+        if hit:
+            gone[pos] = sites.pop(pos)
+            gone[pos]['removed'] = 'in simple repeat regions'
+    # ---- 9. depth = surviving alleles only; SNP typing (:325-340)
+    for pos in sorted(sites.keys()):
+        for nt in list(sites[pos]['depth'].keys()):
+            sites[pos]['depth'].pop(nt)
+        for nt in list(sites[pos]['nt'].keys()):
+            sites[pos]['depth'][nt] = len(sites[pos]['nt'][nt])
+    for pos in sorted(sites.keys()):
+        if pos in snp_positions:
+            total = sum(sites[pos]['depth'].values())
+            top = max(d / total for d in sites[pos]['depth'].values())
+            sites[pos]['type'] = 'het_snp' if min_het_snp_ratio <= top <= max_het_snp_ratio else 'snp'
 
 
 def get_region_mismatches_with_filters(chromosome, start_pos, end_pos, sam, genome,
@@ -200,33 +234,8 @@ def get_region_mismatches_with_filters(chromosome, start_pos, end_pos, sam, geno
             if len(sites[pos]['nt']) < 2:
                 gone[pos] = sites.pop(pos)
                 gone[pos]['removed'] = 'not enough allele after filters'
-        # ---- 7. homopolymer context; flanking bases (:292-312)
-        k = int(homopoly_length / 2)
-        for pos in sorted(sites.keys()):
-            left = genome.fetch(chromosome, pos - homopoly_length, pos).upper()
-            right = genome.fetch(chromosome, pos + 1, pos + homopoly_length + 1).upper()
-            sites[pos]['up'] = left[-1].upper()
-            sites[pos]['down'] = right[0].upper()
-            if len(set(left)) == 1 or len(set(right)) == 1 or len(set(left[-k:] + right[0:k])) == 1:
-                gone[pos] = sites.pop(pos)
-                gone[pos]['removed'] = 'in homopoly regions'
-        # ---- 8. simple repeats (:314-323)
-        here = sorted(sites.keys())
-        for pos, hit in zip(here, _inside(here, simple_repeat_intervals)):
-            if hit:
-                gone[pos] = sites.pop(pos)
-                gone[pos]['removed'] = 'in simple repeat regions'
-        # ---- 9. depth = surviving alleles only; SNP typing (:325-340)
-        for pos in sorted(sites.keys()):
-            for nt in list(sites[pos]['depth'].keys()):
-                sites[pos]['depth'].pop(nt)
-            for nt in list(sites[pos]['nt'].keys()):
-                sites[pos]['depth'][nt] = len(sites[pos]['nt'][nt])
-        for pos in sorted(sites.keys()):
-            if pos in snp_positions:
-                total = sum(sites[pos]['depth'].values())
-                top = max(d / total for d in sites[pos]['depth'].values())
-                sites[pos]['type'] = 'het_snp' if min_het_snp_ratio <= top <= max_het_snp_ratio else 'snp'
+        _context_steps(sites, gone, chromosome, genome, homopoly_length, simple_repeat_intervals, snp_positions,
+                       min_het_snp_ratio, max_het_snp_ratio)
     return kept, dropped
 
 
@@ -252,6 +261,78 @@ def region_mismatch_analysis(chromosome, start_pos, end_pos, sam, genome,
     records, mean_mi, pvals = region_pair_mi(sites, chromosome, min_common_reads, n_shuffles=n_shuffles, seed=seed,
                                              engine=engine)
     return _frames(chromosome, sites, gone, records, mean_mi, pvals)
+
+
+_LATE_REASONS = ('in homopoly regions', 'in simple repeat regions')
+_ACGT = 'ACGT'
+
+
+def _is_whole(x):
+    return isinstance(x, (int, np.integer)) or (isinstance(x, float) and x.is_integer())
+
+
+def region_sites_native(chromosome, start_pos, end_pos, sam, genome,
+                        keep_non_spliced_read=False, min_dist_from_splice=4,
+                        min_allele_depth=3, min_allele_ratio=0.1, min_total_depth=6,
+                        homopoly_length=5, simple_repeat_intervals=[], snp_positions=[],
+                        read_strand_dict=None, min_het_snp_ratio=0.35, max_het_snp_ratio=0.65,
+                        mismatch_window_size=100, max_window_mismatch=10,
+                        max_window_mismatch_type=3, mode='cs'):
+    """``get_region_mismatches_with_filters`` with the BAM-only steps (1-6) in liblgmi_io (lgio_bam_region_sites) and
+    the removed sites as arrays: -> (sites, (removed, reasons)) with ``sites`` what the Python routine returns as its
+    first value (plain dicts per strand) and ``(removed, reasons)`` what ``_compact_gone`` makes of its second — or None
+    when this footprint has to go through the Python routine (a caller-provided read_strand_dict, an alignment object
+    without the native entry point, a cs string or a base the native walk does not cover).  tests/test_region_fast.py
+    holds the two against each other."""
+    from .io import SiteParams, REMOVED_REASONS
+    if (mode != 'cs' or read_strand_dict is not None or not hasattr(sam, 'region_sites')
+            or not _is_whole(min_dist_from_splice) or start_pos is None or end_pos is None or start_pos < 0
+            or end_pos < start_pos):
+        return None
+    params = SiteParams(keep_non_spliced_read=1 if keep_non_spliced_read else 0, min_base_quality=13, max_depth=8000,
+                        min_dist_from_splice=int(min_dist_from_splice), half_window=int(round(mismatch_window_size / 2)),
+                        min_allele_depth=min_allele_depth, min_allele_ratio=min_allele_ratio,
+                        min_total_depth=min_total_depth, max_window_mismatch=max_window_mismatch,
+                        max_window_mismatch_type=max_window_mismatch_type)
+    raw = sam.region_sites(chromosome, start_pos, end_pos, params)
+    if raw is None:
+        return None
+    noff, pool = raw['name_off'], raw['names']
+    names = {}
+
+    def name(i):
+        got = names.get(i)
+        if got is None:
+            got = names[i] = pool[noff[i]:noff[i + 1]].decode()
+        return got
+
+    sites = {'+': {}, '-': {}}
+    aoff, roff, reads = raw['allele_off'], raw['reads_off'], raw['reads'].tolist()
+    ref_b, nt_b = raw['ref'].decode(), raw['allele_nt'].decode()
+    for k in range(len(raw['pos'])):
+        strand = '-' if raw['strand'][k] else '+'
+        site = _new_site()
+        site['ref'] = ref_b[k]
+        for a in range(int(aoff[k]), int(aoff[k + 1])):
+            site['nt'][nt_b[a]] = [name(i) for i in reads[int(roff[a]):int(roff[a + 1])]]
+        for t in np.flatnonzero(raw['neighbor'][k]).tolist():
+            r, alt = _ACGT[t >> 2], _ACGT[t & 3]
+            change = '%s>%s' % (r, alt) if strand == '+' else '%s>%s' % (_COMP4[r], _COMP4[alt])
+            site['neighbor'][change] = int(raw['neighbor'][k][t])
+        sites[strand][int(raw['pos'][k])] = site
+    removed = {}
+    reasons = list(REMOVED_REASONS) + list(_LATE_REASONS)
+    for s, strand in enumerate('+-'):
+        late = {}
+        if sites[strand]:
+            _context_steps(sites[strand], late, chromosome, genome, homopoly_length, simple_repeat_intervals,
+                           snp_positions, min_het_snp_ratio, max_het_snp_ratio)
+        pos, codes = raw['removed'][s]
+        if late:
+            pos = np.concatenate([pos, np.fromiter(late.keys(), np.int64, len(late))])
+            codes = np.concatenate([codes, np.array([reasons.index(v['removed']) for v in late.values()], np.uint8)])
+        removed[strand] = (pos, codes)
+    return sites, (removed, reasons)
 
 
 def _compact_gone(gone):
@@ -284,10 +365,15 @@ def _extract_chunk(job, sam=None, genome=None):
         sam, genome = reopen()
     out = []
     for fp in footprints:
-        sites, gone = get_region_mismatches_with_filters(
-            chromosome=fp['chromosome'], start_pos=fp['start'], end_pos=fp['end'], sam=sam, genome=genome,
-            snp_positions=fp.get('snp_positions', []), simple_repeat_intervals=fp.get('simple_repeat_intervals', []),
-            read_strand_dict=fp.get('read_strand_dict'), **filter_kwargs)
+        args = dict(chromosome=fp['chromosome'], start_pos=fp['start'], end_pos=fp['end'], sam=sam, genome=genome,
+                    snp_positions=fp.get('snp_positions', []), simple_repeat_intervals=fp.get('simple_repeat_intervals', []),
+                    read_strand_dict=fp.get('read_strand_dict'), **filter_kwargs)
+        # a whole run (compact): the BAM-only steps natively, when the footprint is one the native walk covers
+        fast = region_sites_native(**args) if compact and not os.environ.get('LGMI_PY_SITES') else None
+        if fast is not None:
+            out.append((fp['chromosome'],) + fast)
+            continue
+        sites, gone = get_region_mismatches_with_filters(**args)
         if compact:
             gone = _compact_gone(gone)
         if reopen is not None:              # results cross a process boundary: plain dicts (the site factory does not pickle)

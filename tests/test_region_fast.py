@@ -1,0 +1,179 @@
+"""The native site extraction (lgio_bam_region_sites through lgmi.region.region_sites_native) against its
+specification, the Python routine get_region_mismatches_with_filters: same surviving sites (same dict order, same
+allele order, same read lists, same window counts), same removed table (same order, same reasons) — on simulated
+genes at several error rates and filter settings, on hand-made records for the quirks, and refused (None, so the
+caller runs the Python routine) for the inputs the native walk does not cover."""
+import numpy as np
+import pytest
+
+from fakes import simulate_region
+from test_cli import write_inputs
+
+
+def _plain(sites):
+    return {k: dict(v, depth=dict(v['depth']), nt=dict(v['nt']), neighbor=dict(v['neighbor'])) for k, v in sites.items()}
+
+
+def compare(sam, genome, chrom, start, end, **kw):
+    from lgmi.region import get_region_mismatches_with_filters, region_sites_native, _compact_gone
+    want_sites, want_gone = get_region_mismatches_with_filters(chromosome=chrom, start_pos=start, end_pos=end, sam=sam,
+                                                               genome=genome, **kw)
+    got = region_sites_native(chromosome=chrom, start_pos=start, end_pos=end, sam=sam, genome=genome, **kw)
+    assert got is not None
+    got_sites, (got_gone, got_reasons) = got
+    want_compact, want_reasons = _compact_gone(want_gone)
+    n_window = 0
+    for strand in '+-':
+        a, b = _plain(want_sites[strand]), _plain(got_sites[strand])
+        assert list(a) == list(b)                                   # dict order = row order of the site table
+        for pos in a:
+            assert list(a[pos]['nt']) == list(b[pos]['nt']) and list(a[pos]['depth']) == list(b[pos]['depth'])
+            assert a[pos] == b[pos], (strand, pos)
+        wp, wc = want_compact[strand]
+        gp, gc = got_gone[strand]
+        assert wp.tolist() == gp.tolist()
+        w = [want_reasons[c] for c in wc]
+        assert w == [got_reasons[c] for c in gc]
+        n_window += w.count('too many window mismatches')
+    return want_sites, n_window
+
+
+def _open(tmp_path, regions):
+    from lgmi.io import open_alignment, open_fasta
+    bam, fa, _vcf = write_inputs(tmp_path, regions)
+    return open_alignment(bam), open_fasta(fa)
+
+
+SETTINGS = [
+    dict(),
+    dict(min_total_depth=0, min_allele_depth=1, min_allele_ratio=0.0),
+    dict(keep_non_spliced_read=True, min_dist_from_splice=0),
+    dict(mismatch_window_size=30, max_window_mismatch=2, max_window_mismatch_type=1),
+    dict(mismatch_window_size=7, max_window_mismatch=1, max_window_mismatch_type=0, min_total_depth=0),
+    dict(min_dist_from_splice=25, min_allele_ratio=0.3, min_total_depth=12.5, min_allele_depth=2.0),
+]
+
+
+@pytest.mark.parametrize('err', [0.004, 0.03, 0.12])
+def test_native_extraction_equals_the_python_routine(tmp_path, err):
+    regions = {}
+    for k, contig in enumerate(['chrA', 'chrB']):
+        reads, genome, snps, _ = simulate_region(seed=900 + k + int(err * 1000), n_reads=90 + 40 * k, err=err)
+        regions[contig] = (reads, genome, snps)
+    sam, genome = _open(tmp_path, regions)
+    windowed = 0
+    for contig, (_r, g, snps) in regions.items():
+        for kw in SETTINGS:
+            for (a, b) in [(0, len(g)), (150, 500), (400, 401)]:
+                _s, nw = compare(sam, genome, contig, a, b, snp_positions=snps, simple_repeat_intervals=[[250, 280]], **kw)
+                windowed += nw
+    if err >= 0.03:
+        assert windowed > 0             # the window filter (and the sites it brings back empty) was exercised
+
+
+def _write_records(tmp_path, records, length=400):
+    """records: (start, name, reverse, cigar, seq, cs, flag, quality)"""
+    from lgmi.io import BamWriter, open_alignment, open_fasta
+    rng = np.random.default_rng(5)
+    genome = ''.join(rng.choice(list('ACGT'), length))
+    bam, fa = str(tmp_path / 'q.bam'), str(tmp_path / 'q.fa')
+    w = BamWriter(bam, [('c', length)])
+    for start, name, rev, cigar, seq, cs, flag, qual in sorted(records, key=lambda r: r[0]):
+        w.write('c', start, name, rev, cigar, seq, cs, flag=flag, quality=qual)
+    w.close()
+    with open(fa, 'w') as f:
+        f.write('>c\n%s\n' % genome)
+    return open_alignment(bam), open_fasta(fa)
+
+
+def _spliced(start, name, rev, sub_at, alt='g', flag=0, qual=40, ref='a'):
+    """60M 100N 60M with one substitution `sub_at` bases into the first exon"""
+    seq = ['A'] * 120
+    seq[sub_at] = alt.upper()
+    cs = ':%d*%s%s:%d~gt100ag:60' % (sub_at, ref, alt, 59 - sub_at)
+    return (start, name, rev, [(0, 60), (3, 100), (0, 60)], ''.join(seq), cs, flag, qual)
+
+
+def test_native_extraction_quirks(tmp_path):
+    recs = []
+    for k in range(12):                                             # a site at 30 with reference and alternative reads
+        recs.append(_spliced(0, 'r%02d' % k, k % 2 == 1, 30, alt='g' if k < 8 else 'c'))
+    for k in range(6):                                              # reference-allele reads: no substitution at 30
+        recs.append((0, 'm%02d' % k, k % 2 == 1, [(0, 60), (3, 100), (0, 60)], 'A' * 120, ':60~gt100ag:60', 0, 40))
+    # the same NAME on both strands: the first record decides the strand of both (read_strand_dict)
+    recs.append(_spliced(0, 'dup', False, 30))
+    recs.append(_spliced(5, 'dup', True, 25))
+    # secondary / duplicate records are walked for substitutions but are not in the pile-up
+    recs.append(_spliced(2, 'sec', False, 28, flag=256))
+    recs.append(_spliced(2, 'pcr', True, 28, flag=1024))
+    # a low-quality read: its bases drop out of the pile-up (min_base_quality 13), its substitutions do not
+    recs.append(_spliced(1, 'lowq', False, 29, qual=5))
+    # a deletion and an insertion: 20M 3D 37M 100N 60M / 20M 2I 40M 100N 60M
+    recs.append((0, 'del', False, [(0, 20), (2, 3), (0, 37), (3, 100), (0, 60)], 'A' * 117, ':20-acg:7*ag:29~gt100ag:60', 0, 40))
+    recs.append((0, 'ins', True, [(0, 20), (1, 2), (0, 40), (3, 100), (0, 60)], 'A' * 122, ':20+tt:10*ag:29~gt100ag:60', 0, 40))
+    # an unspliced read (skipped unless keep_non_spliced_read) and one whose substitution sits next to the junction
+    recs.append((10, 'flat', False, [(0, 80)], 'A' * 80, ':20*ag:59', 0, 40))
+    recs.append(_spliced(0, 'edge', False, 58))
+    sam, genome = _write_records(tmp_path, recs)
+    for kw in SETTINGS:
+        sites, _ = compare(sam, genome, 'c', 0, 400, **kw)
+    sites, _ = compare(sam, genome, 'c', 0, 400, min_total_depth=2, min_allele_depth=1)
+    assert 30 in sites['+'] and 30 in sites['-']
+    assert 'dup' in sites['+'][30]['nt']['G'] and 'dup' not in sites['-'][30]['nt'].get('G', [])
+
+
+@pytest.mark.parametrize('cs', [None, ':30*an:29~gt100ag:60', ':30*na:29~gt100ag:60', '=AAAA*ag=AAAA', ':30*ag:29~gt100:60', ':60~100:60',
+                                ':3x', '*agt:4'])
+def test_native_extraction_leaves_the_rest_to_python(tmp_path, cs):
+    from lgmi.io import BamWriter, open_alignment, open_fasta
+    from lgmi.region import region_sites_native
+    bam, fa = str(tmp_path / 'q.bam'), str(tmp_path / 'q.fa')
+    w = BamWriter(bam, [('c', 400)])
+    w.write('c', 0, 'ok', False, [(0, 60), (3, 100), (0, 60)], 'A' * 120, ':30*ag:29~gt100ag:60')
+    if cs is None:
+        w.write('c', 1, 'bare', False, [(0, 60)], 'A' * 60, ':60', cs_tag=False)
+    else:
+        w.write('c', 1, 'odd', False, [(0, 60), (3, 100), (0, 60)], 'A' * 120, cs)
+    w.close()
+    with open(fa, 'w') as f:
+        f.write('>c\n%s\n' % ('ACGT' * 100))
+    sam, genome = open_alignment(bam), open_fasta(fa)
+    assert region_sites_native(chromosome='c', start_pos=0, end_pos=400, sam=sam, genome=genome) is None
+    # ... and so do the callers' cases the native entry point has no argument for
+    w = BamWriter(bam, [('c', 400)])
+    w.write('c', 0, 'ok', False, [(0, 60), (3, 100), (0, 60)], 'A' * 120, ':30*ag:29~gt100ag:60')
+    w.close()
+    sam = open_alignment(bam)
+    assert region_sites_native(chromosome='c', start_pos=0, end_pos=400, sam=sam, genome=genome) is not None
+    assert region_sites_native(chromosome='c', start_pos=0, end_pos=400, sam=sam, genome=genome, read_strand_dict={}) is None
+    assert region_sites_native(chromosome='c', start_pos=0, end_pos=400, sam=sam, genome=genome, min_dist_from_splice=2.5) is None
+    assert region_sites_native(chromosome='nope', start_pos=0, end_pos=400, sam=sam, genome=genome) is None
+
+
+def test_whole_run_extraction_uses_the_native_walk(tmp_path, monkeypatch):
+    """regions_mismatch_analysis(concat=True) — the CLI's path — goes through the native walk; LGMI_PY_SITES=1 forces the
+    Python routine; both give the same two site tables"""
+    import lgmi.region as region
+    regions = {}
+    for k, contig in enumerate(['chrA', 'chrB']):
+        reads, genome, snps, _ = simulate_region(seed=77 + k, n_reads=80)
+        regions[contig] = (reads, genome, snps)
+    sam, genome = _open(tmp_path, regions)
+    jobs = [{'chromosome': c, 'start': 0, 'end': len(g), 'snp_positions': s, 'simple_repeat_intervals': [],
+             'read_strand_dict': None} for c, (_r, g, s) in regions.items()]
+    calls = {'native': 0, 'python': 0}
+    native, python = region.region_sites_native, region.get_region_mismatches_with_filters
+    monkeypatch.setattr(region, 'region_sites_native', lambda **kw: (calls.__setitem__('native', calls['native'] + 1), native(**kw))[1])
+    monkeypatch.setattr(region, 'get_region_mismatches_with_filters',
+                        lambda **kw: (calls.__setitem__('python', calls['python'] + 1), python(**kw))[1])
+    fast = region._extract_chunk((None, jobs, {}, True), sam, genome)
+    assert calls == {'native': 2, 'python': 0}
+    monkeypatch.setenv('LGMI_PY_SITES', '1')
+    slow = region._extract_chunk((None, jobs, {}, True), sam, genome)
+    assert calls == {'native': 2, 'python': 2}
+    for (c1, s1, (g1, r1)), (c2, s2, (g2, r2)) in zip(fast, slow):
+        assert c1 == c2
+        for strand in '+-':
+            assert _plain(s1[strand]) == _plain(s2[strand]) and list(s1[strand]) == list(s2[strand])
+            assert g1[strand][0].tolist() == g2[strand][0].tolist()
+            assert [r1[c] for c in g1[strand][1]] == [r2[c] for c in g2[strand][1]]
