@@ -42,15 +42,16 @@
 // 16384 lock-step loop: no squeeze (every in-range candidate looks its four log-factorials up; same results)
 // 2048 lock-step loop: every LF / G look-up replaced by arithmetic (no vector-memory instruction; with 131072's hash)
 // 131072 lock-step loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
-// (262144, 524288 belonged to round 2's streamlined 3x2 loop — capped table search, fixed-stride shuffles; their
-//  measurements are in DESIGN.md §8 — and went with it when the lock-step streams came.)
+// 262144 lock-step loop: the accepted table's four G look-ups read LDS instead (what a per-row window in LDS could reach)
+// (262144 and 524288 meant something else in round 2's streamlined 3x2 loop — capped table search, fixed-stride
+//  shuffles; their measurements are in DESIGN.md §8 — and went with it when the lock-step streams came.)
 // Every bit keeps all table indices inside the range the normal path uses and keeps every rejection loop's acceptance
 // probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the acceptance test unsatisfiable, so
 // k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536, one of which indexed LF[] with set-up
 // values it had skipped (GPU memory fault).  Those meanings are gone for good; 2048 and 16384 were given the new,
 // safe meanings above in round 3 (they only replace values or skip a shortcut, no index is derived from them).
 #endif
-#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 2048 | 4096 | 8192 | 16384 | 131072)
+#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 2048 | 4096 | 8192 | 16384 | 131072 | 262144)
 #if LGMI_PABL & ~LGMI_PABL_KNOWN
 #error "LGMI_PABL: unknown ablation bit (see the list above; 256, 32768, 65536 were removed: they hang or fault)"
 #endif
@@ -1005,7 +1006,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 }
                 const unsigned long long bal = __ballot(acc);
                 if (acc) {
+#if LGMI_PABL & 262144
+                    const long long g3 = tab_thr[(mxm + zc) & 1023u], g2 = tab_thr[(m - zc) & 1023u], g1 = tab_thr[(mn - zc) & 1023u], g0 = tab_thr[zc & 1023u];
+#else
                     const long long g3 = G.ls(mxm + zc), g2 = G.ls(m - zc), g1 = G.ls(mn - zc), g0 = G.ls(zc);
+#endif
                     const long long gx_this = gx;                    // (before the set-up below overwrites it)
                     const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                     setup(x_ring[(next + rank) & (XRING - 1u)], false);
