@@ -624,10 +624,6 @@ static const uint32_t FIRST_MAX = LGMI_FIRST_MAX;
 #define LGMI_GUIDE_BITS 8
 #endif
 static const uint32_t GUIDE_SH = 32u - LGMI_GUIDE_BITS, GUIDE_N = 1u << LGMI_GUIDE_BITS;
-#ifndef LGMI_SQUEEZE_MIN_N
-#define LGMI_SQUEEZE_MIN_N 65536
-#endif
-static const uint32_t SQUEEZE_MIN_N = LGMI_SQUEEZE_MIN_N;      // lock-step rows with at least this many common reads take the squeeze
 static const uint32_t XRING = 512;
 // Lock-step rows: what the set-up of a second draw looks up depends on the first result x0 alone — the log-weight at the
 // mode (four LF) and the G of the two cells x0 fixes — and the first results of a row pile up around their mode.  The
@@ -868,7 +864,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
             uint32_t m = 0u, mn = 0u, mxm = 0u, d9 = 0u;            // mxm = mx - m; d9 = the second draw's mode
             double c0 = 0.0;                                         // A - B d9 (squeeze, below); usable iff -B <= c0 < 0
             const double Bd = (double)pop2 + 2.0;
-            const bool use_squeeze = N >= SQUEEZE_MIN_N;             // wave-uniform
             long long gx = 0;                                        // G of the two cells that depend on x0 only
             double d6 = 0.0, d10 = 0.0, d11 = 0.0;
             // 256 more first draws: lane l makes call filled / 4 + l and writes X[4 c .. 4 c + 3] as offsets into the
@@ -963,35 +958,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                     // division.  2 ln x comes from the hardware's f32 log, widened by 2e-4 either way: a candidate is only
                     // decided here when it is that far from both bounds, so the decision is the exact test's — which the
                     // undecided ones still take.  Nothing changes in the specification or in any result.
-                    // Row-level switch: the ~35 vector instructions of the bounds buy L1 accesses, which only bind when the
-                    // tables' footprint is large — measured: with the squeeze north-star (160k common reads) 245 -> 232 ms,
-                    // cfg5 (145k) 1,443 -> 1,254 ms, but cfg3 / cfg2 (36k - 40k) 142 -> 161 and 7.4 -> 8.3 ms.
+                    // Both sides of the mode in one branch-free form: with dd = zc - d9, k = zc - [dd > 0], j = d9 - [dd < 0],
+                    // S = dd c0 - B dd (dd - 1) / 2 <= 0, P = D_j num_r(k):
+                    //     dd > 0:  S D_k / P <= t <= S / D_k          dd < 0:  S / D_k <= t <= S D_k / P
+                    // (dd = 0: t = 0, the same formulas with S = 0).  The first version had one branch per side of the mode and
+                    // spent more on exec-mask bookkeeping than on arithmetic: it paid only where the L1 bound the loop (a
+                    // row-level switch took it at >= 65,536 common reads; north-star 245 -> 233 ms).  Branch-free it is
+                    // 65 instructions shorter per trip and pays everywhere: north-star 233 -> 215 ms, cfg5 1,260 -> 1,115,
+                    // cfg3 145 -> 145, cfg2 7.7 -> 7.5 — the switch is gone.
                     bool decided = false;
 #if !(LGMI_PABL & 16384)
-                    const int dd = (int)zc - (int)d9;
-                    if (!use_squeeze) { }
-                    else if (dd == 0) { acc = true; decided = true; }        // t = 0 exactly and x < 1
-                    else if (c0 < 0.0 && c0 >= -Bd) {
-                        const double lx = 2.0 * (double)(__logf((float)u) - 22.18070977791825f);     // x = u 2^-32
+                    if (c0 < 0.0 && c0 >= -Bd) {
+                        // x = u 2^-32; v_log_f32 is log2 to ~1 ulp (|log2| <= 32: 4e-6), far inside the 2e-4 margin
+                        const double lx = (double)((__builtin_amdgcn_logf((float)u) - 32.0f) * 1.3862943611198906f);
                         const double lx_hi = lx + 2e-4, lx_lo = lx - 2e-4;
-                        const double dz = (double)zc, dm = (double)mxm, d9d = (double)d9;
-                        if (dd > 0) {
-                            const double d = (double)dd;
-                            const double S1 = d * c0 - Bd * (0.5 * d * (d - 1.0));
-                            const double Dz1 = dz * (dm + dz);                                          // D_{zc-1}
-                            const double nr1 = ((double)mn - dz + 1.0) * ((double)m - dz + 1.0);      // num_r(zc-1)
-                            const double Dd9 = (d9d + 1.0) * (dm + d9d + 1.0);
-                            if (lx_hi * Dd9 * nr1 <= S1 * Dz1) { acc = true; decided = true; }
-                            else if (lx_lo * Dz1 > S1) decided = true;                                  // rejected
-                        } else {
-                            const double d = (double)(-dd);
-                            const double S2 = d * c0 + Bd * (0.5 * d * (d + 1.0));
-                            const double Dz = (dz + 1.0) * (dm + dz + 1.0);                             // D_zc
-                            const double nrz = ((double)mn - dz) * ((double)m - dz);                  // num_r(zc)
-                            const double Dd9m = d9d * (dm + d9d);                                       // D_{d9-1}
-                            if (lx_hi * Dz <= -S2) { acc = true; decided = true; }
-                            else if (lx_lo * Dd9m * nrz > -S2 * Dz) decided = true;                     // rejected
-                        }
+                        const int dd = (int)zc - (int)d9;
+                        const bool up = dd > 0;
+                        const double ddf = (double)dd;
+                        const double S = ddf * c0 - Bd * (0.5 * ddf * (ddf - 1.0));
+                        const double kf = (double)zc - (up ? 1.0 : 0.0), jf = (double)d9 - (dd < 0 ? 1.0 : 0.0), dm = (double)mxm;
+                        const double Dk = (kf + 1.0) * (dm + kf + 1.0);
+                        const double P = ((jf + 1.0) * (dm + jf + 1.0)) * (((double)mn - kf) * ((double)m - kf));
+                        const bool yes = lx_hi * (up ? P : Dk) <= (up ? S * Dk : S);
+                        const bool no = lx_lo * (up ? Dk : P) > (up ? S : S * Dk);
+                        acc = yes;
+                        decided = yes | no;
                     }
 #endif
                     if (!decided) {
