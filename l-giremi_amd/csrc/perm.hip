@@ -757,13 +757,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                     loc = to_fixed52(pm);
                     tab_thr[e0] = (uint32_t)(loc >> 20);
                 }
-                for (uint32_t e = e0 + 1u; e < e1; ++e) {   // the others: by the hypergeometric ratio
-                    const uint32_t k = tab_klo + e;
-                    const double num = (double)(good - k + 1u) * (double)(sample - k + 1u);
-                    const double den = (double)k * (double)(pop - good - sample + k);
-                    pm = pm * num / den;
-                    loc += to_fixed52(pm);
-                    tab_thr[e] = (uint32_t)(loc >> 20);
+                if (e0 + 1u < e1) {                     // the others: by the hypergeometric ratio num / den, with
+                    // num = (good-k+1)(sample-k+1) and den = k (pop-good-sample+k) stepped by their second differences:
+                    // integers below 2^53, so the same doubles as the products (as in unit_mass)
+                    const uint32_t k = tab_klo + e0 + 1u;
+                    const double a = (double)(good - k + 1u), b = (double)(sample - k + 1u), c = (double)k, d = (double)(pop - good - sample + k);
+                    double num = a * b, den = c * d, sn = a + b - 1.0, sd = c + d + 1.0;
+                    for (uint32_t e = e0 + 1u; e < e1; ++e) {
+                        pm = pm * num / den;
+                        loc += to_fixed52(pm);
+                        tab_thr[e] = (uint32_t)(loc >> 20);
+                        num -= sn; den += sd; sn -= 2.0; sd += 2.0;
+                    }
                 }
                 unsigned long long incl = loc;         // inclusive scan of the segment totals over the lanes
 #pragma unroll
