@@ -8,11 +8,10 @@ rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_R
 rocprofv3 --pmc TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_GATE_EN1_sum $K --kernel-trace --output-format csv -d $OUT/b -- $B > $OUT/b.json 2> $OUT/b.log
 rocprofv3 --pmc TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum TCP_GATE_EN2_sum $K --kernel-trace --output-format csv -d $OUT/c -- $B > $OUT/c.json 2> $OUT/c.log || true
 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum $K --kernel-trace --output-format csv -d $OUT/d -- $B > $OUT/d.json 2> $OUT/d.log || true
-rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum $K --kernel-trace --output-format csv -d $OUT/e -- $B > $OUT/e.json 2> $OUT/e.log || true
 cd $ROOT
 python3 - <<'P'
 import csv,glob,collections
-for tag in 'abcde':
+for tag in 'abcd':   # (a fifth pass with the TA_* counters never returned on this pool: dropped)
     for f in glob.glob('gpurun_out/pmc_perm_l1/%s/**/*counter_collection.csv'%tag, recursive=True):
         acc=collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
