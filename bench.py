@@ -333,19 +333,20 @@ def main():
                       'table_draws': draws, 'ms_general': ms_gen, 'ms_fast': ms_fast,
                       'table_draws_per_s': draws / (ms_gen * 1e-3) if ms_gen > 0 else None,
                       'two_by_two_rows_per_s': (info['n_rows'] - general_job) / (ms_fast * 1e-3) if ms_fast > 0 else None,
-                      'bound': 'L1 (TCP) rate of scattered 8-byte table look-ups for k_perm_general (DESIGN.md §8 round 3); '
-                               'VALU issue for k_perm_fast',
+                      'bound': 'VALU issue for both kernels; k_perm_general was bound by the L1 (TCP) rate of scattered 8-byte '
+                               'look-ups until the per-row cache and the squeeze took 10 of its 15 look-ups per draw away '
+                               '(DESIGN.md §8 round 3)',
                       'unit': 'wave64 VALU instructions/s', 'peak': VALU_WAVE_INSTR_PEAK,
                       'counters': sq.get('_file') or committed_profile('pmc_sq_perm').get('_file'),
                       'source': 'the counter-derived fields below come from the committed profile named in `counters` '
                                 '(separate rocprofv3 --pmc passes of this workload), NOT from this run; times and rates are this run\'s'}
-                l1 = committed_profile('pmc_perm_general')
+                l1 = committed_profile('pmc_perm_general_final')
                 if l1.get('derived') and args.workload == 'north_star_dense_50kx200k':
                     dd = l1['derived']
-                    pr['k_perm_general_l1'] = {k: dd.get(k) for k in ('lookups_per_table_draw', 'l1_accesses_per_lookup_instruction',
-                                                                      'l1_accesses_per_cu_cycle', 'l1_miss_frac', 'l2_hit_frac',
-                                                                      'l1_tagconflict_stall_frac_of_cycles', 'instructions_per_table_draw_wave')}
-                    pr['k_perm_general_l1']['source'] = 'committed profile %s (the kernel before the per-row LDS cache), not this run' % l1.get('_file')
+                    pr['k_perm_general_l1'] = {k: dd.get(k) for k in ('l1_accesses_per_table_draw', 'l1_accesses_per_cu_cycle', 'l1_miss_frac',
+                                                                      'l2_hit_frac', 'l1_tagconflict_stall_frac_of_gated_cycles',
+                                                                      'wave_valu_insts_per_table_draw', 'salu_insts_per_valu_inst')}
+                    pr['k_perm_general_l1']['source'] = 'committed profile %s (separate rocprofv3 --pmc passes), not this run' % l1.get('_file')
                 for k in ('k_perm_general', 'k_perm_fast'):
                     c = sq.get(k)
                     if c and c.get('valu_insts') and c.get('ms'):
