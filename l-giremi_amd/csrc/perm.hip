@@ -1117,17 +1117,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                     }
                 }
             } else if (in_draw && g.phase == 2) {
-                if (g.left > 0u && g.rem_good > 0u && g.rem_total > g.rem_good) {
-                    if ((uint32_t)(ux * (double)g.rem_total) < g.rem_good) g.rem_good--;
-                    g.rem_total--;
-                    g.left--;
+                // the WHOLE urn draw inside this trip (at most 9 steps, one pair of the shuffle's stream per step, in
+                // order): with one step per trip a small draw cost as many trips of the state machine as it has steps,
+                // and rows of a few hundred reads — the footprint-shaped regime — are mostly such draws
+                for (;;) {
+                    if (g.left > 0u && g.rem_good > 0u && g.rem_total > g.rem_good) {
+                        if ((uint32_t)(ux * (double)g.rem_total) < g.rem_good) g.rem_good--;
+                        g.rem_total--;
+                        g.left--;
+                    }
+                    if (!(g.left > 0u && g.rem_good > 0u && g.rem_total > g.rem_good)) break;
+                    if (g.spare == 0) {
+                        const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
+                        g.call++;
+                        g.sp1 = o.y; g.sp2 = o.z; g.sp3 = o.w; g.spare = 2;
+                    }
+                    const uint32_t vx = g.spare == 2 ? g.sp1 >> 8 : g.sp3 >> 8;
+                    g.spare--;
+                    ux = ((double)vx + 0.5) * 5.9604644775390625e-08;
                 }
-                if (!(g.left > 0u && g.rem_good > 0u && g.rem_total > g.rem_good)) {
-                    if (g.rem_total == g.rem_good) g.rem_good -= g.left;
-                    z = g.good - g.rem_good;
-                    if (g.m < g.sample) z = g.good - z;
-                    have_z = true;
-                }
+                if (g.rem_total == g.rem_good) g.rem_good -= g.left;
+                z = g.good - g.rem_good;
+                if (g.m < g.sample) z = g.good - z;
+                have_z = true;
             }
             // ---- (2) lanes whose draw just finished (or that start a shuffle): book the result, close the
             //          column / the table when it is complete, set up the next real draw.

@@ -5,3 +5,7 @@ for wl in north_star_dense_50kx200k cfg5_dense_depthx4_S10000 cfg3_22x9091x45455
   timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-to-host --steps 2 --warmup 1 > gpurun_out/cur_$wl.json 2> gpurun_out/cur_$wl.err || { echo "failed $wl"; exit 1; }
   python -c "import json; d=json.load(open('gpurun_out/cur_$wl.json')); print('$wl step', round(d['ms_per_step'],1), 'perm_general', round(d['stage_ms']['ms_perm_general'],1), 'perm_fast', round(d['stage_ms']['ms_perm_fast'],1))"
 done
+for wl in footprints_20k; do
+  timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-to-host --steps 3 --warmup 1 > gpurun_out/cur_$wl.json 2> gpurun_out/cur_$wl.err || { echo "failed $wl"; exit 1; }
+  python -c "import json; d=json.load(open('gpurun_out/cur_$wl.json')); print('$wl step', round(d['ms_per_step'],2), 'perm_general', round(d['stage_ms']['ms_perm_general'],2), 'perm_fast', round(d['stage_ms']['ms_perm_fast'],2))"
+done
