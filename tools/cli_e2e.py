@@ -186,6 +186,9 @@ def main():
     ap.add_argument('--seed', type=int, default=20250811)
     ap.add_argument('--n_shuffles', type=int, default=0)
     ap.add_argument('--build_only', action='store_true')
+    ap.add_argument('--compare_python_sites', type=int, default=0, metavar='T',
+                    help='also run once with LGMI_PY_SITES=1 (the Python site extraction, the specification) at -t T and compare '
+                         'its three output files byte for byte with the last native run')
     args = ap.parse_args()
     bam, fa, vcf = build_inputs(args.workdir, args.genes, args.reads, args.seed)
     if args.build_only:
@@ -208,6 +211,21 @@ def main():
                     removed_rows=sum(1 for _ in open(prefix + '.removed.txt')) - 1)
         print(json.dumps(line))
         sys.stdout.flush()
+    if args.compare_python_sites and args.threads:
+        import filecmp
+        native = os.path.join(args.workdir, 'out_t%d' % args.threads[-1])
+        prefix = os.path.join(args.workdir, 'out_pysites')
+        cmd = [sys.executable, '-m', 'lgmi.cli', '-b', bam, '-c', 'chrS', '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
+               '--mi_calculation_only', '--skip_strand_correction', '-t', str(args.compare_python_sites),
+               '--n_shuffles', str(args.n_shuffles)]
+        env = dict(os.environ, LGMI_PY_SITES='1',
+                   PYTHONPATH=os.path.join(ROOT, 'l-giremi_amd') + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        t0 = time.time()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        same = {ext: (r.returncode == 0 and filecmp.cmp(native + ext, prefix + ext, shallow=False))
+                for ext in ('.mi.txt', '.removed.txt', '.strand.txt')}
+        print(json.dumps({'python_sites_wall_s': round(time.time() - t0, 2), 'threads': args.compare_python_sites,
+                          'identical_to_native': same, 'error': r.stderr[-500:] if r.returncode else None}))
 
 
 if __name__ == '__main__':
