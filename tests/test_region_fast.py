@@ -177,3 +177,22 @@ def test_whole_run_extraction_uses_the_native_walk(tmp_path, monkeypatch):
             assert _plain(s1[strand]) == _plain(s2[strand]) and list(s1[strand]) == list(s2[strand])
             assert g1[strand][0].tolist() == g2[strand][0].tolist()
             assert [r1[c] for c in g1[strand][1]] == [r2[c] for c in g2[strand][1]]
+
+
+def test_native_entry_point_rejects_bad_arguments(tmp_path):
+    from lgmi.io import BamWriter, SiteParams, open_alignment
+    bam = str(tmp_path / 'q.bam')
+    w = BamWriter(bam, [('c', 400)])
+    w.write('c', 0, 'ok', False, [(0, 60), (3, 100), (0, 60)], 'A' * 120, ':30*ag:29~gt100ag:60')
+    w.close()
+    sam = open_alignment(bam)
+    params = SiteParams(min_base_quality=13, max_depth=8000, min_dist_from_splice=4, half_window=50, min_allele_depth=3,
+                        min_allele_ratio=0.1, min_total_depth=6, max_window_mismatch=10, max_window_mismatch_type=3)
+    with pytest.raises(ValueError):
+        sam.region_sites('c', 10, 5, params)            # end before start
+    with pytest.raises(ValueError):
+        sam.region_sites('c', -1, 5, params)
+    got = sam.region_sites('c', 0, 0, params)            # an empty interval: no reads, no sites
+    assert got is not None and len(got['pos']) == 0 and all(len(p) == 0 for p, _c in got['removed'])
+    got = sam.region_sites('c', 300, 400, params)        # nothing aligned there
+    assert got is not None and len(got['pos']) == 0
