@@ -80,6 +80,38 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+def _write_removed(df, path, header=True):
+    """the removed-site table (strings and one integer column, millions of rows: one per covered position of every
+    footprint) as pandas' to_csv(sep='\t', index=False) writes it, byte for byte, through pyarrow's CSV writer when it is
+    there: the strings go in as dictionary codes (3.3 s -> 1.1 s for 3.85 M rows)"""
+    try:
+        import pyarrow as pa
+        import pyarrow.csv as pc
+    except ImportError:
+        pa = None
+    import numpy as np
+    import pandas as pd
+    cols = list(df.columns)
+    if pa is None or cols != ['chromosome', 'strand', 'pos', 'removed'] or df['pos'].dtype != np.int64 or len(df) == 0:
+        df.to_csv(path, sep='\t', index=False, header=header)
+        return
+    arrays = []
+    for c in cols:
+        if c == 'pos':
+            arrays.append(pa.array(df[c].to_numpy()))
+            continue
+        codes, uniq = pd.factorize(df[c].to_numpy())
+        if any(not isinstance(u, str) or any(ch in u for ch in '\t\n\r"') for u in uniq):
+            df.to_csv(path, sep='\t', index=False, header=header)     # something pandas would quote
+            return
+        arrays.append(pa.DictionaryArray.from_arrays(pa.array(codes.astype(np.int32)), pa.array(list(uniq))).cast(pa.string()))
+    with open(path, 'wb') as f:
+        if header:
+            f.write(('\t'.join(cols) + '\n').encode())
+        pc.write_csv(pa.Table.from_arrays(arrays, names=cols), f,
+                     pc.WriteOptions(delimiter='\t', quoting_style='none', include_header=False))
+
+
 def get_footprints(sam, chromosomes, min_read_count=2):
     """[chromosome, start, end, read_count] of merged read intervals with enough reads
     (src/giremi/footprint.py:6-50: sort by start, fuse while the next start <= the running end).
@@ -220,7 +252,7 @@ def main(argv=None):
         # every rank writes its part of the removed-site table next to the output; rank 0 stitches the parts in rank
         # order (= footprint order) once all are there, and writes the gathered pair table
         part = '%s.removed.txt.rank%d' % (args.output_prefix, rank)
-        df_removed.to_csv(part, sep='\t', index=False, header=(rank == 0))
+        _write_removed(df_removed, part, header=(rank == 0))
         group.barrier()
         if rank == 0:
             import shutil
@@ -236,7 +268,7 @@ def main(argv=None):
     else:
         strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
         df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
-        df_removed.to_csv(args.output_prefix + '.removed.txt', sep='\t', index=False)
+        _write_removed(df_removed, args.output_prefix + '.removed.txt')
     if args.mip_table:
         # script/giremi.py:415-429: mip = ECDF of the het-SNP rows' mean_mi (those that have one) at every row's mean_mi.
         # Several ranks: the ECDF needs every rank's het-SNP means — the site tables go to rank 0 through the socket group.

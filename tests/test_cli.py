@@ -313,3 +313,23 @@ def test_cli_cfg1_mip_table(tmp_path):
     cli.main(['-b', bam, '-c', gold['contig'], '-o', prefix, '--genome_fasta', fa, '--snp_bcf', vcf,
               '--mi_calculation_only', '--skip_strand_correction', '--mip_table'])
     _compare_mip_table(prefix + '.mismatch_mip.txt', cases['cfg1']['mismatch_mip'])
+
+
+def test_removed_table_writer_matches_pandas(tmp_path):
+    """cli._write_removed (pyarrow's CSV writer when present) writes what DataFrame.to_csv(sep='\\t', index=False) writes"""
+    import filecmp
+    from lgmi.cli import _write_removed
+    n = 5000
+    k = np.arange(n)
+    df = pd.DataFrame({'chromosome': np.where(k % 7, 'chr1', 'chrUn_random').astype(object),
+                       'strand': np.where(k % 2, '+', '-').astype(object), 'pos': k.astype(np.int64) * 3 - 5,
+                       'removed': np.array(['too few usable reads after filters', 'in homopoly regions'], dtype=object)[k % 2]})
+    cases = [(df, True), (df, False), (df.iloc[:0], True)]
+    odd = df.iloc[:10].copy()
+    odd.loc[odd.index[3], 'removed'] = 'has\ttab'                     # pandas quotes it: the writer must fall back
+    cases.append((odd, True))
+    for frame, header in cases:
+        a, b = str(tmp_path / 'a.txt'), str(tmp_path / 'b.txt')
+        frame.to_csv(a, sep='\t', index=False, header=header)
+        _write_removed(frame, b, header=header)
+        assert filecmp.cmp(a, b, shallow=False)
