@@ -196,3 +196,65 @@ def test_native_entry_point_rejects_bad_arguments(tmp_path):
     assert got is not None and len(got['pos']) == 0 and all(len(p) == 0 for p, _c in got['removed'])
     got = sam.region_sites('c', 300, 400, params)        # nothing aligned there
     assert got is not None and len(got['pos']) == 0
+
+
+def test_native_extraction_on_random_records(tmp_path):
+    """random CIGARs, random cs strings (well-formed but unrelated to the CIGAR, so substitutions land anywhere — also
+    outside the positions the read covers), random flags, qualities and duplicate names: the native walk either declines
+    (None) or returns exactly what the Python routine returns"""
+    from lgmi.io import BamWriter, open_alignment, open_fasta
+    from lgmi.region import region_sites_native
+    rng = np.random.default_rng(77)
+    length = 3000
+    fa = str(tmp_path / 'g.fa')
+    with open(fa, 'w') as f:
+        f.write('>c\n%s\n' % ''.join(rng.choice(list('ACGT'), length)))
+    genome = open_fasta(fa)
+    declined = compared = 0
+    for trial in range(12):
+        bam = str(tmp_path / ('r%d.bam' % trial))
+        w = BamWriter(bam, [('c', length)])
+        recs = []
+        for k in range(int(rng.integers(5, 120))):
+            start = int(rng.integers(0, 1500))
+            cigar, qlen = [], 0
+            for _ in range(int(rng.integers(1, 7))):
+                op = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+                n = int(rng.integers(1, 400 if op == 3 else 60))
+                if cigar and cigar[-1][0] == op:
+                    continue
+                cigar.append((op, n))
+                qlen += n if op in (0, 1, 4) else 0
+            if not any(op == 0 for op, _n in cigar):
+                cigar.append((0, 20)); qlen += 20
+            cs = []
+            for _ in range(int(rng.integers(1, 12))):
+                kind = int(rng.integers(0, 6))
+                if kind <= 1:
+                    cs.append(':%d' % int(rng.integers(1, 80)))
+                elif kind == 2:
+                    a, b = rng.choice(list('acgt'), 2, replace=False)
+                    cs.append('*%s%s' % (a, b))
+                elif kind == 3:
+                    cs.append(('+' if rng.random() < 0.5 else '-') + ''.join(rng.choice(list('acgt'), int(rng.integers(1, 5)))))
+                elif kind == 4:
+                    cs.append('~gt%dag' % int(rng.integers(20, 400)))
+                elif trial % 4 == 3:
+                    cs.append(str(rng.choice(['*an', '=ACGT', ':', '*a', '~gt12'])))      # declined by the native walk
+            flag = int(rng.choice([0, 0, 0, 256, 1024, 512, 2048]))
+            qual = [int(q) for q in rng.integers(0, 41, qlen)] if rng.random() < 0.3 else 40
+            name = 'r%d' % int(rng.integers(0, 60))                                       # duplicate names on purpose
+            recs.append((start, name, bool(rng.random() < 0.5), cigar, ''.join(rng.choice(list('ACGT'), qlen)), ''.join(cs), flag, qual))
+        for start, name, rev, cigar, seq, cs, flag, qual in sorted(recs, key=lambda r: r[0]):
+            w.write('c', start, name, rev, cigar, seq, cs, flag=flag, quality=qual)
+        w.close()
+        sam = open_alignment(bam)
+        for (a, b) in [(0, length), (200, 900)]:
+            for kw in (SETTINGS[1], SETTINGS[2], SETTINGS[4]):
+                got = region_sites_native(chromosome='c', start_pos=a, end_pos=b, sam=sam, genome=genome, **kw)
+                if got is None:
+                    declined += 1
+                    continue
+                compare(sam, genome, 'c', a, b, **kw)
+                compared += 1
+    assert compared > 20 and declined > 0
