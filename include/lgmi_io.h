@@ -166,6 +166,19 @@ int  lgio_bam_region_sites(lgio_bam* bam, int tid, int64_t start, int64_t end, c
                            lgio_sites* out);
 void lgio_sites_free(lgio_sites* sites);
 
+/* ---- round 3: (start, end) of every mapped read of a reference, the footprint scan of src/giremi/footprint.py:6-28,
+ * with the BGZF blocks inflated by `threads` threads (<= 1: the calling thread).  Same reads, same order, same values as
+ * lgio_bam_fetch(bam, tid, -1, 0, 0, ...)'s start / end columns; needs a coordinate-sorted file (which the index
+ * already presumes).  The scan is the one stage of a run whose cost is the size of the BAM. */
+typedef struct lgio_intervals {
+    uint64_t n;
+    const int64_t* start;
+    const int64_t* end;
+    void* owner_;
+} lgio_intervals;
+int  lgio_bam_ref_intervals(lgio_bam* bam, int tid, int threads, lgio_intervals* out);
+void lgio_intervals_free(lgio_intervals* iv);
+
 /* bytes of compressed file read so far through this handle (tests use it to show that a region query does not
  * read the whole file) */
 uint64_t lgio_bam_bytes_read(const lgio_bam* bam);

@@ -950,3 +950,200 @@ static int region_sites_impl(lgio_bam* b, int tid, int64_t start, int64_t end, c
 extern "C" int lgio_bam_region_sites(lgio_bam* b, int tid, int64_t start, int64_t end, const lgio_site_params* P, lgio_sites* out) {
     return guarded([&] { return region_sites_impl(b, tid, start, end, P, out); });
 }
+
+// ---------------------------------------------------------------- whole-reference interval scan, blocks inflated in parallel
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct IntervalsOwner { std::vector<int64_t> start, end; };
+struct BlockRef { uint64_t addr; uint32_t head; uint32_t clen; };      // file offset, bytes before the deflate stream, its length
+
+// header of the BGZF block at `addr` (pread: no shared file position) -> 0 ok, 1 end of file, negative error
+int block_ref(int fd, uint64_t addr, BlockRef& br, uint64_t& next) {
+    uint8_t h[18];
+    const ssize_t got = pread(fd, h, 18, (off_t)addr);
+    if (got == 0) return 1;
+    if (got != 18) return fail(LGIO_E_FORMAT, "truncated BGZF block header at %llu", (unsigned long long)addr);
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(LGIO_E_FORMAT, "not a BGZF block at %llu", (unsigned long long)addr);
+    const uint32_t xlen = le16(h + 10);
+    uint32_t bsize = 0;
+    if (xlen == 6 && h[12] == 'B' && h[13] == 'C') {
+        bsize = le16(h + 16);
+    } else {
+        std::vector<uint8_t> extra(xlen);
+        if (pread(fd, extra.data(), xlen, (off_t)(addr + 12)) != (ssize_t)xlen) return fail(LGIO_E_FORMAT, "truncated BGZF extra field");
+        bool found = false;
+        for (uint32_t p = 0; p + 4 <= xlen;) {
+            const uint32_t slen = le16(&extra[p + 2]);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) { bsize = le16(&extra[p + 4]); found = true; break; }
+            p += 4 + slen;
+        }
+        if (!found) return fail(LGIO_E_FORMAT, "gzip member without a BC subfield at %llu", (unsigned long long)addr);
+    }
+    const uint64_t total = (uint64_t)bsize + 1;
+    if (total < 12ull + xlen + 8) return fail(LGIO_E_FORMAT, "bad BGZF block size at %llu", (unsigned long long)addr);
+    br.addr = addr; br.head = 12 + xlen; br.clen = (uint32_t)(total - 12 - xlen - 8);
+    next = addr + total;
+    return 0;
+}
+
+// one block inflated into `out` (CRC checked); the message of a failure goes to `why` (fail()'s text is thread-local)
+int inflate_block(int fd, const BlockRef& br, std::vector<uint8_t>& comp, std::vector<uint8_t>& out, std::string& why) {
+    char msg[160];
+    comp.resize((size_t)br.clen + 8);
+    if (pread(fd, comp.data(), comp.size(), (off_t)(br.addr + br.head)) != (ssize_t)comp.size()) {
+        snprintf(msg, sizeof msg, "truncated BGZF block at %llu", (unsigned long long)br.addr); why = msg; return LGIO_E_FORMAT;
+    }
+    const uint32_t isize = le32(comp.data() + br.clen + 4);
+    if (isize > 65536) { snprintf(msg, sizeof msg, "BGZF block larger than 64 KiB at %llu", (unsigned long long)br.addr); why = msg; return LGIO_E_FORMAT; }
+    out.resize(isize);
+    if (!isize) return 0;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { why = "inflateInit2 failed"; return LGIO_E_OOM; }
+    zs.next_in = comp.data(); zs.avail_in = (uInt)br.clen;
+    zs.next_out = out.data(); zs.avail_out = isize;
+    const int zr = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (zr != Z_STREAM_END || zs.total_out != isize) { snprintf(msg, sizeof msg, "inflate failed at block %llu", (unsigned long long)br.addr); why = msg; return LGIO_E_FORMAT; }
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out.data(), isize) != le32(comp.data() + br.clen)) {
+        snprintf(msg, sizeof msg, "CRC mismatch in BGZF block %llu", (unsigned long long)br.addr); why = msg; return LGIO_E_FORMAT;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" void lgio_intervals_free(lgio_intervals* iv) {
+    if (!iv) return;
+    delete static_cast<IntervalsOwner*>(iv->owner_);
+    memset(iv, 0, sizeof *iv);
+}
+
+static int ref_intervals_impl(lgio_bam* b, int tid, int threads, lgio_intervals* out) {
+    if (!b || !out) return fail(LGIO_E_ARG, "NULL argument");
+    memset(out, 0, sizeof *out);
+    if (tid < 0 || (size_t)tid >= b->ref_names.size()) return fail(LGIO_E_ARG, "reference id %d out of range", tid);
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    IntervalsOwner* o = new IntervalsOwner();
+    struct Drop { IntervalsOwner* p; ~Drop() { delete p; } } drop{o};
+    auto finish = [&] {
+        out->n = o->start.size(); out->start = o->start.data(); out->end = o->end.data(); out->owner_ = o;
+        drop.p = nullptr;
+        return LGIO_OK;
+    };
+    std::vector<Chunk> chunks;
+    query_chunks(b->index[tid], 0, MAX_POS, chunks);
+    if (chunks.empty()) return finish();
+    const int fd = open(b->path.c_str(), O_RDONLY);
+    if (fd < 0) return fail(LGIO_E_IO, "cannot open %s", b->path.c_str());
+    struct Close { int fd; ~Close() { close(fd); } } closer{fd};
+    // the reads of a reference are contiguous in a sorted file: from the first record the index points at until the
+    // reference id changes.  Windows of WIN blocks: headers hopped over by the calling thread, blocks inflated by all,
+    // records walked by the calling thread (a record may straddle blocks and windows: `stream` carries the remainder).
+    const size_t WIN = 64 * (size_t)threads;
+    uint64_t addr = chunks[0].beg >> 16;
+    size_t skip = (size_t)(chunks[0].beg & 0xFFFF);
+    std::vector<BlockRef> refs;
+    std::vector<std::vector<uint8_t>> bufs(WIN);
+    std::vector<uint8_t> stream;
+    bool done = false, eof = false;
+    // one whole record (without its size word): 0 taken or skipped, 1 = the reference is over, negative error
+    auto one_record = [&](const uint8_t* r, uint32_t bs) -> int {
+        const int32_t rtid = (int32_t)le32(r);
+        if (rtid != tid) { done = true; return 1; }
+        const int64_t pos = (int32_t)le32(r + 4);
+        const uint32_t l_name = r[8], n_cigar = le16(r + 12), flag = le16(r + 14), l_seq = le32(r + 16);
+        if (32ull + l_name + 4ull * n_cigar + (l_seq + 1ull) / 2 + l_seq > bs || l_name == 0) return fail(LGIO_E_FORMAT, "BAM record fields exceed the record");
+        if ((flag & 4) || pos >= MAX_POS) return 0;
+        int64_t span = 0;
+        const uint8_t* c = r + 32 + l_name;
+        for (uint32_t k = 0; k < n_cigar; ++k) {
+            const uint32_t v = le32(c + 4 * k), op = v & 0xF;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4;
+        }
+        o->start.push_back(pos);
+        o->end.push_back(pos + (span > 0 ? span : 1));
+        return 0;
+    };
+    while (!done && !eof) {
+        refs.clear();
+        while (refs.size() < WIN) {
+            BlockRef br; uint64_t next = 0;
+            const int rc = block_ref(fd, addr, br, next);
+            if (rc == 1) { eof = true; break; }
+            if (rc) return rc;
+            refs.push_back(br);
+            addr = next;
+        }
+        if (refs.empty()) break;
+        std::atomic<size_t> take{0};
+        std::atomic<int> err{0};
+        std::mutex mu;
+        std::string why;
+        auto work = [&] {
+            std::vector<uint8_t> comp;
+            std::string w;
+            for (;;) {
+                const size_t i = take.fetch_add(1);
+                if (i >= refs.size() || err.load()) return;
+                const int rc = inflate_block(fd, refs[i], comp, bufs[i], w);
+                if (rc) { std::lock_guard<std::mutex> g(mu); if (!err.load()) { err = rc; why = w; } return; }
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            const size_t nt = std::min<size_t>((size_t)threads, refs.size());
+            for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
+            work();
+            for (std::thread& t : pool) t.join();
+        }
+        if (err.load()) return fail(err.load(), "%s", why.c_str());
+        for (size_t i = 0; i < refs.size() && !done; ++i) {
+            b->z.bytes_read += refs[i].head + refs[i].clen + 8;
+            if (skip > bufs[i].size()) return fail(LGIO_E_FORMAT, "virtual offset beyond its block");
+            const uint8_t* d = bufs[i].data() + skip;
+            size_t n = bufs[i].size() - skip;
+            skip = 0;
+            // records are walked where the block lies; only one that straddles blocks is assembled in `stream`
+            while (n && !done) {
+                if (!stream.empty()) {
+                    size_t need = stream.size() < 4 ? 4 - stream.size() : 0;
+                    if (!need) {
+                        const uint32_t bs = le32(stream.data());
+                        if (bs < 32 || bs > (1u << 29)) return fail(LGIO_E_FORMAT, "implausible BAM record size %u", bs);
+                        need = 4 + (size_t)bs - stream.size();
+                    }
+                    const size_t take = std::min(need, n);
+                    stream.insert(stream.end(), d, d + take);
+                    d += take; n -= take;
+                    if (take == need && stream.size() >= 4 && stream.size() == 4 + (size_t)le32(stream.data())) {
+                        const int rc = one_record(stream.data() + 4, le32(stream.data()));
+                        if (rc < 0) return rc;
+                        stream.clear();
+                    }
+                    continue;
+                }
+                if (n < 4) { stream.assign(d, d + n); break; }
+                const uint32_t bs = le32(d);
+                if (bs < 32 || bs > (1u << 29)) return fail(LGIO_E_FORMAT, "implausible BAM record size %u", bs);
+                if (4 + (size_t)bs > n) { stream.assign(d, d + n); break; }
+                const int rc = one_record(d + 4, bs);
+                if (rc < 0) return rc;
+                d += 4 + (size_t)bs; n -= 4 + (size_t)bs;
+            }
+        }
+    }
+    if (!done && !stream.empty()) return fail(LGIO_E_FORMAT, "file ends inside a record");
+    return finish();
+}
+extern "C" int lgio_bam_ref_intervals(lgio_bam* b, int tid, int threads, lgio_intervals* out) {
+    return guarded([&] { return ref_intervals_impl(b, tid, threads, out); });
+}

@@ -70,6 +70,10 @@ class _Sites(C.Structure):       # lgio_sites
                 ('owner_', C.c_void_p)]
 
 
+class _Intervals(C.Structure):   # lgio_intervals
+    _fields_ = [('n', C.c_uint64), ('start', _i64p), ('end', _i64p), ('owner_', C.c_void_p)]
+
+
 REMOVED_REASONS = ('too many window mismatches', 'too few usable reads after filters', 'not enough allele after filters')
 
 IO_SYMBOLS = {
@@ -90,6 +94,8 @@ IO_SYMBOLS = {
     'lgio_bam_bytes_read': (C.c_uint64, [C.c_void_p]),
     'lgio_bam_region_sites': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(SiteParams), C.POINTER(_Sites)]),
     'lgio_sites_free': (None, [C.POINTER(_Sites)]),
+    'lgio_bam_ref_intervals': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(_Intervals)]),
+    'lgio_intervals_free': (None, [C.POINTER(_Intervals)]),
 }
 _iolib = None
 
@@ -286,13 +292,22 @@ class BamReader:
         finally:
             self._lib.lgio_reads_free(C.byref(rs))
 
-    def intervals(self, contig):
+    def intervals(self, contig, threads=None):
         """(starts, ends) of the mapped reads of a contig as numpy arrays — what the footprint merge needs, without
-        materialising names, sequences or tags (src/giremi/footprint.py:6-28)"""
-        t = self._table(contig, None, None, 0)
-        if t is None:
+        materialising names, sequences or tags (src/giremi/footprint.py:6-28).  The scan reads the whole contig: its BGZF
+        blocks are inflated by `threads` threads (default: the CPUs this process may use, at most 16)"""
+        tid = self._tid.get(contig)
+        if tid is None:
             raise KeyError(contig)
-        return t.start, t.end
+        if threads is None:
+            threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+        iv = _Intervals()
+        _check(self._lib.lgio_bam_ref_intervals(self._h, tid, int(threads), C.byref(iv)))
+        try:
+            n = int(iv.n)
+            return _arr(iv.start, n, np.int64), _arr(iv.end, n, np.int64)
+        finally:
+            self._lib.lgio_intervals_free(C.byref(iv))
 
     def fetch(self, contig=None, start=None, stop=None):
         t = self._table(contig, start, stop, LGIO_ALL)

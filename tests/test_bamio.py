@@ -180,3 +180,30 @@ def test_fasta_random_access(tmp_path):
             f.write('%s\t%d\t%d\t%d\t%d\n' % (name, ln, off, lb, lw))
     g2 = FastaReader(str(fa))
     assert g2.fetch('c1', 100, 200) == seqs['c1'][100:200]
+
+
+@pytest.mark.parametrize('index', [True, False])
+def test_interval_scan_with_threads_equals_the_sequential_fetch(tmp_path, index):
+    """lgio_bam_ref_intervals (blocks inflated by several threads, records walked in place, straddling records
+    assembled) against the start / end columns of a plain fetch of the whole contig — with a .bai and with the index
+    built in memory; corrupt input comes back as an error from whichever thread meets it"""
+    recs = make_bam(tmp_path / 'p.bam', n_reads=12_000, index=index)
+    rd = BamReader(str(tmp_path / 'p.bam'))
+    for contig in ('chr1', 'chr2', 'chrEmpty'):
+        want = rd._table(contig, None, None, 0)
+        for threads in (1, 3, 8, 100):
+            s, e = rd.intervals(contig, threads=threads)
+            assert np.array_equal(s, want.start) and np.array_equal(e, want.end)
+        assert len(want.start) == sum(1 for r in recs if r[0] == contig and not r[4] & 4)
+    s, e = rd.intervals('chr1')                          # default thread count
+    assert len(s) == len(rd._table('chr1', None, None, 0).start)
+    # a flipped byte in the middle of the file: CRC / inflate failure, reported, not a crash
+    raw = bytearray(open(tmp_path / 'p.bam', 'rb').read())
+    raw[len(raw) // 2] ^= 0x5A
+    bad = tmp_path / 'bad.bam'
+    bad.write_bytes(bytes(raw))
+    if index:
+        import shutil
+        shutil.copy(str(tmp_path / 'p.bam') + '.bai', str(bad) + '.bai')
+        with pytest.raises(ValueError):
+            BamReader(str(bad)).intervals('chr1', threads=4)
