@@ -23,6 +23,7 @@ requested interval, and a read contributes an empty string where it has a deleti
 from __future__ import annotations
 
 import ctypes as C
+import bisect
 import gzip
 import os
 import struct
@@ -540,12 +541,25 @@ class VcfReader:
                 c = line.split('\t')
                 start = int(c[1]) - 1
                 self._rec.setdefault(c[0], []).append(_VcfRecord(c[0], start, start + max(len(c[3]), 1)))
-        for v in self._rec.values():
+        self._starts: Dict[str, List[int]] = {}
+        self._longest: Dict[str, int] = {}
+        for c, v in self._rec.items():
             v.sort(key=lambda r: r.start)
+            self._starts[c] = [r.start for r in v]
+            self._longest[c] = max(r.stop - r.start for r in v)
 
     def fetch(self, contig, start=None, end=None):
-        for r in self._rec.get(contig, []):
-            if start is None or (r.stop > start and r.start < end):
+        recs = self._rec.get(contig, [])
+        if start is None:
+            yield from recs
+            return
+        # records are sorted by start: those that can overlap [start, end) begin before `end` and no more than the
+        # longest record before `start` (a scan of the whole contig per query was quadratic over a run's footprints)
+        starts = self._starts.get(contig, [])
+        lo = bisect.bisect_left(starts, start - self._longest.get(contig, 1) + 1)
+        hi = bisect.bisect_left(starts, end)
+        for r in recs[lo:hi]:
+            if r.stop > start:
                 yield r
 
     def close(self):
