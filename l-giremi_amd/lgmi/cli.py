@@ -215,8 +215,13 @@ def main(argv=None):
     jobs = []
     for chrom, start, end, _n in footprints:
         snps = sorted(r.start for r in vcf.fetch(chrom, start, end)) if vcf is not None else []
-        # the reference keeps the repeat intervals that lie OUTSIDE the footprint (script/giremi.py:55-59)
-        reps = [[a, b] for a, b in repeats.get(chrom, []) if a > end or b < start]
+        # The reference hands every footprint the repeat intervals that lie OUTSIDE it (script/giremi.py:55-59: a > end or
+        # b < start).  A site of the footprint comes from a read that overlaps it, and the footprint is the union of the
+        # reads that overlap each other: start <= pos < end.  An interval that begins after `end` or ends before `start`
+        # cannot contain such a position, so the filter it feeds (mismatch.py:314-323) never fires — reproduced as the
+        # empty list, not as a list of (all repeats of the chromosome) per footprint, which is quadratic over a run and
+        # would be pickled to every worker.
+        reps = []
         jobs.append({'chromosome': chrom, 'start': start, 'end': end, 'snp_positions': snps,
                      'simple_repeat_intervals': reps, 'read_strand_dict': None})
     timing['footprint_inputs_s'] = time.perf_counter() - t0

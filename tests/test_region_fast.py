@@ -258,3 +258,30 @@ def test_native_extraction_on_random_records(tmp_path):
                 compare(sam, genome, 'c', a, b, **kw)
                 compared += 1
     assert compared > 20 and declined > 0
+
+
+def test_repeat_intervals_outside_a_footprint_never_remove_a_site(tmp_path):
+    """what lgmi.cli relies on when it hands every footprint an EMPTY repeat list: the reference gives a footprint the
+    repeat intervals with a > end or b < start (script/giremi.py:55-59), and none of those can contain a site of the
+    footprint — the routine returns the same with them as without"""
+    from lgmi.region import get_region_mismatches_with_filters
+    reads, genome_seq, snps, _ = simulate_region(seed=31, n_reads=90)
+    sam, genome = _open(tmp_path, {'chrA': (reads, genome_seq, snps)})
+    start = min(r.reference_start for r in reads)
+    end = max(r.reference_start + len(r._blocks) + 400 for r in reads)       # at least the footprint's end
+    s0, e0 = sam.intervals('chrA')
+    start, end = int(s0.min()), int(e0.max())
+    rng = np.random.default_rng(4)
+    table = [[int(a), int(a + w)] for a, w in zip(rng.integers(-500, end + 2000, 400), rng.integers(1, 300, 400))]
+    outside = [[a, b] for a, b in table if a > end or b < start]
+    assert 10 < len(outside) < len(table)
+    kw = dict(chromosome='chrA', start_pos=start, end_pos=end, sam=sam, genome=genome, snp_positions=snps, min_total_depth=2)
+    with_, gone_w = get_region_mismatches_with_filters(simple_repeat_intervals=outside, **kw)
+    without, gone_wo = get_region_mismatches_with_filters(simple_repeat_intervals=[], **kw)
+    for strand in '+-':
+        assert _plain(with_[strand]) == _plain(without[strand]) and len(without[strand]) > 0
+        assert list(gone_w[strand]) == list(gone_wo[strand])
+        assert not any(v['removed'] == 'in simple repeat regions' for v in gone_w[strand].values())
+    # ... while an interval INSIDE the footprint does remove sites (the filter itself works)
+    inside, _g = get_region_mismatches_with_filters(simple_repeat_intervals=[[start, end]], **kw)
+    assert all(len(inside[strand]) == 0 for strand in '+-')
