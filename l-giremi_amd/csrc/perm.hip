@@ -374,6 +374,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     const uint64_t n_chunks = (n_rows + 63ull) / 64ull;
     __shared__ uint32_t s_queue[128];                       // rows waiting to be queued for k_perm_general
     uint32_t qn = 0u;                                       // how many (wave-uniform)
+    bool any_small = false;                                 // a queued row small enough for k_perm_enum (one store per wave, at the end)
     // (a fixed stride: taking the chunks from a shared counter, as k_perm_general takes its rows, was measured
     // slower here — 79 ms against 63 with 4 chunks per atomic, 139 ms with one)
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // wave-uniform trip count: the grid drains
@@ -404,6 +405,9 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
             tb = bounds22(G, h, kobs);
 #endif
         } else if (kind == 3) {
+            // is any queued row small enough to be enumerated?  (k_perm_enum does nothing otherwise: at north-star its pass
+            // over 1.7e7 queued rows, none of which qualifies, was 3 ms)
+            if (rc.y <= pa.enum_max && (unsigned long long)rc.y <= 4ull * (unsigned long long)n_shuffles) any_small = true;
 #if !(LGMI_PABL & 16)
             if (!n_shuffles) { out_exceed[r] = LGMI_EXCEED_EXACT; if (out_p) out_p[r] = __longlong_as_double(0x7ff8000000000000ll); }   // exact_2x2 only: no estimate
 #endif
@@ -546,6 +550,9 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     }
     __syncthreads();                                        // s_pre / s_acc are reused by the next chunk
     }   // chunk loop
+    // (thousands of waves storing to one address are served one after the other: 0.3 ms on the footprint batch — a wave
+    //  stores only while it still reads 0 there)
+    if (__any(any_small) && lane == 0u && __atomic_load_n(pa.gen_count + 3, __ATOMIC_RELAXED) == 0u) pa.gen_count[3] = 1u;
 #if !(LGMI_PABL & 16)
     if (qn) {                                               // what is left of the wave's queue
         __syncthreads();
@@ -555,6 +562,165 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
         if (lane < qn) gen_list[base + lane] = s_queue[lane];
     }
 #endif
+}
+
+// ---------------------------------------------------------------- small tables by enumeration
+// The exact mass of the tables with S >= S_obs by ENUMERATION, then one binomial variate like a 2 x 2 row (specification:
+// enum_plan / enum_mass in oracle/lgmi_perm_oracle.c).  The largest row and the largest column hold the dependent cells;
+// the other four cells (a, b) run over 0 .. min(R[a], C[b]); a row is enumerated when the product of the four ranges is at
+// most enum_max and 4 n_shuffles.  Rows of a few hundred reads with a rare third allele — what real footprints look like
+// — are a few hundred tables (median 90 in the footprint batch of bench.py) at ~150 instructions each, against ~45 trips
+// of k_perm_general's state machine for 1000 shuffles.
+// A kernel of its own in front of k_perm_general (inside it the same code cost the sampling loops 3 % through register
+// pressure).  Every lane reads one queued row and decides; the qualifying rows of the 64 are then enumerated FOUR AT A TIME,
+// sixteen lanes each (a wave per row was bound by the row's chain of dependent look-ups, and most rows do not fill 64
+// lanes twice).  The rows that stay with k_perm_general go into a second list behind the first.
+__global__ __launch_bounds__(64) void k_perm_enum(PermArgs pa)
+{
+    uint32_t* __restrict__ gen_list = pa.gen_list;
+    const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
+    const uint32_t* __restrict__ counts = pa.counts;
+    const TabG G{pa.G}; const TabLF LF{pa.LF};
+    const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
+    double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
+    const uint32_t lane = threadIdx.x & 63u, grp = lane >> 4;
+    const uint32_t n_gen = *pa.gen_count;
+    if (!pa.gen_count[3]) return;                          // k_perm_fast saw no row that qualifies
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    // there is room for the second list when the queue fills at most half of its buffer; else the finished rows are
+    // marked in the first list and skipped there.  (Walking a list of mostly finished rows cost k_perm_general one
+    // same-address atomic per row: 2.5 ms for the 2e5 rows of the footprint batch, whatever their work.)
+    const bool second = 2ull * (unsigned long long)n_gen <= pa.max_rows;
+    for (uint32_t base = blockIdx.x * 64u; base < n_gen; base += gridDim.x * 64u) {
+        const uint32_t q_mine = base + lane;
+        uint32_t r_mine = 0u, nt_mine = 0u, T_mine[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        bool en_mine = false;
+        if (q_mine < n_gen) {
+            r_mine = gen_list[q_mine];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) T_mine[k] = counts[9ull * r_mine + k];
+            const uint32_t A0 = T_mine[0] + T_mine[1] + T_mine[2], A1 = T_mine[3] + T_mine[4] + T_mine[5], A2 = T_mine[6] + T_mine[7] + T_mine[8];
+            const uint32_t B0 = T_mine[0] + T_mine[3] + T_mine[6], B1 = T_mine[1] + T_mine[4] + T_mine[7], B2 = T_mine[2] + T_mine[5] + T_mine[8];
+            // the two smaller row margins and the two smaller column margins (the product of the four ranges does not depend
+            // on which of two equal margins is taken as the largest)
+            const uint32_t amax = A0 > A1 ? (A0 > A2 ? A0 : A2) : (A1 > A2 ? A1 : A2), bmax = B0 > B1 ? (B0 > B2 ? B0 : B2) : (B1 > B2 ? B1 : B2);
+            const uint32_t amin = A0 < A1 ? (A0 < A2 ? A0 : A2) : (A1 < A2 ? A1 : A2), bmin = B0 < B1 ? (B0 < B2 ? B0 : B2) : (B1 < B2 ? B1 : B2);
+            const uint32_t amid = A0 + A1 + A2 - amax - amin, bmid = B0 + B1 + B2 - bmax - bmin;
+            unsigned long long nt = 1ull;
+            const uint32_t ra[2] = {amin, amid}, cb[2] = {bmin, bmid};
+            en_mine = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                nt *= (unsigned long long)((ra[k >> 1] < cb[k & 1] ? ra[k >> 1] : cb[k & 1]) + 1u);
+                en_mine = en_mine && nt <= pa.enum_max;
+                if (!en_mine) nt = 1ull;
+            }
+            en_mine = en_mine && nt <= 4ull * (unsigned long long)n_shuffles;
+            nt_mine = (uint32_t)nt;
+        }
+        if (second) {
+            const bool keep = q_mine < n_gen && !en_mine;
+            const unsigned long long kb = __ballot(keep);
+            if (kb) {
+                uint32_t at = 0u;
+                if (lane == 0) at = atomicAdd(pa.gen_count + 2, (unsigned int)__popcll(kb));
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                if (keep) gen_list[n_gen + at + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))] = r_mine;
+            }
+        }
+        // one row by `width` lanes (16: four rows of the wave at a time, 64: one): L = the lane that read the row
+        auto enumerate = [&](int L, bool have, uint32_t width) {
+            const uint32_t sub = lane & (width - 1u);
+            const int src = have ? L : (int)lane;
+            const uint32_t r = (uint32_t)__shfl((int)r_mine, src);
+            uint32_t T[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) T[k] = (uint32_t)__shfl((int)T_mine[k], src);
+            unsigned long long mass = 0ull;
+            uint32_t ci = 0u, cj = 0u;
+            if (have) {
+                ci = row_i[r] + pa.site_base; cj = row_j[r] + pa.site_base;
+                const uint32_t R0 = T[0] + T[1] + T[2], R1 = T[3] + T[4] + T[5], R2 = T[6] + T[7] + T[8];
+                const uint32_t C0 = T[0] + T[3] + T[6], C1 = T[1] + T[4] + T[7], C2 = T[2] + T[5] + T[8];
+                const uint32_t N = R0 + R1 + R2;
+                uint32_t la = 0u, lb = 0u;                   // the FIRST largest margin
+                if (R1 > R0) la = 1u;
+                if (R2 > (la ? R1 : R0)) la = 2u;
+                if (C1 > C0) lb = 1u;
+                if (C2 > (lb ? C1 : C0)) lb = 2u;
+                // the table in the layout rows (free, free, la) x columns (free, free, lb)
+                const uint32_t pR0 = la == 0u ? R1 : R0, pR1 = la == 2u ? R1 : R2, pR2 = la == 0u ? R0 : la == 1u ? R1 : R2;
+                const uint32_t pC0 = lb == 0u ? C1 : C0, pC1 = lb == 2u ? C1 : C2;
+                const uint32_t r0 = (pR0 < pC0 ? pR0 : pC0) + 1u, r1 = (pR0 < pC1 ? pR0 : pC1) + 1u;
+                const uint32_t r2 = (pR1 < pC0 ? pR1 : pC0) + 1u, r3 = (pR1 < pC1 ? pR1 : pC1) + 1u;
+                const uint32_t nt = r0 * r1 * r2 * r3;       // <= enum_max <= 8192 (decided above)
+                long long sobs = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sobs += G[T[k]];
+                double c0 = LF[R0];
+                c0 += LF[R1]; c0 += LF[R2]; c0 += LF[C0]; c0 += LF[C1]; c0 += LF[C2]; c0 -= LF[N];
+                // d / r for d < 2^13, r <= 2^13: the f32 quotient is within one of the integer one
+                const float i0 = 1.0f / (float)r0, i1 = 1.0f / (float)r1, i2 = 1.0f / (float)r2;
+                auto divmod = [](uint32_t d, uint32_t rr, float inv, uint32_t& rem) {
+                    uint32_t q = (uint32_t)((float)d * inv);
+                    int m = (int)d - (int)(q * rr);
+                    if (m < 0) { q--; m += (int)rr; } else if (m >= (int)rr) { q++; m -= (int)rr; }
+                    rem = (uint32_t)m;
+                    return q;
+                };
+                for (uint32_t t = sub; t < nt; t += width) {
+                    uint32_t x00, x01, x10, x11;
+                    uint32_t d = divmod(t, r0, i0, x00);
+                    d = divmod(d, r1, i1, x01);
+                    x11 = divmod(d, r2, i2, x10);
+                    const int x02 = (int)pR0 - (int)x00 - (int)x01, x12 = (int)pR1 - (int)x10 - (int)x11;
+                    const int x20 = (int)pC0 - (int)x00 - (int)x10, x21 = (int)pC1 - (int)x01 - (int)x11;
+                    const int x22 = (int)pR2 - x20 - x21;
+                    if ((x02 | x12 | x20 | x21 | x22) < 0) continue;
+                    const long long ss = G[x00] + G[x01] + G[(uint32_t)x02] + G[x10] + G[x11] + G[(uint32_t)x12] +
+                                         G[(uint32_t)x20] + G[(uint32_t)x21] + G[(uint32_t)x22];
+                    if (ss < sobs) continue;
+                    double lf = LF[x00];
+                    lf += LF[x01]; lf += LF[(uint32_t)x02]; lf += LF[x10]; lf += LF[x11]; lf += LF[(uint32_t)x12];
+                    lf += LF[(uint32_t)x20]; lf += LF[(uint32_t)x21]; lf += LF[(uint32_t)x22];
+                    mass += (unsigned long long)(det_exp(c0 - lf) * 4611686018427387904.0);   // 2^62
+                }
+            }
+            // the sum over the lanes of the group (idle groups shuffle zeros among themselves)
+            for (uint32_t o = width >> 1; o > 0u; o >>= 1) mass += __shfl_xor(mass, (int)o);
+            if (have) {
+                unsigned long long thr = mass >> 30;
+                if (thr > 4294967296ull) thr = 4294967296ull;
+                const uint32_t exceed = binom_draw(LF, n_shuffles, thr, ci, cj, k0, k1);   // (every lane of the group the same)
+                if (sub == 0u) {
+                    out_exceed[r] = exceed;
+                    if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+                    if (!second) gen_list[base + (uint32_t)L] = 0xFFFFFFFFu;   // no second list: k_perm_general skips the row
+                }
+            }
+        };
+        // rows of up to 256 tables four at a time, sixteen lanes each (a wave per row was bound by the row's chain of
+        // dependent look-ups, and the median row — 90 tables — does not fill 64 lanes twice); the larger ones by the whole
+        // wave (four of THOSE side by side cost the longest of the four, sixteen lanes wide: measured slower)
+        unsigned long long small = __ballot(en_mine && nt_mine <= 256u), big = __ballot(en_mine && nt_mine > 256u);
+        while (small) {                                      // (wave-uniform)
+            int L = -1;
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; ++g) {
+                if (small) {
+                    const int bpos = __ffsll((long long)small) - 1;
+                    small &= small - 1ull;
+                    if (grp == g) L = bpos;
+                }
+            }
+            enumerate(L, L >= 0, 16u);
+        }
+        while (big) {
+            const int L = __ffsll((long long)big) - 1;
+            big &= big - 1ull;
+            enumerate(L, true, 64u);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- general tables
@@ -661,7 +827,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
     __shared__ uint32_t next_s;
     __shared__ __attribute__((aligned(8))) uint16_t x_ring[XRING];   // lock-step rows: first draws waiting for a lane
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_gen = *gen_count;
+    // the rows k_perm_enum left: its second list when it made one (the same test as there), else the whole queue with
+    // the finished rows marked
+    const uint32_t n_queued = *gen_count;
+    const bool second = pa.enum_max && gen_count[3] && 2ull * (unsigned long long)n_queued <= pa.max_rows;
+    const uint32_t n_gen = second ? gen_count[2] : n_queued;
+    if (second) gen_list += n_queued;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     // rows are taken from a shared counter (gen_count[1], zero at launch), the next one asked for while the current
     // one runs: rows differ in cost (table size, streamlined or general loop) and a fixed stride left the average
@@ -679,6 +850,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
     for (uint32_t qk = 0; qk < batch && qk < n_gen - q0; ++qk) {
         const uint32_t q = q0 + qk;
         const uint32_t r = gen_list[q];
+        if (r == 0xFFFFFFFFu) continue;                  // done by k_perm_enum (wave-uniform)
         const uint32_t ci = row_i[r] + pa.site_base, cj = row_j[r] + pa.site_base;
         uint32_t T[9];
 #pragma unroll
@@ -1254,11 +1426,25 @@ void launch_selftest_le_exp(hipStream_t st, uint64_t n, const double* x2, const 
     hipLaunchKernelGGL(k_selftest_le_exp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, x2, t, fast, det, e_hw, e_det);
 }
 
+// LGMI_PERM_ENUM_MAX: largest number of candidate tables a larger-than-2x2 row is enumerated at (0: never; tests compare
+// both paths with the CPU specification, which has the same switch)
+static uint32_t perm_enum_max()
+{
+    static const uint32_t v = [] {
+        const char* e = getenv("LGMI_PERM_ENUM_MAX");
+        const long x = e ? atol(e) : 4096;
+        return (uint32_t)(x < 0 ? 0 : x > 8192 ? 8192 : x);
+    }();
+    return v;
+}
+
 void launch_perm_fast(hipStream_t st, const PermArgs& a)
 {
     if (!a.max_rows) return;
     const uint64_t chunks = (a.max_rows + 63) / 64;
-    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)std::min<uint64_t>(chunks, 256ull * 32ull)), dim3(64), 0, st, a);
+    PermArgs b = a;
+    b.enum_max = perm_enum_max();
+    hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)std::min<uint64_t>(chunks, 256ull * 32ull)), dim3(64), 0, st, b);
 }
 
 void launch_perm_general(hipStream_t st, const PermArgs& a)
@@ -1275,7 +1461,10 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
         const int v = e ? atoi(e) : dflt;
         return v >= 1 && v <= 32 ? v : dflt;
     }();
-    hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, a);
+    PermArgs b = a;
+    b.enum_max = perm_enum_max();
+    if (b.enum_max) hipLaunchKernelGGL(k_perm_enum, dim3(256 * 16), dim3(64), 0, st, b);
+    hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, b);
 }
 
 }  // namespace lgmi

@@ -705,6 +705,74 @@ static uint32_t perm_lockstep(const perm_tables* t, const first_table* ft, uint3
     return exceed;
 }
 
+/* ------------------------------------------------------------------ small tables: exact mass + one binomial variate
+ * (round 3)  The number of shuffles with S >= S_obs is Binomial(n_shuffles, P) whatever the table's shape; for 2 x 2
+ * tables P comes from ptail22.  A larger table whose margins admit few tables gets its P by ENUMERATION instead of
+ * n_shuffles Monte-Carlo tables — rows of a few hundred reads with a rare third allele, the shape real footprints have,
+ * are a few hundred tables:
+ *   la, lb   = the (first) largest row margin, the (first) largest column margin: their cells are the dependent ones
+ *   free     = the four cells (a, b), a != la, b != lb, in row-major order; cell (a, b) runs over 0 .. min(R[a], C[b])
+ *   n_tables = the product of the four (min(R[a], C[b]) + 1); the row is enumerated iff
+ *              n_tables <= ENUM_MAX and n_tables <= 4 n_shuffles
+ *   table t  = mixed-radix digits of t (first free cell = least significant); the dependent cells follow from the
+ *              margins; the table exists iff none of them is negative
+ *   mass     = sum over the existing tables with S >= S_obs of trunc(2^62 exp(c0 - lf)); lf = the nine LF[cell] added
+ *              row by row with the rows taken in the order (free, free, la) and the columns in the order (free, free, lb) —
+ *              the layout in which the GPU holds the table; c0 = LF[R0] + LF[R1] + LF[R2] + LF[C0] + LF[C1] + LF[C2] - LF[N]
+ *              added in this order.  The mass is an integer sum: any order
+ *   exceed   = binom_draw(n_shuffles, min(2^32, mass >> 30), ...)      (the 2 x 2 rows' stream: a row is one or the other)
+ */
+static uint32_t ENUM_MAX = 4096u;   /* (a variable only so that tests can switch the enumeration off: lgo_set_enum_max) */
+static int enum_plan(const uint32_t R[3], const uint32_t C[3], uint32_t n_shuffles, uint32_t fa[2], uint32_t fb[2],
+                     uint32_t* la_out, uint32_t* lb_out, uint32_t radix[4], uint64_t* n_tables)
+{
+    uint32_t la = 0, lb = 0, a, k = 0;
+    uint64_t n = 1;
+    for (a = 1; a < 3; ++a) { if (R[a] > R[la]) la = a; if (C[a] > C[lb]) lb = a; }
+    for (a = 0, k = 0; a < 3; ++a) if (a != la) fa[k++] = a;
+    for (a = 0, k = 0; a < 3; ++a) if (a != lb) fb[k++] = a;
+    for (k = 0; k < 4; ++k) {
+        const uint32_t ra = R[fa[k >> 1]], cb = C[fb[k & 1]];
+        radix[k] = (ra < cb ? ra : cb) + 1u;
+        n *= radix[k];
+        if (n > ENUM_MAX) return 0;
+    }
+    *la_out = la; *lb_out = lb; *n_tables = n;
+    return n <= 4ull * (uint64_t)n_shuffles;
+}
+
+static uint64_t enum_mass(const perm_tables* t, const uint32_t R[3], const uint32_t C[3], uint32_t N, int64_t sobs,
+                          const uint32_t fa[2], const uint32_t fb[2], uint32_t la, uint32_t lb, const uint32_t radix[4],
+                          uint64_t n_tables)
+{
+    uint64_t mass = 0, tt;
+    double c0 = t->LF[R[0]];
+    c0 += t->LF[R[1]]; c0 += t->LF[R[2]]; c0 += t->LF[C[0]]; c0 += t->LF[C[1]]; c0 += t->LF[C[2]]; c0 -= t->LF[N];
+    for (tt = 0; tt < n_tables; ++tt) {
+        int64_t x[3][3], rest;
+        uint32_t T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, k;
+        uint64_t d = tt;
+        int ok = 1;
+        double lf;
+        for (k = 0; k < 4; ++k) { x[fa[k >> 1]][fb[k & 1]] = (int64_t)(d % radix[k]); d /= radix[k]; }
+        for (k = 0; k < 2; ++k) {
+            x[fa[k]][lb] = (int64_t)R[fa[k]] - x[fa[k]][fb[0]] - x[fa[k]][fb[1]];
+            x[la][fb[k]] = (int64_t)C[fb[k]] - x[fa[0]][fb[k]] - x[fa[1]][fb[k]];
+        }
+        rest = (int64_t)R[la] - x[la][fb[0]] - x[la][fb[1]];
+        x[la][lb] = rest;
+        for (k = 0; k < 9; ++k) { if (x[k / 3][k % 3] < 0) ok = 0; else T[k] = (uint32_t)x[k / 3][k % 3]; }
+        if (!ok || stat9(t, T) < sobs) continue;
+        {
+            const uint32_t ro[3] = {fa[0], fa[1], la}, co[3] = {fb[0], fb[1], lb};
+            lf = t->LF[T[3 * ro[0] + co[0]]];
+            for (k = 1; k < 9; ++k) lf += t->LF[T[3 * ro[k / 3] + co[k % 3]]];
+        }
+        mass += (uint64_t)(lgo_det_exp(c0 - lf) * 4611686018427387904.0);
+    }
+    return mass;
+}
+
 static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row_i, uint32_t row_j,
                          uint32_t n_shuffles, uint64_t seed, double* ptail_out)
 {
@@ -736,6 +804,15 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
     {
         const int64_t sobs = stat9(t, T);
         first_table ft;
+        {
+            uint32_t fa[2], fb[2], la, lb, radix[4];
+            uint64_t n_tables;
+            if (enum_plan(R, C, n_shuffles, fa, fb, &la, &lb, radix, &n_tables)) {
+                uint64_t thr = enum_mass(t, R, C, N, sobs, fa, fb, la, lb, radix, n_tables) >> 30;
+                if (thr > 4294967296ull) thr = 4294967296ull;
+                return binom_draw(t, n_shuffles, thr, row_i, row_j, k0, k1);
+            }
+        }
         first_table_build(t, N, R[nzr[0]], C[nzc[0]], &ft);   /* the first non-empty row and column */
         if (ft.valid && nr * nc == 6 && N - R[nzr[0]] > 1 && N - C[nzc[0]] > 1)
             hrua_width_bound(&ft, N, (int)nr, R[nzr[0]], R[nzr[1]], C[nzc[0]], C[nzc[1]]);
@@ -924,4 +1001,29 @@ int lgo_perm_ptail(const uint32_t T[9], double* ptail)
 int lgo_hg_draw_many(uint32_t pop, uint32_t good, uint32_t sample, uint64_t seed, uint32_t n, uint32_t* out)
 {
     return lgo_hg_draw_many2(pop, good, sample, seed, n, out, 0);
+}
+
+/* test hook: the enumerated mass of a table larger than 2 x 2 (units of 2^-62) and its number of candidate tables;
+ * returns 1 when the row is enumerated at this n_shuffles, 0 when it keeps the Monte-Carlo path, -1 on error */
+int lgo_perm_enum_mass(const uint32_t T[9], uint32_t n_shuffles, uint64_t* mass, uint64_t* n_tables)
+{
+    perm_tables t;
+    uint32_t R[3], C[3], N = 0, a, fa[2], fb[2], la, lb, radix[4];
+    int ok;
+    for (a = 0; a < 3; ++a) { R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2]; C[a] = T[a] + T[3 + a] + T[6 + a]; N += R[a]; }
+    if (tables_init(&t, N)) return -1;
+    *mass = 0; *n_tables = 0;
+    ok = enum_plan(R, C, n_shuffles, fa, fb, &la, &lb, radix, n_tables);
+    if (ok) *mass = enum_mass(&t, R, C, N, stat9(&t, T), fa, fb, la, lb, radix, *n_tables);
+    free(t.G); free(t.LF);
+    return ok;
+}
+
+/* test hook: the largest number of candidate tables a row is enumerated at (0: every larger-than-2x2 row keeps the
+ * Monte-Carlo path); the GPU library reads the same from LGMI_PERM_ENUM_MAX.  Returns the previous value. */
+uint32_t lgo_set_enum_max(uint32_t v)
+{
+    const uint32_t old = ENUM_MAX;
+    ENUM_MAX = v;
+    return old;
 }

@@ -1,0 +1,37 @@
+"""GPU parity of the permutation stage with the small-table enumeration switched OFF on both sides (LGMI_PERM_ENUM_MAX=0
+in the environment of this process, lgo_set_enum_max(0) in the CPU specification): every larger-than-2x2 row takes the
+Monte-Carlo path — the urn draws and the per-lane state machine that small rows otherwise no longer reach at large S.
+Run by tests/test_gpu_parity.py in a process of its own (the library reads the variable once)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'l-giremi_amd'), os.path.join(ROOT, 'tests')]
+assert os.environ.get('LGMI_PERM_ENUM_MAX') == '0'
+
+import lgmi                                        # noqa: E402
+from oracle import c_oracle                        # noqa: E402
+from util_synth import random_batch                # noqa: E402
+
+lib = c_oracle.load()
+lib.lgo_set_enum_max.restype = ctypes.c_uint32
+lib.lgo_set_enum_max.argtypes = [ctypes.c_uint32]
+lib.lgo_set_enum_max(0)
+eng = lgmi.Engine(0)
+rows = general = 0
+for seed in range(6):
+    pb = random_batch(5200 + seed, n_blocks=1 + seed % 3, tri_frac=0.3, R=(6, 900))
+    S = [100, 257, 1000][seed % 3]
+    ora = c_oracle.run(pb, min_common=[1, 5][seed % 2], het_only=True, n_shuffles=S, seed=7 + seed)
+    res = eng.run(pb, min_common=[1, 5][seed % 2], het_only=True, n_shuffles=S, seed=7 + seed, emit_counts=True)
+    np.testing.assert_array_equal(res.row_i, ora['row_i'])
+    np.testing.assert_array_equal(res.row_counts, ora['row_counts'])
+    np.testing.assert_array_equal(res.row_exceed, ora['row_exceed'])
+    c = res.row_counts.reshape(-1, 3, 3)
+    general += int((((c.sum(axis=2) > 0).sum(axis=1) > 2) | ((c.sum(axis=1) > 0).sum(axis=1) > 2)).sum())
+    rows += res.n_rows
+eng.close()
+print('OK rows=%d general=%d' % (rows, general))

@@ -595,3 +595,17 @@ def test_stream_site_base_shifts_the_philox_counters(engine):
     _p, want = c_oracle.perm_rows(b.row_i + np.uint32(base), b.row_j + np.uint32(base), b.row_counts, 60, 11)
     np.testing.assert_array_equal(b.row_exceed, want)
     assert (a.row_exceed != b.row_exceed).any()
+
+
+def test_permutation_p_with_the_enumeration_switched_off():
+    """small larger-than-2x2 rows get their tail mass by enumeration (round 3); with LGMI_PERM_ENUM_MAX=0 — and the same
+    switch in the CPU specification — they all take the Monte-Carlo path again: tests/helpers/perm_enum_worker.py"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, 'helpers', 'perm_enum_worker.py')],
+                       env=dict(os.environ, LGMI_PERM_ENUM_MAX='0'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith('OK') and int(last.split('general=')[1]) > 100

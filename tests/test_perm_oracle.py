@@ -433,3 +433,87 @@ def test_lockstep_prefix_property(lib):
     _, a = _lockstep_rec(lib, T, 700)
     _, b = _lockstep_rec(lib, T, 2500)
     assert (b[:700] == a).all()
+
+
+def exact_p_fast(T):
+    """P(S >= S_obs) over all tables with the margins of T, like exact_p_general but as one numpy grid over the four
+    cells of the two SMALLEST rows and columns (independent of the specification's code; any choice of free cells
+    enumerates the same set of tables)"""
+    from scipy.special import gammaln
+    M = np.asarray(T, np.int64).reshape(3, 3)
+    ro, co = np.argsort(M.sum(axis=1), kind='stable'), np.argsort(M.sum(axis=0), kind='stable')
+    M = M[ro][:, co]                                   # largest row and column last: their cells are the dependent ones
+    R, Cm, N = M.sum(axis=1), M.sum(axis=0), int(M.sum())
+    g = [np.arange(min(R[a], Cm[b]) + 1, dtype=np.int64) for a in (0, 1) for b in (0, 1)]
+    x00, x01, x10, x11 = np.meshgrid(*g, indexing='ij', sparse=True)
+    cells = [x00, x01, R[0] - x00 - x01, x10, x11, R[1] - x10 - x11, Cm[0] - x00 - x10, Cm[1] - x01 - x11]
+    cells.append(R[2] - cells[6] - cells[7])
+    cells = [np.broadcast_to(c, np.broadcast_shapes(*[k.shape for k in cells])) for c in cells]
+    ok = np.ones(cells[0].shape, bool)
+    for c in cells:
+        ok &= c >= 0
+    cells = [c[ok].astype(np.float64) for c in cells]
+    const = gammaln(R + 1.0).sum() + gammaln(Cm + 1.0).sum() - gammaln(N + 1.0)
+    pr = np.exp(const - sum(gammaln(c + 1.0) for c in cells))
+    st = sum(np.where(c > 0, c * np.log(np.maximum(c, 1.0)), 0.0) for c in cells)
+    sobs = float(sum(v * np.log(v) for v in M.ravel() if v > 0))
+    assert abs(pr.sum() - 1) < 1e-9
+    return float(pr[st >= sobs - 1e-9 * max(1.0, abs(sobs))].sum())
+
+
+# ---- small tables by enumeration (round 3: enum_plan / enum_mass)
+def _enum(lib, T, n_shuffles=100000):
+    lib.lgo_perm_enum_mass.restype = C.c_int
+    lib.lgo_perm_enum_mass.argtypes = [u32p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    mass, nt = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.lgo_perm_enum_mass(np.asarray(T, np.uint32).ctypes.data_as(u32p), n_shuffles, C.byref(mass), C.byref(nt))
+    return rc, mass.value * 2.0 ** -62, nt.value
+
+
+ENUM_TABLES = [[3, 2, 1, 1, 6, 2, 2, 1, 7], [4, 0, 2, 1, 5, 0, 0, 2, 6], [0, 0, 0, 2, 6, 3, 5, 1, 4], [2, 0, 5, 1, 0, 8, 6, 0, 3],
+               [10, 3, 2, 2, 9, 4, 1, 3, 12], [40, 3, 0, 5, 30, 0, 2, 1, 0], [0, 25, 4, 0, 3, 31, 0, 6, 2], [7, 7, 7, 7, 7, 7, 7, 7, 7],
+               [120, 2, 0, 3, 90, 0, 1, 4, 0], [1, 0, 0, 0, 1, 0, 0, 0, 1]]
+
+
+@pytest.mark.parametrize('T', ENUM_TABLES)
+def test_enumerated_mass_is_the_exact_tail_probability(lib, T):
+    rc, mass, nt = _enum(lib, T)
+    M = np.asarray(T).reshape(3, 3)
+    R, Cm = M.sum(axis=1), M.sum(axis=0)
+    la, lb = int(np.argmax(R)), int(np.argmax(Cm))            # first largest margin
+    want = int(np.prod([min(R[a], Cm[b]) + 1 for a in range(3) if a != la for b in range(3) if b != lb]))
+    assert rc == (1 if want <= 4096 else 0)
+    if not rc:
+        return
+    assert nt == want
+    exact = exact_p_fast(T)
+    assert abs(mass - exact) <= 1e-11 * max(exact, 1e-30) + nt * 2.0 ** -61, (mass, exact)
+
+
+def test_enumeration_limits(lib):
+    # too many candidate tables, or more than 4 n_shuffles of them: the row keeps the Monte-Carlo path
+    assert _enum(lib, [300, 200, 100, 150, 250, 90, 80, 120, 310])[0] == 0
+    T = [10, 3, 0, 2, 9, 0, 1, 3, 0]
+    nt = _enum(lib, T)[2]
+    assert _enum(lib, T, n_shuffles=(nt + 3) // 4)[0] == 1 and _enum(lib, T, n_shuffles=(nt + 3) // 4 - 1)[0] == 0
+    # a 3 x 2 row of a few hundred reads with a rare third allele: a few hundred tables
+    rc, mass, nt = _enum(lib, [180, 0, 150, 12, 0, 9, 3, 0, 2], 1000)
+    assert rc == 1 and nt <= 4000 and 0 < mass <= 1
+
+
+@pytest.mark.parametrize('T', ENUM_TABLES[:4] + ENUM_TABLES[5:7])
+def test_monte_carlo_and_enumeration_paths_agree(lib, T):
+    """the same rows through both paths of the specification: exceed / S of the Monte-Carlo path (enumeration switched
+    off) and of the enumeration path (one binomial variate) both sit on the exact tail probability"""
+    lib.lgo_set_enum_max.restype = C.c_uint32
+    lib.lgo_set_enum_max.argtypes = [C.c_uint32]
+    S = 40000
+    exact = exact_p_fast(T)
+    sd = np.sqrt(max(exact * (1 - exact), 1e-12) / S)
+    old = lib.lgo_set_enum_max(0)
+    try:
+        _p, ex_mc = run_perm([T], S)
+    finally:
+        lib.lgo_set_enum_max(old)
+    _p, ex_enum = run_perm([T], S)
+    assert abs(ex_mc[0] / S - exact) < 5 * sd + 2e-4 and abs(ex_enum[0] / S - exact) < 5 * sd + 2e-4
