@@ -1463,6 +1463,10 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
     }();
     PermArgs b = a;
     b.enum_max = perm_enum_max();
+    // LGMI_PERM_NO_SECOND_LIST=1 (tests): as if the queue filled more than half of its buffer — k_perm_enum marks the rows it
+    // finishes in the queue and k_perm_general skips them, instead of walking a second list
+    static const bool no_second = [] { const char* e = getenv("LGMI_PERM_NO_SECOND_LIST"); return e && atoi(e) != 0; }();
+    if (no_second) b.max_rows = 1;
     if (b.enum_max) hipLaunchKernelGGL(k_perm_enum, dim3(256 * 16), dim3(64), 0, st, b);
     hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, b);
 }

@@ -1,7 +1,11 @@
-"""GPU parity of the permutation stage with the small-table enumeration switched OFF on both sides (LGMI_PERM_ENUM_MAX=0
-in the environment of this process, lgo_set_enum_max(0) in the CPU specification): every larger-than-2x2 row takes the
-Monte-Carlo path — the urn draws and the per-lane state machine that small rows otherwise no longer reach at large S.
-Run by tests/test_gpu_parity.py in a process of its own (the library reads the variable once)."""
+"""GPU parity of the permutation stage in the two configurations the default run does not reach, each in a process of
+its own (the library reads its variables once), started by tests/test_gpu_parity.py:
+  LGMI_PERM_ENUM_MAX=0     the small-table enumeration switched OFF on both sides (lgo_set_enum_max(0) in the CPU
+                           specification): every larger-than-2x2 row takes the Monte-Carlo path — the urn draws and the
+                           per-lane state machine that small rows otherwise no longer reach at large S;
+  LGMI_PERM_ENUM_MAX=4096 LGMI_PERM_NO_SECOND_LIST=1
+                           the enumeration on, but k_perm_enum marking its rows in the queue instead of making the second
+                           list (what it does when the queue fills more than half of its buffer)."""
 import ctypes
 import os
 import sys
@@ -10,7 +14,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'l-giremi_amd'), os.path.join(ROOT, 'tests')]
-assert os.environ.get('LGMI_PERM_ENUM_MAX') == '0'
+MODE = os.environ.get('LGMI_PERM_ENUM_MAX')
+assert MODE in ('0', '4096')
 
 import lgmi                                        # noqa: E402
 from oracle import c_oracle                        # noqa: E402
@@ -19,7 +24,7 @@ from util_synth import random_batch                # noqa: E402
 lib = c_oracle.load()
 lib.lgo_set_enum_max.restype = ctypes.c_uint32
 lib.lgo_set_enum_max.argtypes = [ctypes.c_uint32]
-lib.lgo_set_enum_max(0)
+lib.lgo_set_enum_max(int(MODE))
 eng = lgmi.Engine(0)
 rows = general = 0
 for seed in range(6):

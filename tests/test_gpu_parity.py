@@ -597,15 +597,18 @@ def test_stream_site_base_shifts_the_philox_counters(engine):
     assert (a.row_exceed != b.row_exceed).any()
 
 
-def test_permutation_p_with_the_enumeration_switched_off():
-    """small larger-than-2x2 rows get their tail mass by enumeration (round 3); with LGMI_PERM_ENUM_MAX=0 — and the same
-    switch in the CPU specification — they all take the Monte-Carlo path again: tests/helpers/perm_enum_worker.py"""
+@pytest.mark.parametrize('env', [{'LGMI_PERM_ENUM_MAX': '0'}, {'LGMI_PERM_ENUM_MAX': '4096', 'LGMI_PERM_NO_SECOND_LIST': '1'}],
+                         ids=['enumeration_off', 'rows_marked_in_the_queue'])
+def test_permutation_p_in_the_other_configurations(env):
+    """small larger-than-2x2 rows get their tail mass by enumeration (round 3).  With LGMI_PERM_ENUM_MAX=0 — and the same
+    switch in the CPU specification — they all take the Monte-Carlo path again; with LGMI_PERM_NO_SECOND_LIST=1 the
+    enumeration kernel marks its rows in the queue instead of listing the others: tests/helpers/perm_enum_worker.py"""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, 'helpers', 'perm_enum_worker.py')],
-                       env=dict(os.environ, LGMI_PERM_ENUM_MAX='0'), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith('OK') and int(last.split('general=')[1]) > 100
