@@ -572,9 +572,13 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 // — are a few hundred tables (median 90 in the footprint batch of bench.py) at ~150 instructions each, against ~45 trips
 // of k_perm_general's state machine for 1000 shuffles.
 // A kernel of its own in front of k_perm_general (inside it the same code cost the sampling loops 3 % through register
-// pressure).  Every lane reads one queued row and decides; the qualifying rows of the 64 are then enumerated FOUR AT A TIME,
+// pressure).  The first ENUM_ROWS lanes read one queued row each and decide; the qualifying rows are then enumerated FOUR AT A TIME,
 // sixteen lanes each (a wave per row was bound by the row's chain of dependent look-ups, and most rows do not fill 64
 // lanes twice).  The rows that stay with k_perm_general go into a second list behind the first.
+#ifndef LGMI_ENUM_ROWS
+#define LGMI_ENUM_ROWS 16
+#endif
+static const uint32_t ENUM_ROWS = LGMI_ENUM_ROWS;   // <= 64
 __global__ __launch_bounds__(64) void k_perm_enum(PermArgs pa)
 {
     uint32_t* __restrict__ gen_list = pa.gen_list;
@@ -591,11 +595,14 @@ __global__ __launch_bounds__(64) void k_perm_enum(PermArgs pa)
     // marked in the first list and skipped there.  (Walking a list of mostly finished rows cost k_perm_general one
     // same-address atomic per row: 2.5 ms for the 2e5 rows of the footprint batch, whatever their work.)
     const bool second = 2ull * (unsigned long long)n_gen <= pa.max_rows;
-    for (uint32_t base = blockIdx.x * 64u; base < n_gen; base += gridDim.x * 64u) {
+    // (ENUM_ROWS = 16 queued rows per wave and round; with 64 the footprint batch's 2e5 rows are ONE round of the grid:
+    //  2.18 ms for this kernel and k_perm_general together against 2.04; 8: 1.95, 32: 2.07)
+    for (uint32_t base = blockIdx.x * ENUM_ROWS; base < n_gen; base += gridDim.x * ENUM_ROWS) {
         const uint32_t q_mine = base + lane;
         uint32_t r_mine = 0u, nt_mine = 0u, T_mine[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         bool en_mine = false;
-        if (q_mine < n_gen) {
+        const bool mine = lane < ENUM_ROWS && q_mine < n_gen;
+        if (mine) {
             r_mine = gen_list[q_mine];
 #pragma unroll
             for (int k = 0; k < 9; ++k) T_mine[k] = counts[9ull * r_mine + k];
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(64) void k_perm_enum(PermArgs pa)
             nt_mine = (uint32_t)nt;
         }
         if (second) {
-            const bool keep = q_mine < n_gen && !en_mine;
+            const bool keep = mine && !en_mine;
             const unsigned long long kb = __ballot(keep);
             if (kb) {
                 uint32_t at = 0u;
