@@ -100,7 +100,13 @@ def _write_removed(df, path, header=True):
         if c == 'pos':
             arrays.append(pa.array(df[c].to_numpy()))
             continue
-        codes, uniq = pd.factorize(df[c].to_numpy())
+        if isinstance(df[c].dtype, pd.CategoricalDtype):
+            codes, uniq = df[c].cat.codes.to_numpy(), list(df[c].cat.categories)
+            if (codes < 0).any():                                          # a missing value: pandas writes an empty field
+                df.to_csv(path, sep='\t', index=False, header=header)
+                return
+        else:
+            codes, uniq = pd.factorize(df[c].to_numpy())
         if any(not isinstance(u, str) or any(ch in u for ch in '\t\n\r"') for u in uniq):
             df.to_csv(path, sep='\t', index=False, header=header)     # something pandas would quote
             return

@@ -66,15 +66,19 @@ def mean_mismatch_pair_mutual_info(mismatch_pair_mi, engine: Optional[Engine] = 
     return [[pos, float(mean[k])] for pos, k in index.items()]
 
 
-def _run_regions(regions, min_common_reads, n_shuffles, seed, engine):
-    """pack every (footprint, strand) of `regions` as one batch and run it -> (batch, result) or (None, None)"""
+def _run_regions(regions, min_common_reads, n_shuffles, seed, engine, batch=None):
+    """pack every (footprint, strand) of `regions` as one batch and run it -> (batch, result) or (None, None);
+    `batch`: the same blocks already packed (the extraction workers of a whole run pack their own footprints)"""
     blocks = []
     for mm, _chrom in regions:
         blocks.extend(mm.get(s, {}) for s in ('+', '-'))
     if not any(len(b) > 1 for b in blocks):
         return None, None
     eng = engine or default_engine()
-    batch = pack_blocks(blocks)
+    if batch is None:
+        batch = pack_blocks(blocks)
+    elif batch.n_blocks != len(blocks):
+        raise ValueError('pre-packed batch has %d blocks for %d (footprint, strand) pairs' % (batch.n_blocks, len(blocks)))
     res = eng.run(batch, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True)
     if batch.bad_sites.any():
         # the reference ranks the alleles of BOTH sites of every qualifying pair — het-involved or not — before the
@@ -134,7 +138,7 @@ def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: O
     return out
 
 
-def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None):
+def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None, batch=None):
     """The same launch, returned the way a whole run consumes it: ONE table of all regions' pair rows in the
     reference's order (script/giremi.py:381-394 concatenates the per-footprint frames of mismatch.py:407-418) built
     column by column from the result arrays — no Python object per row, which is what 10^7 rows of tens of
@@ -143,7 +147,7 @@ def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, eng
     import pandas as pd
     regions = list(regions)
     cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
-    batch, res = _run_regions(regions, min_common_reads, n_shuffles, seed, engine)
+    batch, res = _run_regions(regions, min_common_reads, n_shuffles, seed, engine, batch)
     if batch is None or res.n_rows == 0:
         df = pd.DataFrame({c: [] for c in cols})
         if n_shuffles:
@@ -164,7 +168,7 @@ def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, eng
     return df, _site_means(batch, res, len(regions))
 
 
-def regions_pair_mi_table_dist(regions, group, engine: Engine, min_common_reads=5, n_shuffles=0, seed=0, root=0):
+def regions_pair_mi_table_dist(regions, group, engine: Engine, min_common_reads=5, n_shuffles=0, seed=0, root=0, batch=None):
     """regions_pair_mi_table when the footprints of a run were dealt to several ranks (one process per GPU; the
     reference's analogue is the chunked Pool.map over footprints, src/giremi/script/giremi.py:367-394): every rank
     packs and runs ITS regions, the pair rows of all ranks travel HBM-to-HBM onto `root` in rank order
@@ -178,7 +182,8 @@ def regions_pair_mi_table_dist(regions, group, engine: Engine, min_common_reads=
     blocks = []
     for mm, _chrom in regions:
         blocks.extend(mm.get(s, {}) for s in ('+', '-'))
-    batch = pack_blocks(blocks) if blocks else pack_blocks([{}])
+    if batch is None or batch.n_blocks != len(blocks) or not blocks:
+        batch = pack_blocks(blocks) if blocks else pack_blocks([{}])
     n_sites = len(batch.site_pos)
     counts = group.allgather(int(n_sites))
     base = int(sum(counts[:rank]))

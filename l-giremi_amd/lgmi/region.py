@@ -356,11 +356,15 @@ def _compact_gone(gone):
     return out, reasons
 
 
+_STRIP_READS = True      # (tests that stand a CPU oracle in for the MI step need the read lists back from the workers)
+
+
 def _extract_chunk(job, sam=None, genome=None):
     """site extraction + filters for a list of footprints -> [(chromosome, sites, gone)] (pool worker and serial path);
     with job[3] (compact) `gone` is the array form of _compact_gone"""
     reopen, footprints, filter_kwargs = job[:3]
     compact = len(job) > 3 and job[3]
+    pack = len(job) > 4 and job[4]
     if reopen is not None:
         sam, genome = reopen()
     out = []
@@ -381,6 +385,21 @@ def _extract_chunk(job, sam=None, genome=None):
             if not compact:
                 gone = {strand: dict(d) for strand, d in gone.items()}
         out.append((fp['chromosome'], sites, gone))
+    if pack:
+        # a worker of a whole run packs its own footprints (the parent concatenates the chunks' batches): the packing is
+        # spread over the pool like the extraction, and the read-name lists — most of what a chunk's result weighs, and of
+        # no use after the packing — stay here
+        from .pack import pack_blocks
+        blocks = []
+        for _chrom, sites, _gone in out:
+            blocks.extend(sites.get(s, {}) for s in '+-')
+        batch = pack_blocks(blocks) if blocks else None
+        if _STRIP_READS:
+            for _chrom, sites, _gone in out:
+                for strand in '+-':
+                    for site in sites[strand].values():
+                        site['nt'] = {a: len(v) for a, v in site['nt'].items()}     # (allele order kept; _site_rows reads depth)
+        return out, batch
     return out
 
 
@@ -399,6 +418,7 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     t0 = time.perf_counter()
     footprints = list(footprints)
     staged = None
+    prepacked = None                        # the footprints' blocks already packed by the extraction workers
     if threads and threads > 1 and len(footprints) > 1 and reopen is not None:
         # host-side site extraction is per footprint and shares nothing: the reference maps it over a process pool
         # (script/giremi.py:367-380, -t); so does this, with the MI step kept OUT of the workers — they return site
@@ -406,9 +426,17 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
         # (`reopen()` -> (sam, genome)); the pool must be done before the parent creates its HIP context (fork).
         import multiprocessing as mp
         chunk = max(1, -(-len(footprints) // (4 * threads)))
-        jobs = [(reopen, footprints[k:k + chunk], filter_kwargs, bool(concat)) for k in range(0, len(footprints), chunk)]
+        jobs = [(reopen, footprints[k:k + chunk], filter_kwargs, bool(concat), bool(concat))
+                for k in range(0, len(footprints), chunk)]
         with mp.get_context('fork').Pool(threads) as pool:
-            staged = [x for part in pool.map(_extract_chunk, jobs) for x in part]
+            parts = pool.map(_extract_chunk, jobs)
+        if concat:
+            from .pack import concat_batches
+            staged = [x for part, _b in parts for x in part]
+            batches = [b for _part, b in parts if b is not None]
+            prepacked = concat_batches(batches) if batches else None
+        else:
+            staged = [x for part in parts for x in part]
     if staged is None:
         staged = _extract_chunk((None, footprints, filter_kwargs, bool(concat)), sam, genome)
     if callable(engine) and not hasattr(engine, 'run'):
@@ -423,29 +451,36 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
             # several ranks, each with its own contiguous run of footprints: the pair rows are gathered over RCCL onto
             # rank 0 (df_pairs is None elsewhere); the two site tables stay per rank (the caller concatenates them)
             df_pairs, means = regions_pair_mi_table_dist([(sites, chrom) for chrom, sites, _gone in staged], group, engine,
-                                                         min_common_reads, n_shuffles=n_shuffles, seed=seed)
+                                                         min_common_reads, n_shuffles=n_shuffles, seed=seed, batch=prepacked)
         else:
             df_pairs, means = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in staged], min_common_reads,
-                                                    n_shuffles=n_shuffles, seed=seed, engine=engine)
+                                                    n_shuffles=n_shuffles, seed=seed, engine=engine, batch=prepacked)
         if timing is not None:
             timing['pack_gpu_table_s'] = time.perf_counter() - t0
             t0 = time.perf_counter()
         site_rows = []
+        # the removed table is one row per covered position of every footprint — tens of millions in a run: its three
+        # string columns are built as categoricals from small-integer codes (values, order and what to_csv writes are
+        # those of plain string columns)
+        chrom_code, reason_code = {}, {}
         g_chrom, g_strand, g_pos, g_reason = [], [], [], []
         for (chrom, sites, (gone, reasons)), mean_mi in zip(staged, means):
             site_rows.extend(_site_rows(chrom, sites, mean_mi))
-            table = np.array(reasons, dtype=object)
-            for strand in '+-':
+            cc = chrom_code.setdefault(chrom, len(chrom_code))
+            remap = np.array([reason_code.setdefault(r, len(reason_code)) for r in reasons], np.int8)
+            for k, strand in enumerate('+-'):
                 pos, codes = gone[strand]
                 if len(pos):
-                    g_chrom.append(np.full(len(pos), chrom, dtype=object))
-                    g_strand.append(np.full(len(pos), strand, dtype=object))
+                    g_chrom.append(np.full(len(pos), cc, np.int32))
+                    g_strand.append(np.full(len(pos), k, np.int8))
                     g_pos.append(pos)
-                    g_reason.append(table[codes])
+                    g_reason.append(remap[codes])
         cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+        as_cat = lambda parts, dt, names: pd.Categorical.from_codes(cat(parts, dt), categories=list(names))
         out = (pd.DataFrame.from_records(site_rows, columns=_SITE_COLS), df_pairs,
-               pd.DataFrame({'chromosome': cat(g_chrom, object), 'strand': cat(g_strand, object), 'pos': cat(g_pos, np.int64),
-                             'removed': cat(g_reason, object)}, columns=['chromosome', 'strand', 'pos', 'removed']))
+               pd.DataFrame({'chromosome': as_cat(g_chrom, np.int32, chrom_code), 'strand': as_cat(g_strand, np.int8, '+-'),
+                             'pos': cat(g_pos, np.int64), 'removed': as_cat(g_reason, np.int8, reason_code)},
+                            columns=['chromosome', 'strand', 'pos', 'removed']))
         if timing is not None:
             timing['site_tables_s'] = time.perf_counter() - t0
         return out

@@ -149,13 +149,14 @@ def test_cli_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
-    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None):
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None):
         blocks = oracle_blocks(regions, mc)
         cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
         return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),
                 [m for _r, m, _p in blocks])
     monkeypatch.setattr(region, 'regions_pair_mi', oracle_blocks)
     monkeypatch.setattr(region, 'regions_pair_mi_table', oracle_table)
+    monkeypatch.setattr(region, '_STRIP_READS', False)        # the oracle stand-in reads the read lists
     monkeypatch.setattr(lgmi.engine, 'Engine', NoEngine)
     run_cli_and_compare(tmp_path)
     # -t 2: the site extraction of the two footprints in a process pool (the reference's -t), same files out
@@ -223,13 +224,14 @@ def test_cli_cfg1_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
-    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None):
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None):
         blocks = oracle_blocks(regions, mc)
         cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
         return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),
                 [m for _r, m, _p in blocks])
     monkeypatch.setattr(region, 'regions_pair_mi', oracle_blocks)
     monkeypatch.setattr(region, 'regions_pair_mi_table', oracle_table)
+    monkeypatch.setattr(region, '_STRIP_READS', False)
     monkeypatch.setattr(lgmi.engine, 'Engine', NoEngine)
     gold, bam, fa, vcf = cfg1_inputs(tmp_path)
     from lgmi import cli
@@ -325,6 +327,10 @@ def test_removed_table_writer_matches_pandas(tmp_path):
                        'strand': np.where(k % 2, '+', '-').astype(object), 'pos': k.astype(np.int64) * 3 - 5,
                        'removed': np.array(['too few usable reads after filters', 'in homopoly regions'], dtype=object)[k % 2]})
     cases = [(df, True), (df, False), (df.iloc[:0], True)]
+    # what regions_mismatch_analysis(concat=True) hands the CLI: the string columns as categoricals
+    as_cat = df.assign(chromosome=pd.Categorical(df['chromosome']), strand=pd.Categorical(df['strand'], categories=['+', '-']),
+                       removed=pd.Categorical(df['removed']))
+    cases.append((as_cat, True))
     odd = df.iloc[:10].copy()
     odd.loc[odd.index[3], 'removed'] = 'has\ttab'                     # pandas quotes it: the writer must fall back
     cases.append((odd, True))
