@@ -837,7 +837,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if ((rc = salloc((void**)&d_rowcnt, std::max<size_t>(n_items, 1) * 4))) return rc;
     if ((rc = salloc((void**)&d_rowstart, (n_items + 1) * 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
-    if ((rc = salloc((void**)&d_cnt, (size_t)ns * 4 + 32))) return rc;
+    if ((rc = salloc((void**)&d_cnt, (size_t)ns * 4 + 64))) return rc;
     d_err = (int*)(d_cnt + ns);
     unsigned int* d_gencount = (unsigned int*)(d_cnt + ns) + 1;    // [0] queued rows, [1] k_perm_general's next row, [2] rows k_perm_enum leaves to it, [3] some row is enumerable (zeroed with d_cnt)
     d_wordpairs = nullptr;
@@ -882,7 +882,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     pcache->on_device = true;
     tr.mark("uploaded");
     if (ns) HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
-    HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 32, st));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 64, st));
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
 
     // FP4 matrix-core blocks: operands re-laid in wave-load order (part of "prep": ~2 ms at north-star)
@@ -1162,8 +1162,8 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
     unsigned int n_general = 0;
     if (res->cap_rows) {
         if ((rc = pool.alloc((void**)&d_genlist, (size_t)res->cap_rows * 4))) return rc;
-        if ((rc = pool.alloc((void**)&d_gencount, 32))) return rc;      // [0] queued rows, [1] k_perm_general's next row, [2] rows k_perm_enum leaves to it, [3] some row is enumerable
-        HIPCHK(hipMemsetAsync(d_gencount, 0, 32, st));
+        if ((rc = pool.alloc((void**)&d_gencount, 64))) return rc;      // [0] queued rows, [1] k_perm_general's next row, [2] rows k_perm_enum leaves to it, [3] some row is enumerable
+        HIPCHK(hipMemsetAsync(d_gencount, 0, 64, st));
         PermArgs pa{};
         pa.n_rows_dev = res->d_nrows; pa.max_rows = res->cap_rows;
         pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.rec = res->d_rec; pa.G = ctx->d_G; pa.LF = ctx->d_LF;

@@ -167,9 +167,11 @@ struct PermArgs {
     uint32_t site_base;           // added to row_i / row_j in the Philox counters (lgmi_params.stream_site_base)
     int exact_2x2;                // rows with at most 2 x 2 non-empty classes get the exact p, not a binomial draw
     uint32_t enum_max;            // larger tables with at most this many candidate tables: exact mass by enumeration (set by launch_perm_general)
+    uint32_t six_pts;             // six-cell tables: lattice points per shuffle a row may cost on the exact path, 0 = off (set by launch_perm_general)
     double* out_p; uint32_t* out_exceed;   // out_p may be NULL (lgmi_params.no_row_p: p is a function of exceed)
     uint32_t* gen_list; unsigned int* gen_count;   // gen_count[0] rows queued by k_perm_fast, [1] next row of k_perm_general, [2] rows k_perm_enum
-                                                   // leaves to k_perm_general, listed at gen_list + gen_count[0] (all three zero at launch)
+                                                   // leaves to k_perm_general, listed at gen_list + gen_count[0], [3] some row is enumerable,
+                                                   // [4] rows k_perm_six leaves (third list), [5] its next row, [6] rows it finished (all zero at launch)
 };
 void launch_perm_fast(hipStream_t st, const PermArgs& a);
 void launch_perm_general(hipStream_t st, const PermArgs& a);

@@ -267,7 +267,7 @@ __device__ Tail22 bounds22(TabG G, const HG22& h, uint32_t kobs) {
 static const uint32_t UNIT = LGMI_UNIT, SUB = 16;
 static const uint32_t QBATCH = 4;     // rows a wave of k_perm_general takes from the shared counter at a time
 
-__device__ __forceinline__ unsigned long long unit_mass(TabLF LF, const HG22& h, uint32_t k0, uint32_t len) {
+__device__ __forceinline__ double unit_sum(TabLF LF, const HG22& h, uint32_t k0, uint32_t len) {   // any length (range_sum_d in the oracle)
     uint32_t k = k0;
     double term = pmf22(LF, h, k), sum = term;
     uint32_t rem = len - 1u;
@@ -294,7 +294,10 @@ __device__ __forceinline__ unsigned long long unit_mass(TabLF LF, const HG22& h,
         k += m;
         rem -= m;
     }
-    return (unsigned long long)(sum * 4611686018427387904.0);   // 2^62
+    return sum;
+}
+__device__ __forceinline__ unsigned long long unit_mass(TabLF LF, const HG22& h, uint32_t k0, uint32_t len) {
+    return (unsigned long long)(unit_sum(LF, h, k0, len) * 4611686018427387904.0);   // 2^62
 }
 
 // The number of "as or more extreme" shuffles of a 2 x 2 table is Binomial(n_shuffles, P_tail): one binomial
@@ -730,6 +733,261 @@ __global__ __launch_bounds__(64) void k_perm_enum(PermArgs pa)
     }
 }
 
+// ---------------------------------------------------------------- six-cell tables: exact mass along the perimeter (round 4)
+// A 3 x 2 / 2 x 3 table has two degrees of freedom and {S < S_obs} is the lattice inside a convex curve: for a null pair
+// at 2e5 reads ~1.4e4 tables in ~100 chords, each chord a 2 x 2 problem.  One more draw changes a hypergeometric CDF by one
+// pmf term, so a chord's mass is an affine map of its predecessor's, M_c = rho_c M_p + beta_c, with coefficients made of the
+// two chords' bounds, two pmf values and the few values by which the bounds moved: the work is the region's PERIMETER
+// (~2e3 lane-steps per row), not its area (1.4e4) and not 1000 rejection-sampled tables (3.1e5 lane-instructions).  The
+// exceed count is then one binomial variate, as for 2 x 2 rows.  Specification: six_plan / six_inside_walk in
+// oracle/lgmi_perm_oracle.c (canonical form, chord bounds, collapsed table, zero test, gate, the maps and the order they
+// are composed in: see the comments there; every name below is theirs).
+//   phase S  one lane per queued row: table, canonical form, zero test, chord range from the collapsed table, gate
+//   phase C  the wave's qualifying rows one after the other, 64 chords at a time, one lane per chord: two boundary searches
+//            from a half-width guess, the map's coefficients, an inclusive scan of the 64 maps, a butterfly sum
+//   phase D  one lane per row again: the binomial draws of all the wave's rows side by side
+// Rows that stay with the sampling kernel (3 x 3, gate) go to a third list behind the input list, 64 per atomic; when the
+// buffer has no room for it (more than a third of all rows queued) the finished rows are marked in the input list instead.
+struct SixLists { uint32_t* in; uint32_t n_in; uint32_t* out; bool third; };
+__device__ __forceinline__ SixLists six_lists(const PermArgs& pa)
+{
+    // the rows k_perm_enum left: its second list when it made one, else the whole queue with the finished rows marked
+    // (the same test as there); the third list goes behind whichever it is, when there is room
+    const uint32_t n_queued = pa.gen_count[0];
+    const bool second = pa.enum_max && pa.gen_count[3] && 2ull * (unsigned long long)n_queued <= pa.max_rows;
+    SixLists l;
+    l.n_in = second ? pa.gen_count[2] : n_queued;
+    const uint32_t off = second ? n_queued : 0u;
+    l.in = pa.gen_list + off;
+    l.third = pa.six_pts && (unsigned long long)off + 2ull * (unsigned long long)l.n_in <= pa.max_rows;
+    l.out = pa.gen_list + off + l.n_in;
+    return l;
+}
+
+__device__ __forceinline__ uint32_t kc22(const HG22& h) {
+    // floor(n K / N): the product is below 2^53, so one f64 division lands within one of the quotient (as in k_perm_general)
+    const unsigned long long prod = (unsigned long long)h.n * (unsigned long long)h.K;
+    uint32_t kc = (uint32_t)((double)prod / (double)h.N);
+    const long long rem = (long long)prod - (long long)kc * (long long)h.N;
+    if (rem < 0) kc--; else if (rem >= (long long)h.N) kc++;
+    if (kc < h.kmin) kc = h.kmin;
+    if (kc > h.kmax) kc = h.kmax;
+    return kc;
+}
+__device__ __forceinline__ void hg22_set(HG22& h, uint32_t N, uint32_t K, uint32_t n, double c0) {
+    h.N = N; h.K = K; h.n = n;
+    h.kmin = K + n > N ? K + n - N : 0u;
+    h.kmax = K < n ? K : n;
+    h.c0 = c0;
+}
+// inside (klo, khi) of {stat22(h, x) < s} around kc: the two monotone boundaries, searched from a half-width guess
+__device__ __forceinline__ void inside22(TabG G, const HG22& h, long long s, long long& klo, long long& khi) {
+    const uint32_t kc = kc22(h);
+    const long long d0 = s - stat22(G, h, kc);
+    long long hw = 0;
+    if (d0 > 0) {
+        // S(x) - S(x*) ~ (x - x*)^2 2^28 / (2 var): a guess only (the search does not depend on it)
+        const float Nf = (float)h.N, var = (float)h.n * (float)h.K * ((float)(h.N - h.K) * (float)(h.N - h.n)) / (Nf * Nf * Nf);
+        hw = (long long)__fsqrt_rn(2.0f * var * (float)d0 * 3.7252903e-09f);
+    }
+    const long long lo = (long long)h.kmin - 1, hi = (long long)kc, refl = lo + hi;
+    klo = refl - first_true(lo, hi, refl - ((long long)kc - hw), [&](long long j) { return stat22(G, h, (uint32_t)(refl - j)) >= s; });
+    khi = first_true((long long)kc + 1, (long long)h.kmax + 1, (long long)kc + 1 + hw, [&](long long k) { return stat22(G, h, (uint32_t)k) >= s; });
+}
+
+#ifndef LGMI_SIX_WPS
+#define LGMI_SIX_WPS 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS, LGMI_SIX_WPS))) void k_perm_six(PermArgs pa)
+{
+    const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
+    const uint32_t* __restrict__ counts = pa.counts;
+    const TabG G{pa.G}; const TabLF LF{pa.LF};
+    const uint32_t n_shuffles = pa.n_shuffles; const uint64_t seed = pa.seed;
+    double* __restrict__ out_p = pa.out_p; uint32_t* __restrict__ out_exceed = pa.out_exceed;
+    const uint32_t lane = threadIdx.x & 63u;
+    const SixLists ls = six_lists(pa);
+    unsigned long long box_max = ((unsigned long long)pa.six_pts * (unsigned long long)n_shuffles) >> 4;
+    if (box_max > 4194304ull) box_max = 4194304ull;
+    unsigned int* const next_row = pa.gen_count + 5;
+    uint32_t q_next = 0u;
+    if (lane == 0) q_next = atomicAdd(next_row, 64u);
+    for (;;) {                                               // every wave reaches q0 >= n_in: the grid drains
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_next);
+        if (q0 >= ls.n_in) break;
+        if (lane == 0) q_next = atomicAdd(next_row, 64u);
+        // ---- phase S
+        const uint32_t q = q0 + lane;
+        uint32_t r = 0xFFFFFFFFu;
+        if (q < ls.n_in) r = ls.in[q];
+        int st = 0;                                          // 0 nothing, 1 stays with k_perm_general, 2 six-cell with chords, 3 six-cell, thr known
+        uint32_t Ao = 0u, Ap = 1u, Aq = 1u, B0 = 0u;
+        long long sobs = 0, zlo = 0, zhi = 0;
+        double cJ = 0.0;
+        unsigned long long thr = 0ull;
+        if (r != 0xFFFFFFFFu) {
+            uint32_t T[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) T[k] = counts[9ull * r + k];
+            const uint32_t R0 = T[0] + T[1] + T[2], R1 = T[3] + T[4] + T[5], R2 = T[6] + T[7] + T[8];
+            const uint32_t C0 = T[0] + T[3] + T[6], C1 = T[1] + T[4] + T[7], C2 = T[2] + T[5] + T[8];
+            const uint32_t N = R0 + R1 + R2;
+            const int nr = (R0 != 0u) + (R1 != 0u) + (R2 != 0u), nc = (C0 != 0u) + (C1 != 0u) + (C2 != 0u);
+            st = 1;
+            if (nr * nc == 6) {
+                uint32_t A0, A1, A2, B1;
+                if (nr == 3) { A0 = R0; A1 = R1; A2 = R2; B0 = C0 ? C0 : C1; B1 = C0 ? (C1 ? C1 : C2) : C2; }
+                else { A0 = C0; A1 = C1; A2 = C2; B0 = R0 ? R0 : R1; B1 = R0 ? (R1 ? R1 : R2) : R2; }
+                int o = 0;
+                uint32_t am = A0;
+                if (A1 < am) { o = 1; am = A1; }
+                if (A2 < am) { o = 2; am = A2; }
+                Ao = am;
+                Ap = o == 0 ? A1 : A0;
+                Aq = o == 2 ? A1 : A2;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sobs += G[T[k]];
+                cJ = LF[A0];
+                cJ += LF[A1]; cJ += LF[A2]; cJ += LF[B0]; cJ += LF[B1]; cJ -= LF[N];
+                double b = cJ;
+                b += (double)N;
+                b += det_log(((double)Ao + 1.0) * ((double)Ap + 1.0));
+                b -= (double)sobs * 3.725290298461914e-09;
+                if (b < -23.1) { st = 3; thr = 0ull; }
+                else {
+                    HG22 hc;
+                    hg22_set(hc, N, Ao, B0, 0.0);
+                    const long long sc = sobs + 8 - (G[Ap] + G[Aq] - G[Ap + Aq]);
+                    inside22(G, hc, sc, zlo, zhi);
+                    if (zhi - zlo - 1 <= 0) { st = 3; thr = 4294967296ull; }
+                    else {
+                        long long zc = (long long)kc22(hc);
+                        if (zc <= zlo) zc = zlo + 1;
+                        if (zc >= zhi) zc = zhi - 1;
+                        HG22 h;
+                        hg22_set(h, Ap + Aq, Ap, B0 - (uint32_t)zc, 0.0);
+                        long long klo, khi;
+                        inside22(G, h, sobs - G[(uint32_t)zc] - G[Ao - (uint32_t)zc], klo, khi);
+                        const long long len = khi - klo - 1;
+                        const unsigned long long box = (unsigned long long)(zhi - zlo - 1) + (unsigned long long)(len > 1 ? len : 1);
+                        if (box <= box_max) st = 2;
+                    }
+                }
+            }
+        }
+        // rows that stay with k_perm_general: the third list, one atomic per wave and round
+        {
+            const unsigned long long kb = __ballot(st == 1);
+            if (kb && ls.third) {
+                uint32_t at = 0u;
+                if (lane == 0) at = atomicAdd(pa.gen_count + 4, (unsigned int)__popcll(kb));
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                if (st == 1) ls.out[at + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))] = r;
+            }
+        }
+        // ---- phase C: the perimeter walk (six_inside_walk in the oracle: every chord an affine map of its predecessor's mass)
+        unsigned long long todo = __ballot(st == 2);
+        while (todo) {                                       // (wave-uniform)
+            const int L = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint32_t rAo = bcast32(Ao, L), rAp = bcast32(Ap, L), rAq = bcast32(Aq, L), rB0 = bcast32(B0, L);
+            const long long rsobs = (long long)bcast64((unsigned long long)sobs, L);
+            const long long rzlo = (long long)bcast64((unsigned long long)zlo, L), rzhi = (long long)bcast64((unsigned long long)zhi, L);
+            const double rcJ = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(cJ), L));
+            const uint32_t nz = (uint32_t)(rzhi - rzlo - 1), Np = rAp + rAq, K = rAp;
+            double total = 0.0, M_carry = 0.0;
+            int a_carry = 0, b_carry = 0;
+            for (uint32_t base = 0u; base < nz; base += 64u) {
+                const uint32_t cnt = nz - base < 64u ? nz - base : 64u;
+                const bool active = lane < cnt;
+                HG22 h = {Np, K, 0u, 0u, 0u, 0.0};
+                int a = 0, b = 0, kc = 0;
+                uint32_t z = 0u;
+                if (active) {
+                    z = (uint32_t)(rzlo + 1) + base + lane;
+                    double c0 = rcJ;
+                    c0 -= LF[z];
+                    c0 -= LF[rAo - z];
+                    hg22_set(h, Np, K, rB0 - z, c0);
+                    long long klo, khi;
+                    inside22(G, h, rsobs - G[z] - G[rAo - z], klo, khi);
+                    a = (int)klo; b = (int)khi - 1;
+                    kc = (int)kc22(h);
+                }
+                int a_p = __shfl_up(a, 1), b_p = __shfl_up(b, 1);
+                const bool first = base == 0u && lane == 0u;
+                if (lane == 0u) { a_p = first ? kc : a_carry; b_p = first ? kc : b_carry; }
+                double rho = 1.0, beta = 0.0;                // idle lanes: the identity map
+                if (active) {
+                    double t2 = 0.0, adjT = 0.0, adjB = 0.0;
+                    rho = 0.0;
+                    if (!first) {
+                        const double rz = 1.0 / (double)z, rden = 1.0 / (double)(Np - h.n);
+                        const double f = (double)(rAo - z + 1u) * (double)(h.n + 1u);
+                        double tb = 0.0, ta = 0.0;
+                        rho = f * rz;
+                        rho = rho * rden;
+                        if (b_p >= (int)h.kmin && b_p <= (int)h.kmax) tb = pmf22(LF, h, (uint32_t)b_p) * (double)((int)K - b_p);
+                        if (a_p >= (int)h.kmin && a_p <= (int)h.kmax) ta = pmf22(LF, h, (uint32_t)a_p) * (double)((int)K - a_p);
+                        t2 = tb - ta;
+                        t2 = t2 * rden;
+                    }
+                    if (b > b_p) {
+                        const int s0 = b_p + 1 > (int)h.kmin ? b_p + 1 : (int)h.kmin;
+                        if (b >= s0) adjT = unit_sum(LF, h, (uint32_t)s0, (uint32_t)(b - s0 + 1));
+                    } else if (b < b_p) {
+                        const int e = b_p < (int)h.kmax ? b_p : (int)h.kmax;
+                        if (e > b) adjT = -unit_sum(LF, h, (uint32_t)(b + 1), (uint32_t)(e - b));
+                    }
+                    if (a < a_p) {
+                        const int e = a_p < (int)h.kmax ? a_p : (int)h.kmax;
+                        if (e > a) adjB = unit_sum(LF, h, (uint32_t)(a + 1), (uint32_t)(e - a));
+                    } else if (a > a_p) {
+                        const int s0 = a_p + 1 > (int)h.kmin ? a_p + 1 : (int)h.kmin;
+                        if (a >= s0) adjB = -unit_sum(LF, h, (uint32_t)s0, (uint32_t)(a - s0 + 1));
+                    }
+                    beta = t2 + adjT;
+                    beta = beta + adjB;
+                    if (b - a <= 0) { rho = 0.0; beta = 0.0; }
+                }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {           // inclusive scan of the affine maps (Hillis-Steele, as the oracle)
+                    const double pr = __shfl_up(rho, o), pb = __shfl_up(beta, o);
+                    if (lane >= (uint32_t)o) {
+                        const double x = rho * pb;
+                        beta = x + beta;
+                        rho = rho * pr;
+                    }
+                }
+                double M = rho * M_carry;
+                M = M + beta;
+                if (!active) M = 0.0;
+                M_carry = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(M), (int)cnt - 1));
+                a_carry = (int)bcast32((uint32_t)a, (int)cnt - 1); b_carry = (int)bcast32((uint32_t)b, (int)cnt - 1);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) M = M + __shfl_xor(M, o);
+                total = total + M;
+            }
+            if ((int)lane == L) {
+                unsigned long long ins = 0ull;
+                if (total >= 1.0) ins = 4611686018427387904ull;
+                else if (total > 0.0) ins = (unsigned long long)(total * 4611686018427387904.0);
+                thr = (4611686018427387904ull - ins) >> 30;
+                st = 3;
+            }
+        }
+        // ---- phase D
+        if (st == 3) {
+            const uint32_t exceed = binom_draw(LF, n_shuffles, thr, row_i[r] + pa.site_base, row_j[r] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
+            out_exceed[r] = exceed;
+            if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+            if (!ls.third) ls.in[q] = 0xFFFFFFFFu;          // no third list: k_perm_general skips the row
+        }
+        const uint32_t done = (uint32_t)__popcll(__ballot(st == 3));        // (statistics: lgmi_run_info.n_six_rows)
+        if (lane == 0 && done) atomicAdd(pa.gen_count + 6, done);
+    }
+}
+
 // ---------------------------------------------------------------- general tables
 //
 // One wave per queued row; lane l runs shuffles l, l+64, ...  A shuffle is a chain of up to
@@ -823,7 +1081,7 @@ __device__ __forceinline__ unsigned long long to_fixed52(double p) {
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WPS, LGMI_PERM_WPS))) void k_perm_general(PermArgs pa)
 {
-    const uint32_t* __restrict__ gen_list = pa.gen_list; const unsigned int* __restrict__ gen_count = pa.gen_count;
+    const unsigned int* __restrict__ gen_count = pa.gen_count;
     const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
     const uint32_t* __restrict__ counts = pa.counts;
     const TabG G{pa.G}; const TabLF LF{pa.LF};
@@ -834,12 +1092,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
     __shared__ uint32_t next_s;
     __shared__ __attribute__((aligned(8))) uint16_t x_ring[XRING];   // lock-step rows: first draws waiting for a lane
     const uint32_t lane = threadIdx.x & 63u;
-    // the rows k_perm_enum left: its second list when it made one (the same test as there), else the whole queue with
-    // the finished rows marked
-    const uint32_t n_queued = *gen_count;
-    const bool second = pa.enum_max && gen_count[3] && 2ull * (unsigned long long)n_queued <= pa.max_rows;
-    const uint32_t n_gen = second ? gen_count[2] : n_queued;
-    if (second) gen_list += n_queued;
+    // the rows k_perm_six left in its third list when it made one; else the rows k_perm_enum left: its second list when it
+    // made one, else the whole queue with the finished rows marked (six_lists: the same tests as in those kernels)
+    const SixLists sl = six_lists(pa);
+    const uint32_t n_gen = sl.third ? gen_count[4] : sl.n_in;
+    const uint32_t* __restrict__ gen_list = sl.third ? sl.out : sl.in;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     // rows are taken from a shared counter (gen_count[1], zero at launch), the next one asked for while the current
     // one runs: rows differ in cost (table size, streamlined or general loop) and a fixed stride left the average
@@ -1445,6 +1702,18 @@ static uint32_t perm_enum_max()
     return v;
 }
 
+// LGMI_PERM_SIX_PTS: sixteenths of a chord per shuffle a six-cell row may cost on the exact path (0: every such row is sampled;
+// the CPU specification has the same switch, lgo_set_six_pts)
+static uint32_t perm_six_pts()
+{
+    static const uint32_t v = [] {
+        const char* e = getenv("LGMI_PERM_SIX_PTS");
+        const long x = e ? atol(e) : 16;
+        return (uint32_t)(x < 0 ? 0 : x > 65536 ? 65536 : x);
+    }();
+    return v;
+}
+
 void launch_perm_fast(hipStream_t st, const PermArgs& a)
 {
     if (!a.max_rows) return;
@@ -1474,7 +1743,9 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
     // finishes in the queue and k_perm_general skips them, instead of walking a second list
     static const bool no_second = [] { const char* e = getenv("LGMI_PERM_NO_SECOND_LIST"); return e && atoi(e) != 0; }();
     if (no_second) b.max_rows = 1;
+    b.six_pts = perm_six_pts();
     if (b.enum_max) hipLaunchKernelGGL(k_perm_enum, dim3(256 * 16), dim3(64), 0, st, b);
+    if (b.six_pts) hipLaunchKernelGGL(k_perm_six, dim3(256 * 4 * LGMI_SIX_WPS), dim3(64), 0, st, b);
     hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, b);
 }
 

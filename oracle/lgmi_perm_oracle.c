@@ -773,6 +773,303 @@ static uint64_t enum_mass(const perm_tables* t, const uint32_t R[3], const uint3
     return mass;
 }
 
+/* ------------------------------------------------------------------ six-cell tables: exact mass chord by chord (round 4)
+ * A 3 x 2 / 2 x 3 table — a tri-allelic site against a bi-allelic one, 96 % of the larger-than-2x2 rows of a dense
+ * chromosome — has two degrees of freedom, and the set {S < S_obs} is the lattice inside a convex curve around the
+ * table of independence: for null pairs a few ten thousand tables at 2e5 reads, far fewer than the arithmetic of
+ * n_shuffles rejection-sampled tables.  Its mass is summed exactly, chord by chord, each chord being a 2 x 2 problem
+ * (unit_mass above), and the exceed count is ONE binomial variate, as for 2 x 2 rows and enumerated rows.
+ *
+ *   canonical form: three CLASSES with margins A[0..2] (the rows when three rows are non-empty, else the columns, in
+ *       table order) against two SIDES with margins B0, B1; a table is (a_0, a_1, a_2) = the classes' counts on side 0,
+ *       a_0 + a_1 + a_2 = B0.  o = the class with the (first) smallest margin, p < q the other two in order.
+ *       z = a_o is the chord index, x = a_p runs along the chord, a_q = B0 - z - x.
+ *   chord z: the 2 x 2 problem h_z = {N' = A_p + A_q, K = A_p, n = B0 - z} in x with
+ *       S(x, z)   = stat22(h_z, x) + G[z] + G[A_o - z],      so  S < S_obs  <=>  stat22(h_z, x) < sobs_z = sobs - G[z] - G[A_o - z]
+ *       pmf(x, z) = exp(c0_z - LF[x] - LF[K - x] - LF[n - x] - LF[N' - K - n + x]),   c0_z = cJ - LF[z] - LF[A_o - z]  (in this order),
+ *       cJ = LF[A_0] + LF[A_1] + LF[A_2] + LF[B0] + LF[B1] - LF[N]  (in this order)
+ *       stat22 falls up to kc = floor(n K / N') and rises after it: the chord's inside is (klo_z, khi_z) with
+ *       klo_z = the last x in [kmin - 1, kc] with stat22 >= sobs_z (kmin - 1: none), khi_z = the first x in [kc + 1, kmax + 1]
+ *       with stat22 >= sobs_z (kmax + 1: none); both boundaries of monotone predicates (any search order finds them).
+ *   which chords: min over real x of S(x, z) = stat22(h_c, z) + G[A_p] + G[A_q] - G[A_p + A_q] with the COLLAPSED table
+ *       h_c = {N, K = A_o, n = B0} (class o against the rest) — convex in z, and below the chord's lattice minimum (G is
+ *       rounded: 8 units of slack).  Chords z in (zlo, zhi), the boundaries of stat22(h_c, z) >= sc = sobs + 8 - (G[A_p] + G[A_q]
+ *       - G[A_p + A_q]) on either side of floor(B0 A_o / N), found like klo / khi; a chord there may still be empty.
+ *   zero test first: ln n! >= n ln n - n, so every table with S >= S_obs has pmf <= exp(cJ + N - sobs 2^-28) and there
+ *       are at most (A_o + 1)(A_p + 1) of them: if cJ + N + ln((A_o + 1)(A_p + 1)) - sobs 2^-28 < -23.1 the set weighs less
+ *       than 2^-33, thr = 0 (linked pairs: a tri-allelic het SNP against another het SNP).
+ *   gate: the work is proportional to the region's perimeter (six_inside_walk below): box = (zhi - zlo - 1) + max(1, length
+ *       of the chord through z_c = floor(B0 A_o / N) clamped into (zlo, zhi)); the row takes this path iff
+ *       box <= min(2^22, SIX_PTS * n_shuffles / 16) — with SIX_PTS = 16: as many chords as shuffles, about where the walk
+ *       costs what n_shuffles sampled tables cost; otherwise (and all 3 x 3 rows) the Monte-Carlo paths below.
+ *   inside = the mass of {S < S_obs}: six_inside_walk (perimeter); six_inside (the plain sum over the area, chord by chord
+ *       in units of 64 values) is kept as the independent check the tests hold it against,
+ *   thr = (2^62 - inside) >> 30 (0 when inside > 2^62), exceed = binom_draw(n_shuffles, thr, ...).
+ * Accuracy: as the 2 x 2 centre form — |dP| <= 1e-9 up to 2e5 reads (the LF table's rounding times the inside mass).
+ */
+static uint32_t SIX_PTS = 16u;     /* sixteenths of a chord per shuffle a row may cost (0: the path is off; lgo_set_six_pts) */
+
+typedef struct {
+    uint32_t A[3], B0, B1, N, o, p, q;     /* canonical margins, o / p / q = indices into A */
+    int64_t sobs;
+    double cJ;
+    hg22 hc;                                /* the collapsed table */
+    int64_t zlo, zhi;                       /* chords z in (zlo, zhi) */
+    int zero;                               /* the zero test fired: thr = 0 */
+} six_row;
+
+/* last x in [lo, hi] with stat22(h, x) >= s for a predicate that is true then false along x; lo is a sentinel (never evaluated) */
+static int64_t last_ge(const perm_tables* t, const hg22* h, int64_t lo, int64_t hi, int64_t s)
+{
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo + 1) / 2;
+        if (stat22(t, h, (uint32_t)mid) >= s) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+/* first x in [lo, hi] with stat22(h, x) >= s, false then true; hi is a sentinel */
+static int64_t first_ge(const perm_tables* t, const hg22* h, int64_t lo, int64_t hi, int64_t s)
+{
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (stat22(t, h, (uint32_t)mid) >= s) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+static void hg22_set(hg22* h, uint32_t N, uint32_t K, uint32_t n, double c0)
+{
+    h->N = N; h->K = K; h->n = n;
+    h->kmin = K + n > N ? K + n - N : 0;
+    h->kmax = K < n ? K : n;
+    h->c0 = c0;
+}
+
+static uint32_t kc_of(const hg22* h)
+{
+    uint32_t kc = (uint32_t)(((uint64_t)h->n * (uint64_t)h->K) / (uint64_t)h->N);
+    if (kc < h->kmin) kc = h->kmin;
+    if (kc > h->kmax) kc = h->kmax;
+    return kc;
+}
+
+/* chord z of a six-cell row: the 2 x 2 problem and the inside (klo, khi) */
+static void six_chord(const perm_tables* t, const six_row* s, int64_t z, hg22* h, int64_t* klo, int64_t* khi)
+{
+    const uint32_t Ao = s->A[s->o], Ap = s->A[s->p], Aq = s->A[s->q];
+    const int64_t sobs_z = s->sobs - t->G[z] - t->G[Ao - z];
+    double c0 = s->cJ;
+    uint32_t kc;
+    c0 -= t->LF[z];
+    c0 -= t->LF[Ao - z];
+    hg22_set(h, Ap + Aq, Ap, (uint32_t)(s->B0 - z), c0);
+    kc = kc_of(h);
+    *klo = last_ge(t, h, (int64_t)h->kmin - 1, (int64_t)kc, sobs_z);
+    *khi = first_ge(t, h, (int64_t)kc + 1, (int64_t)h->kmax + 1, sobs_z);
+}
+
+/* returns 1 when the row takes the six-cell path at this n_shuffles */
+static int six_plan(const perm_tables* t, const uint32_t T[9], uint32_t n_shuffles, six_row* s)
+{
+    uint32_t R[3], C[3], nzr[3], nzc[3], nr = 0, nc = 0, a, N = 0;
+    uint64_t box_max, box;
+    int64_t sc, zc, klo, khi, len;
+    hg22 h;
+    if (!SIX_PTS) return 0;
+    for (a = 0; a < 3; ++a) { R[a] = T[3 * a] + T[3 * a + 1] + T[3 * a + 2]; C[a] = T[a] + T[3 + a] + T[6 + a]; N += R[a]; }
+    for (a = 0; a < 3; ++a) { if (R[a]) nzr[nr++] = a; if (C[a]) nzc[nc++] = a; }
+    if (nr * nc != 6) return 0;
+    if (nr == 3) { for (a = 0; a < 3; ++a) s->A[a] = R[a]; s->B0 = C[nzc[0]]; s->B1 = C[nzc[1]]; }
+    else { for (a = 0; a < 3; ++a) s->A[a] = C[a]; s->B0 = R[nzr[0]]; s->B1 = R[nzr[1]]; }
+    s->N = N;
+    s->o = 0;
+    if (s->A[1] < s->A[s->o]) s->o = 1;
+    if (s->A[2] < s->A[s->o]) s->o = 2;
+    s->p = s->o == 0 ? 1 : 0;
+    s->q = s->o == 2 ? 1 : 2;
+    s->sobs = stat9(t, T);
+    s->cJ = t->LF[s->A[0]];
+    s->cJ += t->LF[s->A[1]]; s->cJ += t->LF[s->A[2]]; s->cJ += t->LF[s->B0]; s->cJ += t->LF[s->B1]; s->cJ -= t->LF[N];
+    s->zero = 0; s->zlo = 0; s->zhi = 0;
+    {
+        const double lnt = lgo_det_log(((double)s->A[s->o] + 1.0) * ((double)s->A[s->p] + 1.0));
+        double b = s->cJ;
+        b += (double)N;
+        b += lnt;
+        b -= (double)s->sobs * 3.725290298461914e-09;     /* 2^-28 */
+        if (b < -23.1) { s->zero = 1; return 1; }
+    }
+    hg22_set(&s->hc, N, s->A[s->o], s->B0, 0.0);
+    sc = s->sobs + 8 - (t->G[s->A[s->p]] + t->G[s->A[s->q]] - t->G[s->A[s->p] + s->A[s->q]]);
+    zc = (int64_t)kc_of(&s->hc);
+    s->zlo = last_ge(t, &s->hc, (int64_t)s->hc.kmin - 1, zc, sc);
+    s->zhi = first_ge(t, &s->hc, zc + 1, (int64_t)s->hc.kmax + 1, sc);
+    if (s->zhi - s->zlo - 1 <= 0) return 1;                 /* no table below S_obs: inside = 0, thr = 2^32 */
+    if (zc <= s->zlo) zc = s->zlo + 1;
+    if (zc >= s->zhi) zc = s->zhi - 1;
+    six_chord(t, s, zc, &h, &klo, &khi);
+    len = khi - klo - 1;
+    box = (uint64_t)(s->zhi - s->zlo - 1) + (uint64_t)(len > 1 ? len : 1);
+    box_max = ((uint64_t)SIX_PTS * (uint64_t)n_shuffles) >> 4;
+    if (box_max > 4194304ull) box_max = 4194304ull;         /* 2^22 */
+    return box <= box_max;
+}
+
+/* the mass of {S < S_obs} in units of 2^-62 (integer sum over the chords' units), the number of lattice points */
+static uint64_t six_inside(const perm_tables* t, const six_row* s, uint64_t* area)
+{
+    uint64_t m = 0, ar = 0;
+    int64_t z;
+    for (z = s->zlo + 1; z < s->zhi; ++z) {
+        hg22 h;
+        int64_t klo, khi;
+        six_chord(t, s, z, &h, &klo, &khi);
+        if (khi - klo - 1 > 0) { m += range_mass(t, &h, klo + 1, khi - klo - 1); ar += (uint64_t)(khi - klo - 1); }
+    }
+    if (area) *area = ar;
+    return m;
+}
+
+/* sum of pmf22 over [k0, k0 + len) as a double: unit_mass's recurrence (first term from the log-factorials, sub-blocks of
+ * SUB steps), any length, no truncation */
+static double range_sum_d(const perm_tables* t, const hg22* h, int64_t k0, int64_t len)
+{
+    uint32_t k = (uint32_t)k0;
+    double term = pmf22(t, h, k), sum = term;
+    int64_t rem = len - 1;
+    while (rem > 0) {
+        const int64_t m = rem < SUB ? rem : SUB;
+        double P = 0.0, Nn = 1.0, Q = 1.0;
+        double a = (double)(h->K - k), b = (double)(h->n - k), c = (double)(k + 1u), d = (double)(h->N - h->K - h->n + k + 1u);
+        int64_t j;
+        for (j = 0; j < m; ++j) {
+            const double num = a * b, den = c * d;
+            Nn = Nn * num;
+            Q = Q * den;
+            P = fma(P, den, Nn);
+            a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
+        }
+        sum += term * P / Q;
+        term = term * Nn / Q;
+        k += (uint32_t)m;
+        rem -= m;
+    }
+    return sum;
+}
+
+/* The mass of {S < S_obs} along the PERIMETER instead of over the area.  With X_n ~ HG(N', K, n) one more draw gives
+ * P(X_{n+1} <= x) = P(X_n <= x) - P(X_n = x) (K - x) / (N' - n); chord z + 1 has n - 1 draws, so for a fixed range (a, b] of x
+ *     M'(z + 1) = rho_z M(z) + [J(b, z + 1) (K - b) - J(a, z + 1) (K - a)] / (N' - n_{z+1}),
+ *     rho_z = w(z + 1) / w(z) = (A_o - z)(n_z) / ((z + 1)(N' - n_z + 1))          (w = the collapsed table's pmf)
+ * with M(z) = the joint mass of chord z over (a, b] and J the joint pmf (0 outside the chord's support): exact, a few terms per
+ * chord instead of the chord's length.  Then the range is moved from the previous chord's inside (a_p, b_p] to this chord's
+ * (a, b] by adding / removing the few values in between (range_sum_d).  So every chord is an affine map of its predecessor's
+ * mass, M_c = rho_c M_p + beta_c, all of whose coefficients depend on the two chords' bounds only:
+ *     rho_c  = ((A_o - z + 1)(n + 1)) (1 / z) (1 / (N' - n))                        (n = n_z; products in this order)
+ *     beta_c = (J(b_p, z)(K - b_p) - J(a_p, z)(K - a_p)) (1 / (N' - n)) + adjT + adjB
+ *     adjT   = + sum (max(b_p + 1, kmin) .. b) if b > b_p,  - sum (b + 1 .. min(b_p, kmax)) if b < b_p
+ *     adjB   = + sum (a + 1 .. min(a_p, kmax)) if a < a_p,  - sum (max(a_p + 1, kmin) .. a) if a > a_p
+ * the row's first chord: rho = 0, a_p = b_p = its own kc (the adjustments sum the whole chord); an empty chord: rho = beta = 0.
+ * The chords are taken 64 at a time (one per GPU lane): the 64 maps are composed by an inclusive Hillis-Steele scan
+ * (offsets 1, 2, .., 32: beta <- rho beta_prev + beta, rho <- rho rho_prev, products and sums rounded separately), applied
+ * to the mass carried in from the previous 64, summed by an xor butterfly (offsets 32 .. 1), and the row's total is the
+ * sum of the 64-chord totals in order.  All of it is IEEE +, -, *, / on doubles in a fixed order: the same bits on both
+ * sides.  inside = trunc(2^62 total) clipped to [0, 2^62]. */
+static uint64_t six_inside_walk(const perm_tables* t, const six_row* s)
+{
+    const uint32_t Ao = s->A[s->o], Ap = s->A[s->p], Aq = s->A[s->q], Np = Ap + Aq, K = Ap;
+    const int64_t nz = s->zhi - s->zlo - 1;
+    double total = 0.0, M_carry = 0.0;
+    int64_t a_carry = 0, b_carry = 0, base;
+    for (base = 0; base < nz; base += 64) {
+        double rho[64], beta[64], M[64];
+        int64_t av[64], bv[64];
+        const int cnt = (int)(nz - base < 64 ? nz - base : 64);
+        int l, o;
+        for (l = 0; l < 64; ++l) { rho[l] = 1.0; beta[l] = 0.0; av[l] = bv[l] = 0; }
+        for (l = 0; l < cnt; ++l) {                      /* the chords' own bounds */
+            hg22 h;
+            int64_t klo, khi;
+            six_chord(t, s, s->zlo + 1 + base + l, &h, &klo, &khi);
+            av[l] = klo; bv[l] = khi - 1;
+        }
+        for (l = 0; l < cnt; ++l) {
+            const int64_t z = s->zlo + 1 + base + l;
+            const int first = (base == 0 && l == 0);
+            hg22 h;
+            int64_t klo, khi, a, b, a_p, b_p;
+            double r = 0.0, t2 = 0.0, adjT = 0.0, adjB = 0.0, be;
+            six_chord(t, s, z, &h, &klo, &khi);
+            a = klo; b = khi - 1;
+            if (first) { a_p = b_p = (int64_t)kc_of(&h); }
+            else if (l == 0) { a_p = a_carry; b_p = b_carry; }
+            else { a_p = av[l - 1]; b_p = bv[l - 1]; }
+            if (!first) {
+                const double rz = 1.0 / (double)z, rden = 1.0 / (double)(Np - h.n);
+                const double f = (double)(Ao - z + 1) * (double)(h.n + 1u);
+                double tb = 0.0, ta = 0.0;
+                r = f * rz;
+                r = r * rden;
+                if (b_p >= (int64_t)h.kmin && b_p <= (int64_t)h.kmax) tb = pmf22(t, &h, (uint32_t)b_p) * (double)((int64_t)K - b_p);
+                if (a_p >= (int64_t)h.kmin && a_p <= (int64_t)h.kmax) ta = pmf22(t, &h, (uint32_t)a_p) * (double)((int64_t)K - a_p);
+                t2 = tb - ta;
+                t2 = t2 * rden;
+            }
+            if (b > b_p) {
+                const int64_t st = b_p + 1 > (int64_t)h.kmin ? b_p + 1 : (int64_t)h.kmin;
+                if (b >= st) adjT = range_sum_d(t, &h, st, b - st + 1);
+            } else if (b < b_p) {
+                const int64_t e = b_p < (int64_t)h.kmax ? b_p : (int64_t)h.kmax;
+                if (e > b) adjT = -range_sum_d(t, &h, b + 1, e - b);
+            }
+            if (a < a_p) {
+                const int64_t e = a_p < (int64_t)h.kmax ? a_p : (int64_t)h.kmax;
+                if (e > a) adjB = range_sum_d(t, &h, a + 1, e - a);
+            } else if (a > a_p) {
+                const int64_t st = a_p + 1 > (int64_t)h.kmin ? a_p + 1 : (int64_t)h.kmin;
+                if (a >= st) adjB = -range_sum_d(t, &h, st, a - st + 1);
+            }
+            be = t2 + adjT;
+            be = be + adjB;
+            if (b - a <= 0) { r = 0.0; be = 0.0; }
+            rho[l] = r; beta[l] = be;
+        }
+        for (o = 1; o < 64; o <<= 1) {                   /* inclusive scan of the affine maps */
+            double pr[64], pb[64];
+            for (l = 0; l < 64; ++l) { pr[l] = rho[l]; pb[l] = beta[l]; }
+            for (l = o; l < 64; ++l) {
+                double x = pr[l] * pb[l - o];
+                beta[l] = x + pb[l];
+                rho[l] = pr[l] * pr[l - o];
+            }
+        }
+        for (l = 0; l < 64; ++l) {
+            double x = rho[l] * M_carry;
+            x = x + beta[l];
+            M[l] = l < cnt ? x : 0.0;
+        }
+        M_carry = M[cnt - 1]; a_carry = av[cnt - 1]; b_carry = bv[cnt - 1];
+        for (o = 32; o > 0; o >>= 1) {                   /* xor butterfly: every lane ends with the same sum */
+            double v[64];
+            for (l = 0; l < 64; ++l) v[l] = M[l] + M[l ^ o];
+            for (l = 0; l < 64; ++l) M[l] = v[l];
+        }
+        total = total + M[0];
+    }
+    if (!(total > 0.0)) return 0;
+    if (total >= 1.0) return 4611686018427387904ull;
+    return (uint64_t)(total * 4611686018427387904.0);
+}
+
+static uint64_t six_thr(const perm_tables* t, const six_row* s, double* p_out)
+{
+    uint64_t inside;
+    if (s->zero) { if (p_out) *p_out = 0.0; return 0; }
+    inside = six_inside_walk(t, s);
+    if (p_out) { *p_out = 1.0 - (double)inside * 2.168404344971009e-19; if (*p_out < 0.0) *p_out = 0.0; }
+    return inside <= 4611686018427387904ull ? (4611686018427387904ull - inside) >> 30 : 0;
+}
+
 static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row_i, uint32_t row_j,
                          uint32_t n_shuffles, uint64_t seed, double* ptail_out)
 {
@@ -812,6 +1109,11 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
                 if (thr > 4294967296ull) thr = 4294967296ull;
                 return binom_draw(t, n_shuffles, thr, row_i, row_j, k0, k1);
             }
+        }
+        if (!ptail_out) {          /* (the exact-p entry keeps NaN for every larger table) */
+            six_row sx;
+            if (six_plan(t, T, n_shuffles, &sx))
+                return binom_draw(t, n_shuffles, six_thr(t, &sx, NULL), row_i, row_j, k0, k1);
         }
         first_table_build(t, N, R[nzr[0]], C[nzc[0]], &ft);   /* the first non-empty row and column */
         if (ft.valid && nr * nc == 6 && N - R[nzr[0]] > 1 && N - C[nzc[0]] > 1)
@@ -1017,6 +1319,42 @@ int lgo_perm_enum_mass(const uint32_t T[9], uint32_t n_shuffles, uint64_t* mass,
     if (ok) *mass = enum_mass(&t, R, C, N, stat9(&t, T), fa, fb, la, lb, radix, *n_tables);
     free(t.G); free(t.LF);
     return ok;
+}
+
+/* test hook: the six-cell path of a table at this n_shuffles.  Returns 1 when the row takes it (0: Monte-Carlo, -1: error);
+ * out[0] = mass of {S < S_obs} in units of 2^-62 summed over the AREA (six_inside: the independent check), out[1] = its
+ * lattice points, out[2] = chords examined, out[3] = the zero test fired, out[4] = thr, out[5] = the same mass by the
+ * perimeter walk (six_inside_walk: what thr is made of) */
+int lgo_perm_six(const uint32_t T[9], uint32_t n_shuffles, uint64_t out[6])
+{
+    perm_tables t;
+    six_row sx;
+    uint32_t n = 0;
+    int k, ok;
+    for (k = 0; k < 9; ++k) n += T[k];
+    if (tables_init(&t, n)) return -1;
+    out[0] = out[1] = out[2] = out[3] = out[4] = out[5] = 0;
+    ok = six_plan(&t, T, n_shuffles, &sx);
+    if (ok) {
+        out[3] = (uint64_t)sx.zero;
+        if (!sx.zero) {
+            out[0] = six_inside(&t, &sx, &out[1]);      /* the area sum: the independent check of the perimeter walk */
+            out[2] = (uint64_t)(sx.zhi - sx.zlo - 1 > 0 ? sx.zhi - sx.zlo - 1 : 0);
+            out[5] = six_inside_walk(&t, &sx);
+        }
+        out[4] = six_thr(&t, &sx, NULL);
+    }
+    free(t.G); free(t.LF);
+    return ok;
+}
+
+/* test hook: lattice points per shuffle a six-cell row may cost (0: the path is off; the GPU library reads the same from
+ * LGMI_PERM_SIX_PTS).  Returns the previous value. */
+uint32_t lgo_set_six_pts(uint32_t v)
+{
+    const uint32_t old = SIX_PTS;
+    SIX_PTS = v;
+    return old;
 }
 
 /* test hook: the largest number of candidate tables a row is enumerated at (0: every larger-than-2x2 row keeps the
