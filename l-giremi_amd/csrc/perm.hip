@@ -774,25 +774,95 @@ __device__ __forceinline__ uint32_t kc22(const HG22& h) {
     if (kc > h.kmax) kc = h.kmax;
     return kc;
 }
+// the same with the division replaced by a product with rN ~ 1 / N (any rN within a few ulp: the remainder settles it)
+__device__ __forceinline__ uint32_t kc22r(const HG22& h, double rN) {
+    const unsigned long long prod = (unsigned long long)h.n * (unsigned long long)h.K;
+    uint32_t kc = (uint32_t)((double)prod * rN);
+    const long long rem = (long long)prod - (long long)kc * (long long)h.N;
+    if (rem < 0) kc--; else if (rem >= (long long)h.N) kc++;
+    if (kc < h.kmin) kc = h.kmin;
+    if (kc > h.kmax) kc = h.kmax;
+    return kc;
+}
 __device__ __forceinline__ void hg22_set(HG22& h, uint32_t N, uint32_t K, uint32_t n, double c0) {
     h.N = N; h.K = K; h.n = n;
     h.kmin = K + n > N ? K + n - N : 0u;
     h.kmax = K < n ? K : n;
     h.c0 = c0;
 }
+// first_true on 32-bit integers (every count here is below 2^28)
+template <class P>
+__device__ __forceinline__ int first_true32(int lo, int hi, int g, P pred) {
+    if (g < lo) g = lo;
+    if (g > hi) g = hi;
+    int l, r;                                          // pred(r) holds; pred(l) does not (or l == lo - 1)
+    if (g == hi || pred(g)) {
+        r = g; l = lo - 1;
+        int step = 1;
+        while (r > lo) {
+            int c = r - step;
+            if (c < lo) c = lo;
+            if (pred(c)) { r = c; step <<= 1; } else { l = c; break; }
+        }
+    } else {
+        l = g; r = hi;
+        int step = 1;
+        for (;;) {
+            const int c = l + step;
+            if (c >= hi) break;
+            if (pred(c)) { r = c; break; }
+            l = c; step <<= 1;
+        }
+    }
+    while (r - l > 1) {
+        const int mid = l + ((r - l) >> 1);
+        if (pred(mid)) r = mid; else l = mid;
+    }
+    return r;
+}
 // inside (klo, khi) of {stat22(h, x) < s} around kc: the two monotone boundaries, searched from a half-width guess
-__device__ __forceinline__ void inside22(TabG G, const HG22& h, long long s, long long& klo, long long& khi) {
-    const uint32_t kc = kc22(h);
+__device__ __forceinline__ void inside22(TabG G, const HG22& h, uint32_t kc, long long s, int& klo, int& khi) {
     const long long d0 = s - stat22(G, h, kc);
-    long long hw = 0;
+    int hw = 0;
     if (d0 > 0) {
         // S(x) - S(x*) ~ (x - x*)^2 2^28 / (2 var): a guess only (the search does not depend on it)
         const float Nf = (float)h.N, var = (float)h.n * (float)h.K * ((float)(h.N - h.K) * (float)(h.N - h.n)) / (Nf * Nf * Nf);
-        hw = (long long)__fsqrt_rn(2.0f * var * (float)d0 * 3.7252903e-09f);
+        hw = (int)__fsqrt_rn(2.0f * var * (float)d0 * 3.7252903e-09f);
     }
-    const long long lo = (long long)h.kmin - 1, hi = (long long)kc, refl = lo + hi;
-    klo = refl - first_true(lo, hi, refl - ((long long)kc - hw), [&](long long j) { return stat22(G, h, (uint32_t)(refl - j)) >= s; });
-    khi = first_true((long long)kc + 1, (long long)h.kmax + 1, (long long)kc + 1 + hw, [&](long long k) { return stat22(G, h, (uint32_t)k) >= s; });
+    const int lo = (int)h.kmin - 1, hi = (int)kc, refl = lo + hi;
+    klo = refl - first_true32(lo, hi, refl - ((int)kc - hw), [&](int j) { return stat22(G, h, (uint32_t)(refl - j)) >= s; });
+    khi = first_true32((int)kc + 1, (int)h.kmax + 1, (int)kc + 1 + hw, [&](int k) { return stat22(G, h, (uint32_t)k) >= s; });
+}
+
+// walk_sum of the oracle: J = pmf22 along lo .. hi (0 outside the support): first = J(lo), last = J(hi), rest = sum over lo + 1 .. hi
+__device__ __forceinline__ void walk_sum(TabLF LF, const HG22& h, int lo, int hi, double& first, double& last, double& rest) {
+    const int lo2 = lo > (int)h.kmin ? lo : (int)h.kmin, hi2 = hi < (int)h.kmax ? hi : (int)h.kmax;
+    first = 0.0; last = 0.0; rest = 0.0;
+    if (lo2 > hi2) return;
+    uint32_t k = (uint32_t)lo2;
+    const double term0 = pmf22(LF, h, k);
+    double term = term0, sum = 0.0;
+    uint32_t rem = (uint32_t)(hi2 - lo2);
+#pragma unroll 1
+    while (rem > 0u) {
+        const uint32_t m = rem < SUB ? rem : SUB;
+        double P = 0.0, Nn = 1.0, Q = 1.0;
+        const double a = (double)(h.K - k), b = (double)(h.n - k), c = (double)(k + 1u), d = (double)(h.N - h.K - h.n + k + 1u);
+        double num = a * b, den = c * d, sn = a + b - 1.0, sd = c + d + 1.0;
+#pragma unroll 1
+        for (uint32_t j = 0; j < m; ++j) {
+            Nn = Nn * num;
+            Q = Q * den;
+            P = fma(P, den, Nn);
+            num -= sn; den += sd; sn -= 2.0; sd += 2.0;
+        }
+        sum += term * P / Q;
+        term = term * Nn / Q;
+        k += m;
+        rem -= m;
+    }
+    if (lo >= (int)h.kmin) { first = term0; rest = sum; } else { rest = term0 + sum; }
+    if (hi <= (int)h.kmax) last = term;
 }
 
 #ifndef LGMI_SIX_WPS
@@ -809,6 +879,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
     const SixLists ls = six_lists(pa);
     unsigned long long box_max = ((unsigned long long)pa.six_pts * (unsigned long long)n_shuffles) >> 4;
     if (box_max > 4194304ull) box_max = 4194304ull;
+    __shared__ uint32_t s_pre[65];                          // sub-chunks of 16 chords before each of the wave's rows
+    __shared__ unsigned long long s_acc[64];                // the rows' inside masses (2^-62, integer sums)
     unsigned int* const next_row = pa.gen_count + 5;
     uint32_t q_next = 0u;
     if (lane == 0) q_next = atomicAdd(next_row, 64u);
@@ -821,9 +893,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
         uint32_t r = 0xFFFFFFFFu;
         if (q < ls.n_in) r = ls.in[q];
         int st = 0;                                          // 0 nothing, 1 stays with k_perm_general, 2 six-cell with chords, 3 six-cell, thr known
-        uint32_t Ao = 0u, Ap = 1u, Aq = 1u, B0 = 0u;
-        long long sobs = 0, zlo = 0, zhi = 0;
-        double cJ = 0.0;
+        uint32_t Ao = 0u, Ap = 1u, Aq = 1u, B0 = 0u, nz = 0u;
+        int zlo = 0;
+        long long sobs = 0;
+        double cJ = 0.0, rN = 0.0;
         unsigned long long thr = 0ull;
         if (r != 0xFFFFFFFFu) {
             uint32_t T[9];
@@ -845,6 +918,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 Ao = am;
                 Ap = o == 0 ? A1 : A0;
                 Aq = o == 2 ? A1 : A2;
+                rN = 1.0 / (double)(Ap + Aq);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) sobs += G[T[k]];
                 cJ = LF[A0];
@@ -858,18 +932,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                     HG22 hc;
                     hg22_set(hc, N, Ao, B0, 0.0);
                     const long long sc = sobs + 8 - (G[Ap] + G[Aq] - G[Ap + Aq]);
-                    inside22(G, hc, sc, zlo, zhi);
+                    const uint32_t kcc = kc22(hc);
+                    int zhi;
+                    inside22(G, hc, kcc, sc, zlo, zhi);
                     if (zhi - zlo - 1 <= 0) { st = 3; thr = 4294967296ull; }
                     else {
-                        long long zc = (long long)kc22(hc);
+                        int zc = (int)kcc;
                         if (zc <= zlo) zc = zlo + 1;
                         if (zc >= zhi) zc = zhi - 1;
                         HG22 h;
                         hg22_set(h, Ap + Aq, Ap, B0 - (uint32_t)zc, 0.0);
-                        long long klo, khi;
-                        inside22(G, h, sobs - G[(uint32_t)zc] - G[Ao - (uint32_t)zc], klo, khi);
-                        const long long len = khi - klo - 1;
-                        const unsigned long long box = (unsigned long long)(zhi - zlo - 1) + (unsigned long long)(len > 1 ? len : 1);
+                        int klo, khi;
+                        inside22(G, h, kc22r(h, rN), sobs - G[(uint32_t)zc] - G[Ao - (uint32_t)zc], klo, khi);
+                        const int len = khi - klo - 1;
+                        nz = (uint32_t)(zhi - zlo - 1);
+                        const unsigned long long box = (unsigned long long)nz + (unsigned long long)(len > 1 ? len : 1);
                         if (box <= box_max) st = 2;
                     }
                 }
@@ -885,94 +962,113 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 if (st == 1) ls.out[at + (uint32_t)__popcll(kb & ((1ull << lane) - 1ull))] = r;
             }
         }
-        // ---- phase C: the perimeter walk (six_inside_walk in the oracle: every chord an affine map of its predecessor's mass)
-        unsigned long long todo = __ballot(st == 2);
-        while (todo) {                                       // (wave-uniform)
-            const int L = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            const uint32_t rAo = bcast32(Ao, L), rAp = bcast32(Ap, L), rAq = bcast32(Aq, L), rB0 = bcast32(B0, L);
-            const long long rsobs = (long long)bcast64((unsigned long long)sobs, L);
-            const long long rzlo = (long long)bcast64((unsigned long long)zlo, L), rzhi = (long long)bcast64((unsigned long long)zhi, L);
-            const double rcJ = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(cJ), L));
-            const uint32_t nz = (uint32_t)(rzhi - rzlo - 1), Np = rAp + rAq, K = rAp;
-            double total = 0.0, M_carry = 0.0;
-            int a_carry = 0, b_carry = 0;
-            for (uint32_t base = 0u; base < nz; base += 64u) {
-                const uint32_t cnt = nz - base < 64u ? nz - base : 64u;
-                const bool active = lane < cnt;
+        // ---- phase C: the perimeter walk (six_inside_walk in the oracle: every chord an affine map of its predecessor's
+        //      mass, composed 16 chords at a time).  The sub-chunks of the wave's rows are laid side by side, four per trip:
+        //      a chord's composite depends on its distance from its sub-chunk's start only, the first chord of a row has
+        //      rho = 0 (whatever sits in the lanes before it drops out exactly), and the masses are added as integers.
+        {
+            const uint32_t my_sc = st == 2 ? (nz + 15u) >> 4 : 0u;
+            uint32_t incl = my_sc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if (lane >= (uint32_t)o) incl += v;
+            }
+            __syncthreads();                                 // (one wave per workgroup) the previous round's reads are over
+            s_pre[lane] = incl - my_sc;
+            if (lane == 63u) s_pre[64] = incl;
+            s_acc[lane] = 0ull;
+            __syncthreads();
+            const uint32_t TS = s_pre[64];                   // wave-uniform
+            const uint32_t grp = lane >> 4, sub = lane & 15u;
+            double M_it = 0.0;                               // carried from lane 63 of the previous trip
+            int a_it = 0, b_it = 0;
+            for (uint32_t sid0 = 0u; sid0 < TS; sid0 += 4u) {
+                const uint32_t sid = sid0 + grp;
+                const bool valid = sid < TS;
+                uint32_t lo = 0u, hi = 63u;                  // the row of sub-chunk sid: the largest slot with pre[slot] <= sid
+                if (valid) {
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        if (s_pre[mid] <= sid) lo = mid; else hi = mid - 1u;
+                    }
+                }
+                const int rs = (int)lo;
+                const uint32_t rAo = __shfl(Ao, rs), rAp = __shfl(Ap, rs), rAq = __shfl(Aq, rs), rB0 = __shfl(B0, rs), rnz = __shfl(nz, rs);
+                const int rzlo = __shfl(zlo, rs);
+                const long long rsobs = __shfl(sobs, rs);
+                const double rcJ = __shfl(cJ, rs), rrN = __shfl(rN, rs);
+                const uint32_t j = valid ? 16u * (sid - s_pre[rs]) + sub : 0u;
+                const bool active = valid && j < rnz;
+                const uint32_t Np = rAp + rAq, K = rAp;
                 HG22 h = {Np, K, 0u, 0u, 0u, 0.0};
                 int a = 0, b = 0, kc = 0;
                 uint32_t z = 0u;
                 if (active) {
-                    z = (uint32_t)(rzlo + 1) + base + lane;
+                    z = (uint32_t)(rzlo + 1) + j;
                     double c0 = rcJ;
                     c0 -= LF[z];
                     c0 -= LF[rAo - z];
                     hg22_set(h, Np, K, rB0 - z, c0);
-                    long long klo, khi;
-                    inside22(G, h, rsobs - G[z] - G[rAo - z], klo, khi);
-                    a = (int)klo; b = (int)khi - 1;
-                    kc = (int)kc22(h);
+                    kc = (int)kc22r(h, rrN);
+                    int klo, khi;
+                    inside22(G, h, (uint32_t)kc, rsobs - G[z] - G[rAo - z], klo, khi);
+                    a = klo; b = khi - 1;
                 }
                 int a_p = __shfl_up(a, 1), b_p = __shfl_up(b, 1);
-                const bool first = base == 0u && lane == 0u;
-                if (lane == 0u) { a_p = first ? kc : a_carry; b_p = first ? kc : b_carry; }
+                if (lane == 0u) { a_p = a_it; b_p = b_it; }
+                const bool first = j == 0u;
+                if (first) { a_p = kc; b_p = kc; }
                 double rho = 1.0, beta = 0.0;                // idle lanes: the identity map
                 if (active) {
-                    double t2 = 0.0, adjT = 0.0, adjB = 0.0;
+                    double fT, lT, rT, fB, lB, rB;
+                    walk_sum(LF, h, b < b_p ? b : b_p, b < b_p ? b_p : b, fT, lT, rT);
+                    walk_sum(LF, h, a < a_p ? a : a_p, a < a_p ? a_p : a, fB, lB, rB);
+                    const double adjT = b >= b_p ? rT : -rT, adjB = a < a_p ? rB : -rB;
+                    double t2 = 0.0;
                     rho = 0.0;
                     if (!first) {
-                        const double rz = 1.0 / (double)z, rden = 1.0 / (double)(Np - h.n);
+                        const double Jb = b >= b_p ? fT : lT, Ja = a < a_p ? lB : fB;
+                        const double zd = (double)z;
+                        const double rzd = 1.0 / (zd * (double)(Np - h.n));
                         const double f = (double)(rAo - z + 1u) * (double)(h.n + 1u);
-                        double tb = 0.0, ta = 0.0;
-                        rho = f * rz;
-                        rho = rho * rden;
-                        if (b_p >= (int)h.kmin && b_p <= (int)h.kmax) tb = pmf22(LF, h, (uint32_t)b_p) * (double)((int)K - b_p);
-                        if (a_p >= (int)h.kmin && a_p <= (int)h.kmax) ta = pmf22(LF, h, (uint32_t)a_p) * (double)((int)K - a_p);
+                        rho = f * rzd;
+                        const double tb = Jb * (double)((int)K - b_p), ta = Ja * (double)((int)K - a_p);
                         t2 = tb - ta;
-                        t2 = t2 * rden;
-                    }
-                    if (b > b_p) {
-                        const int s0 = b_p + 1 > (int)h.kmin ? b_p + 1 : (int)h.kmin;
-                        if (b >= s0) adjT = unit_sum(LF, h, (uint32_t)s0, (uint32_t)(b - s0 + 1));
-                    } else if (b < b_p) {
-                        const int e = b_p < (int)h.kmax ? b_p : (int)h.kmax;
-                        if (e > b) adjT = -unit_sum(LF, h, (uint32_t)(b + 1), (uint32_t)(e - b));
-                    }
-                    if (a < a_p) {
-                        const int e = a_p < (int)h.kmax ? a_p : (int)h.kmax;
-                        if (e > a) adjB = unit_sum(LF, h, (uint32_t)(a + 1), (uint32_t)(e - a));
-                    } else if (a > a_p) {
-                        const int s0 = a_p + 1 > (int)h.kmin ? a_p + 1 : (int)h.kmin;
-                        if (a >= s0) adjB = -unit_sum(LF, h, (uint32_t)s0, (uint32_t)(a - s0 + 1));
+                        t2 = t2 * (zd * rzd);
                     }
                     beta = t2 + adjT;
                     beta = beta + adjB;
                     if (b - a <= 0) { rho = 0.0; beta = 0.0; }
                 }
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {           // inclusive scan of the affine maps (Hillis-Steele, as the oracle)
+                for (int o = 1; o < 16; o <<= 1) {           // inclusive scan of the maps inside each sub-chunk (Hillis-Steele)
                     const double pr = __shfl_up(rho, o), pb = __shfl_up(beta, o);
-                    if (lane >= (uint32_t)o) {
+                    if (sub >= (uint32_t)o) {
                         const double x = rho * pb;
                         beta = x + beta;
                         rho = rho * pr;
                     }
                 }
-                double M = rho * M_carry;
-                M = M + beta;
-                if (!active) M = 0.0;
-                M_carry = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(M), (int)cnt - 1));
-                a_carry = (int)bcast32((uint32_t)a, (int)cnt - 1); b_carry = (int)bcast32((uint32_t)b, (int)cnt - 1);
+                // the mass carried into each sub-chunk: the last chord of the sub-chunk before it (the same row's, or dropped by
+                // rho = 0 when a row starts here)
+                double carry = M_it, M = 0.0;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) M = M + __shfl_xor(M, o);
-                total = total + M;
+                for (uint32_t g = 0; g < 4u; ++g) {
+                    double x = rho * carry;
+                    x = x + beta;
+                    if (grp == g) M = x;
+                    carry = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(x), (int)(16u * g + 15u)));
+                }
+                M_it = carry;
+                a_it = (int)bcast32((uint32_t)a, 63); b_it = (int)bcast32((uint32_t)b, 63);
+                if (active && M > 0.0)
+                    atomicAdd(&s_acc[rs], M >= 1.0 ? 4611686018427387904ull : (unsigned long long)(M * 4611686018427387904.0));
             }
-            if ((int)lane == L) {
-                unsigned long long ins = 0ull;
-                if (total >= 1.0) ins = 4611686018427387904ull;
-                else if (total > 0.0) ins = (unsigned long long)(total * 4611686018427387904.0);
-                thr = (4611686018427387904ull - ins) >> 30;
+            __syncthreads();
+            if (st == 2) {
+                const unsigned long long ins = s_acc[lane];
+                thr = ins <= 4611686018427387904ull ? (4611686018427387904ull - ins) >> 30 : 0ull;
                 st = 3;
             }
         }
@@ -983,7 +1079,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
             if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
             if (!ls.third) ls.in[q] = 0xFFFFFFFFu;          // no third list: k_perm_general skips the row
         }
-        const uint32_t done = (uint32_t)__popcll(__ballot(st == 3));        // (statistics: lgmi_run_info.n_six_rows)
+        const uint32_t done = (uint32_t)__popcll(__ballot(st == 3));        // (statistics)
         if (lane == 0 && done) atomicAdd(pa.gen_count + 6, done);
     }
 }

@@ -930,13 +930,24 @@ static uint64_t six_inside(const perm_tables* t, const six_row* s, uint64_t* are
     return m;
 }
 
-/* sum of pmf22 over [k0, k0 + len) as a double: unit_mass's recurrence (first term from the log-factorials, sub-blocks of
- * SUB steps), any length, no truncation */
-static double range_sum_d(const perm_tables* t, const hg22* h, int64_t k0, int64_t len)
+/* The joint pmf J(x) = pmf22(h, x) along lo .. hi by unit_mass's recurrence (first term from the log-factorials, sub-blocks
+ * of SUB steps; any length), J = 0 outside the chord's support [kmin, kmax]:
+ *     *first = J(lo), *last = J(hi), *rest = the sum of J over lo + 1 .. hi.
+ * With lo' = max(lo, kmin), hi' = min(hi, kmax) (nothing when lo' > hi'): the recurrence starts at lo' with term0 = pmf22(lo')
+ * and sums the terms after it into rest'; first = term0 and rest = rest' when lo >= kmin, else first = 0 and
+ * rest = term0 + rest'; last = the recurrence's final term when hi <= kmax, else 0. */
+static void walk_sum(const perm_tables* t, const hg22* h, int64_t lo, int64_t hi, double* first, double* last, double* rest)
 {
-    uint32_t k = (uint32_t)k0;
-    double term = pmf22(t, h, k), sum = term;
-    int64_t rem = len - 1;
+    const int64_t lo2 = lo > (int64_t)h->kmin ? lo : (int64_t)h->kmin, hi2 = hi < (int64_t)h->kmax ? hi : (int64_t)h->kmax;
+    uint32_t k;
+    double term0, term, sum = 0.0;
+    int64_t rem;
+    *first = 0.0; *last = 0.0; *rest = 0.0;
+    if (lo2 > hi2) return;
+    k = (uint32_t)lo2;
+    term0 = pmf22(t, h, k);
+    term = term0;
+    rem = hi2 - lo2;
     while (rem > 0) {
         const int64_t m = rem < SUB ? rem : SUB;
         double P = 0.0, Nn = 1.0, Q = 1.0;
@@ -954,7 +965,8 @@ static double range_sum_d(const perm_tables* t, const hg22* h, int64_t k0, int64
         k += (uint32_t)m;
         rem -= m;
     }
-    return sum;
+    if (lo >= (int64_t)h->kmin) { *first = term0; *rest = sum; } else { *rest = term0 + sum; }
+    if (hi <= (int64_t)h->kmax) *last = term;
 }
 
 /* The mass of {S < S_obs} along the PERIMETER instead of over the area.  With X_n ~ HG(N', K, n) one more draw gives
@@ -963,102 +975,84 @@ static double range_sum_d(const perm_tables* t, const hg22* h, int64_t k0, int64
  *     rho_z = w(z + 1) / w(z) = (A_o - z)(n_z) / ((z + 1)(N' - n_z + 1))          (w = the collapsed table's pmf)
  * with M(z) = the joint mass of chord z over (a, b] and J the joint pmf (0 outside the chord's support): exact, a few terms per
  * chord instead of the chord's length.  Then the range is moved from the previous chord's inside (a_p, b_p] to this chord's
- * (a, b] by adding / removing the few values in between (range_sum_d).  So every chord is an affine map of its predecessor's
- * mass, M_c = rho_c M_p + beta_c, all of whose coefficients depend on the two chords' bounds only:
- *     rho_c  = ((A_o - z + 1)(n + 1)) (1 / z) (1 / (N' - n))                        (n = n_z; products in this order)
- *     beta_c = (J(b_p, z)(K - b_p) - J(a_p, z)(K - a_p)) (1 / (N' - n)) + adjT + adjB
- *     adjT   = + sum (max(b_p + 1, kmin) .. b) if b > b_p,  - sum (b + 1 .. min(b_p, kmax)) if b < b_p
- *     adjB   = + sum (a + 1 .. min(a_p, kmax)) if a < a_p,  - sum (max(a_p + 1, kmin) .. a) if a > a_p
- * the row's first chord: rho = 0, a_p = b_p = its own kc (the adjustments sum the whole chord); an empty chord: rho = beta = 0.
- * The chords are taken 64 at a time (one per GPU lane): the 64 maps are composed by an inclusive Hillis-Steele scan
- * (offsets 1, 2, .., 32: beta <- rho beta_prev + beta, rho <- rho rho_prev, products and sums rounded separately), applied
- * to the mass carried in from the previous 64, summed by an xor butterfly (offsets 32 .. 1), and the row's total is the
- * sum of the 64-chord totals in order.  All of it is IEEE +, -, *, / on doubles in a fixed order: the same bits on both
- * sides.  inside = trunc(2^62 total) clipped to [0, 2^62]. */
+ * (a, b] by adding / removing the few values in between.  So every chord is an affine map of its predecessor's mass,
+ * M_c = rho_c M_p + beta_c, whose coefficients depend on the two chords' bounds only.  Chord j = 0, 1, .. of the row, z = zlo + 1 + j,
+ * n = B0 - z, K = A_p, N' = A_p + A_q, (a, b] = (klo, khi - 1] its inside, (a_p, b_p] its predecessor's (j = 0: a_p = b_p = its own kc):
+ *     top      walk_sum(min(b, b_p) .. max(b, b_p)) -> first, last, rest:   Jb = b >= b_p ? first : last,   adjT = b >= b_p ? rest : -rest
+ *     bottom   walk_sum(min(a, a_p) .. max(a, a_p)) -> first, last, rest:   Ja = a <  a_p ? last : first,   adjB = a <  a_p ? rest : -rest
+ *     rzd    = 1 / ((double)z (double)(N' - n));   rho = ((double)(A_o - z + 1) (double)(n + 1)) rzd
+ *     t2     = (Jb (double)(K - b_p) - Ja (double)(K - a_p)) ((double)z rzd);   beta = (t2 + adjT) + adjB
+ *     j = 0: rho = 0, t2 = 0 (the adjustments sum the whole chord);   an empty chord (b <= a): rho = beta = 0.
+ * The maps are composed 16 chords at a time (sub-chunk g = chords 16 g .. 16 g + 15 of the row): an inclusive Hillis-Steele scan
+ * inside the sub-chunk (offsets 1, 2, 4, 8: beta <- rho beta_prev + beta, rho <- rho rho_prev, products and sums rounded
+ * separately), applied to the mass of the previous sub-chunk's last chord (0 for g = 0): M_j = rho_incl M_carry + beta_incl.
+ * A chord's composite depends on its distance from the sub-chunk's start only, so the GPU may lay sub-chunks of different
+ * rows side by side in one wave.  inside = sum over the chords of trunc(2^62 min(max(M_j, 0), 1)): an integer sum, any order.
+ * All of it is IEEE +, -, *, / on doubles in a fixed order: the same bits on both sides. */
 static uint64_t six_inside_walk(const perm_tables* t, const six_row* s)
 {
     const uint32_t Ao = s->A[s->o], Ap = s->A[s->p], Aq = s->A[s->q], Np = Ap + Aq, K = Ap;
     const int64_t nz = s->zhi - s->zlo - 1;
-    double total = 0.0, M_carry = 0.0;
+    uint64_t inside = 0;
+    double M_carry = 0.0;
     int64_t a_carry = 0, b_carry = 0, base;
-    for (base = 0; base < nz; base += 64) {
-        double rho[64], beta[64], M[64];
-        int64_t av[64], bv[64];
-        const int cnt = (int)(nz - base < 64 ? nz - base : 64);
+    for (base = 0; base < nz; base += 16) {
+        double rho[16], beta[16];
+        int64_t av[16], bv[16];
+        const int cnt = (int)(nz - base < 16 ? nz - base : 16);
         int l, o;
-        for (l = 0; l < 64; ++l) { rho[l] = 1.0; beta[l] = 0.0; av[l] = bv[l] = 0; }
-        for (l = 0; l < cnt; ++l) {                      /* the chords' own bounds */
-            hg22 h;
-            int64_t klo, khi;
-            six_chord(t, s, s->zlo + 1 + base + l, &h, &klo, &khi);
-            av[l] = klo; bv[l] = khi - 1;
-        }
+        for (l = 0; l < 16; ++l) { rho[l] = 1.0; beta[l] = 0.0; av[l] = bv[l] = 0; }
         for (l = 0; l < cnt; ++l) {
             const int64_t z = s->zlo + 1 + base + l;
             const int first = (base == 0 && l == 0);
             hg22 h;
             int64_t klo, khi, a, b, a_p, b_p;
-            double r = 0.0, t2 = 0.0, adjT = 0.0, adjB = 0.0, be;
+            double r = 0.0, t2 = 0.0, adjT, adjB, be, fT, lT, rT, fB, lB, rB;
             six_chord(t, s, z, &h, &klo, &khi);
             a = klo; b = khi - 1;
+            av[l] = a; bv[l] = b;
             if (first) { a_p = b_p = (int64_t)kc_of(&h); }
             else if (l == 0) { a_p = a_carry; b_p = b_carry; }
             else { a_p = av[l - 1]; b_p = bv[l - 1]; }
+            walk_sum(t, &h, b < b_p ? b : b_p, b < b_p ? b_p : b, &fT, &lT, &rT);
+            walk_sum(t, &h, a < a_p ? a : a_p, a < a_p ? a_p : a, &fB, &lB, &rB);
+            adjT = b >= b_p ? rT : -rT;
+            adjB = a < a_p ? rB : -rB;
             if (!first) {
-                const double rz = 1.0 / (double)z, rden = 1.0 / (double)(Np - h.n);
+                const double Jb = b >= b_p ? fT : lT, Ja = a < a_p ? lB : fB;
+                const double zd = (double)z;
+                const double rzd = 1.0 / (zd * (double)(Np - h.n));
                 const double f = (double)(Ao - z + 1) * (double)(h.n + 1u);
-                double tb = 0.0, ta = 0.0;
-                r = f * rz;
-                r = r * rden;
-                if (b_p >= (int64_t)h.kmin && b_p <= (int64_t)h.kmax) tb = pmf22(t, &h, (uint32_t)b_p) * (double)((int64_t)K - b_p);
-                if (a_p >= (int64_t)h.kmin && a_p <= (int64_t)h.kmax) ta = pmf22(t, &h, (uint32_t)a_p) * (double)((int64_t)K - a_p);
+                double tb, ta;
+                r = f * rzd;
+                tb = Jb * (double)((int64_t)K - b_p);
+                ta = Ja * (double)((int64_t)K - a_p);
                 t2 = tb - ta;
-                t2 = t2 * rden;
-            }
-            if (b > b_p) {
-                const int64_t st = b_p + 1 > (int64_t)h.kmin ? b_p + 1 : (int64_t)h.kmin;
-                if (b >= st) adjT = range_sum_d(t, &h, st, b - st + 1);
-            } else if (b < b_p) {
-                const int64_t e = b_p < (int64_t)h.kmax ? b_p : (int64_t)h.kmax;
-                if (e > b) adjT = -range_sum_d(t, &h, b + 1, e - b);
-            }
-            if (a < a_p) {
-                const int64_t e = a_p < (int64_t)h.kmax ? a_p : (int64_t)h.kmax;
-                if (e > a) adjB = range_sum_d(t, &h, a + 1, e - a);
-            } else if (a > a_p) {
-                const int64_t st = a_p + 1 > (int64_t)h.kmin ? a_p + 1 : (int64_t)h.kmin;
-                if (a >= st) adjB = -range_sum_d(t, &h, st, a - st + 1);
+                t2 = t2 * (zd * rzd);
             }
             be = t2 + adjT;
             be = be + adjB;
             if (b - a <= 0) { r = 0.0; be = 0.0; }
             rho[l] = r; beta[l] = be;
         }
-        for (o = 1; o < 64; o <<= 1) {                   /* inclusive scan of the affine maps */
-            double pr[64], pb[64];
-            for (l = 0; l < 64; ++l) { pr[l] = rho[l]; pb[l] = beta[l]; }
-            for (l = o; l < 64; ++l) {
-                double x = pr[l] * pb[l - o];
+        for (o = 1; o < 16; o <<= 1) {                   /* inclusive scan of the affine maps */
+            double pr[16], pb[16];
+            for (l = 0; l < 16; ++l) { pr[l] = rho[l]; pb[l] = beta[l]; }
+            for (l = o; l < 16; ++l) {
+                const double x = pr[l] * pb[l - o];
                 beta[l] = x + pb[l];
                 rho[l] = pr[l] * pr[l - o];
             }
         }
-        for (l = 0; l < 64; ++l) {
+        for (l = 0; l < cnt; ++l) {
             double x = rho[l] * M_carry;
             x = x + beta[l];
-            M[l] = l < cnt ? x : 0.0;
+            rho[l] = x;                                   /* (rho[] now holds the chords' masses) */
+            if (x > 0.0) inside += x >= 1.0 ? 4611686018427387904ull : (uint64_t)(x * 4611686018427387904.0);
         }
-        M_carry = M[cnt - 1]; a_carry = av[cnt - 1]; b_carry = bv[cnt - 1];
-        for (o = 32; o > 0; o >>= 1) {                   /* xor butterfly: every lane ends with the same sum */
-            double v[64];
-            for (l = 0; l < 64; ++l) v[l] = M[l] + M[l ^ o];
-            for (l = 0; l < 64; ++l) M[l] = v[l];
-        }
-        total = total + M[0];
+        M_carry = rho[cnt - 1]; a_carry = av[cnt - 1]; b_carry = bv[cnt - 1];
     }
-    if (!(total > 0.0)) return 0;
-    if (total >= 1.0) return 4611686018427387904ull;
-    return (uint64_t)(total * 4611686018427387904.0);
+    return inside;
 }
 
 static uint64_t six_thr(const perm_tables* t, const six_row* s, double* p_out)
