@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LGMI_ABI_VERSION 4
+#define LGMI_ABI_VERSION 5
 
 /* error codes */
 #define LGMI_OK        0
@@ -171,7 +171,8 @@ typedef struct lgmi_run_info {
     uint32_t n_count_launches;
     uint32_t n_mfma_tiles;  /* 128 x 128 tiles computed on the matrix cores (0: VALU popcount only)      */
     uint32_t mfma_dtype;    /* operand type of those tiles: 0 none, 1 int8, 2 fp4 (e2m1)                 */
-    uint32_t reserved;
+    uint32_t n_six_rows;    /* of n_general_rows: 3 x 2 / 2 x 3 rows whose exact tail mass came from the perimeter walk
+                               (k_perm_six) — one binomial variate each instead of n_shuffles table draws  */
     uint64_t n_examined_total; /* examined pairs of the whole batch (== n_examined when unsharded)         */
     uint64_t n_general_rows;   /* rows whose table is larger than 2 x 2: these get n_shuffles real table
                                   draws each; 2 x 2 rows get ONE binomial variate            */
@@ -209,6 +210,11 @@ typedef struct lgmi_dresult lgmi_dresult; /* result rows resident in HBM       *
 
 int         lgmi_abi_version(void);
 const char* lgmi_last_error(void);
+/* sizeof the library's own lgmi_batch (which = 0), lgmi_params (1), lgmi_result (2), lgmi_run_info (3), lgmi_synth_spec (4),
+ * lgmi_shard_plan (5), lgmi_gather_opts (6), lgmi_comm_info_t (7); 0 for any other `which`.  A binding checks its struct
+ * declarations against these before its first call: a caller built against an older header would otherwise have the
+ * library read or write past its structs (ABI 5; INTEGRATION.md 4 shows the check). */
+size_t      lgmi_struct_size(int which);
 int         lgmi_device_count(int* out_count);
 
 int  lgmi_ctx_create(int device_id, lgmi_ctx** out);

@@ -243,6 +243,19 @@ struct HostResult : ResultOwner {  // owner_ of a host lgmi_result: pinned buffe
 // ---------------------------------------------------------------- basics
 extern "C" int lgmi_abi_version(void) { return LGMI_ABI_VERSION; }
 extern "C" const char* lgmi_last_error(void) { return g_err.c_str(); }
+extern "C" size_t lgmi_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(lgmi_batch);
+        case 1: return sizeof(lgmi_params);
+        case 2: return sizeof(lgmi_result);
+        case 3: return sizeof(lgmi_run_info);
+        case 4: return sizeof(lgmi_synth_spec);
+        case 5: return sizeof(lgmi_shard_plan);
+        case 6: return sizeof(lgmi_gather_opts);
+        case 7: return sizeof(lgmi_comm_info_t);
+        default: return 0;
+    }
+}
 
 extern "C" int lgmi_device_count(int* out_count) {
     if (!out_count) return fail(LGMI_E_ARG, "out_count is NULL");
@@ -971,9 +984,10 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[5], st));
     unsigned long long* hs = ctx->h_scal;
-    hs[0] = hs[1] = hs[2] = hs[3] = 0;
+    hs[0] = hs[1] = hs[2] = hs[3] = hs[4] = 0;
     HIPCHK(hipMemcpyAsync(&hs[0], d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&hs[1], d_gencount, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&hs[4], d_gencount + 6, 4, hipMemcpyDeviceToHost, st));    // rows k_perm_six finished
     HIPCHK(hipMemcpyAsync(&hs[2], d_wordpairs, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&hs[3], d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
     tr.mark("enqueued");
@@ -992,6 +1006,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     inf.n_examined = pl.n_examined;
     inf.n_examined_total = pl.n_examined_total;
     inf.n_general_rows = n_general;
+    inf.n_six_rows = (uint32_t)hs[4];
     inf.n_tile_pairs = (uint64_t)pl.tiles.size() * TILE * TILE + (uint64_t)pl.mtiles.size() * 128 * 128;
     inf.word_pairs = wp;
     inf.bytes_in = pl.bytes_in;
@@ -999,7 +1014,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     inf.n_count_launches = (pl.tiles.empty() ? 0 : 1) + (pl.mtiles.empty() ? 0 : 1);
     inf.n_mfma_tiles = (uint32_t)std::min<size_t>(pl.mtiles.size(), 0xFFFFFFFFu);
     inf.mfma_dtype = pl.mtiles.empty() ? 0u : (pl.mfma_fp4 ? 2u : 1u);
-    inf.reserved = 0; inf.n_seq_shards = 1;
+    inf.n_seq_shards = 1;
     inf.ms_plan_host = ms_plan_host;
     HIPCHK(hipEventElapsedTime(&inf.ms_prep, ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&inf.ms_count, ctx->ev[1], ctx->ev[2]));
@@ -1111,7 +1126,7 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
         if (s == 0) tot = pi;
         else {
             tot.n_rows += pi.n_rows; tot.n_examined += pi.n_examined; tot.n_tile_pairs += pi.n_tile_pairs;
-            tot.word_pairs += pi.word_pairs; tot.bytes_out += pi.bytes_out; tot.n_general_rows += pi.n_general_rows;
+            tot.word_pairs += pi.word_pairs; tot.bytes_out += pi.bytes_out; tot.n_general_rows += pi.n_general_rows; tot.n_six_rows += pi.n_six_rows;
             tot.ms_total += pi.ms_total; tot.ms_prep += pi.ms_prep; tot.ms_count += pi.ms_count; tot.ms_emit += pi.ms_emit;
             tot.ms_perm += pi.ms_perm; tot.ms_mean += pi.ms_mean; tot.ms_plan_host += pi.ms_plan_host;
             tot.ms_perm_fast += pi.ms_perm_fast; tot.ms_perm_general += pi.ms_perm_general;
@@ -1174,14 +1189,16 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
         HIPCHK(hipEventRecord(ctx->ev[6], st));
         launch_perm_general(st, pa);
         HIPCHK(hipGetLastError());
-        ctx->h_scal[1] = 0;
+        ctx->h_scal[1] = 0; ctx->h_scal[4] = 0;
         HIPCHK(hipMemcpyAsync(&ctx->h_scal[1], d_gencount, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&ctx->h_scal[4], d_gencount + 6, 4, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
     HIPCHK(wait_stream(st));
     if (res->cap_rows) n_general = (unsigned int)ctx->h_scal[1];
     lgmi_run_info& inf = res->info;
     inf.n_general_rows = n_general;
+    inf.n_six_rows = res->cap_rows ? (uint32_t)ctx->h_scal[4] : 0u;
     HIPCHK(hipEventElapsedTime(&inf.ms_perm, ctx->ev[3], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&inf.ms_perm_fast, ctx->ev[3], ctx->ev[6]));
     HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));

@@ -1799,7 +1799,7 @@ static uint32_t perm_enum_max()
 }
 
 // LGMI_PERM_SIX_PTS: sixteenths of a chord per shuffle a six-cell row may cost on the exact path (0: every such row is sampled;
-// the CPU specification has the same switch, lgo_set_six_pts)
+// the CPU specification has the same switch)
 static uint32_t perm_six_pts()
 {
     static const uint32_t v = [] {

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LGMI_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'liblgmi.so'))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK, E_ARG, E_OOM, E_HIP, E_RCCL, E_NODEV, E_STATE, E_DOMAIN = 0, -1, -2, -3, -4, -5, -6, -7
 TYPE_MISMATCH, TYPE_SNP, TYPE_HET_SNP = 0, 1, 2
 UNIQUE_ID_BYTES = 128
@@ -48,7 +48,7 @@ class RunInfo(C.Structure):
                 ('ms_total', C.c_float), ('ms_prep', C.c_float), ('ms_count', C.c_float),
                 ('ms_emit', C.c_float), ('ms_perm', C.c_float), ('ms_mean', C.c_float),
                 ('n_count_launches', C.c_uint32), ('n_mfma_tiles', C.c_uint32),
-                ('mfma_dtype', C.c_uint32), ('reserved', C.c_uint32),
+                ('mfma_dtype', C.c_uint32), ('n_six_rows', C.c_uint32),
                 ('n_examined_total', C.c_uint64), ('n_general_rows', C.c_uint64),
                 ('ms_plan_host', C.c_float), ('ms_perm_fast', C.c_float), ('ms_perm_general', C.c_float),
                 ('n_seq_shards', C.c_uint32)]
@@ -94,6 +94,7 @@ VP = C.c_void_p
 SYMBOLS = {
     'lgmi_abi_version': (C.c_int, []),
     'lgmi_last_error': (C.c_char_p, []),
+    'lgmi_struct_size': (C.c_size_t, [C.c_int]),
     'lgmi_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'lgmi_ctx_create': (C.c_int, [C.c_int, C.POINTER(VP)]),
     'lgmi_ctx_destroy': (None, [VP]),
@@ -146,6 +147,10 @@ def load():
             fn.argtypes = args
         if lib.lgmi_abi_version() != ABI_VERSION:
             raise RuntimeError('liblgmi.so ABI %d != binding ABI %d' % (lib.lgmi_abi_version(), ABI_VERSION))
+        for which, st in enumerate((Batch, Params, Result, RunInfo, SynthSpec, ShardPlan, GatherOpts, CommInfo)):
+            if lib.lgmi_struct_size(which) != C.sizeof(st):       # a stale declaration would be read / written past
+                raise RuntimeError('liblgmi.so: sizeof %s is %d, the binding declares %d'
+                                   % (st.__name__, lib.lgmi_struct_size(which), C.sizeof(st)))
         _lib = lib
     return _lib
 

@@ -597,12 +597,17 @@ def test_stream_site_base_shifts_the_philox_counters(engine):
     assert (a.row_exceed != b.row_exceed).any()
 
 
-@pytest.mark.parametrize('env', [{'LGMI_PERM_ENUM_MAX': '0'}, {'LGMI_PERM_ENUM_MAX': '4096', 'LGMI_PERM_NO_SECOND_LIST': '1'}],
-                         ids=['enumeration_off', 'rows_marked_in_the_queue'])
+@pytest.mark.parametrize('env', [{'LGMI_PERM_ENUM_MAX': '0'}, {'LGMI_PERM_ENUM_MAX': '4096', 'LGMI_PERM_NO_SECOND_LIST': '1'},
+                                 {'LGMI_PERM_SIX_PTS': '0', 'LGMI_WORKER_DENSE': '1'}, {'LGMI_PERM_SIX_PTS': '4096', 'LGMI_WORKER_DENSE': '1'},
+                                 {'LGMI_PERM_SIX_PTS': '0', 'LGMI_PERM_ENUM_MAX': '0'}],
+                         ids=['enumeration_off', 'rows_marked_in_the_queue', 'six_cell_path_off', 'six_cell_gate_wide_open',
+                              'every_larger_row_sampled'])
 def test_permutation_p_in_the_other_configurations(env):
-    """small larger-than-2x2 rows get their tail mass by enumeration (round 3).  With LGMI_PERM_ENUM_MAX=0 — and the same
-    switch in the CPU specification — they all take the Monte-Carlo path again; with LGMI_PERM_NO_SECOND_LIST=1 the
-    enumeration kernel marks its rows in the queue instead of listing the others: tests/helpers/perm_enum_worker.py"""
+    """small larger-than-2x2 rows get their tail mass by enumeration (round 3), 3 x 2 / 2 x 3 rows behind a gate by the
+    perimeter walk (round 4).  With LGMI_PERM_ENUM_MAX=0 / LGMI_PERM_SIX_PTS=0 — and the same switches in the CPU
+    specification — they take the Monte-Carlo paths again (the lock-step loop included, on dense blocks of 40,000 and
+    200,000 reads); with LGMI_PERM_NO_SECOND_LIST=1 the enumeration kernel and the six-cell kernel mark their rows in the
+    queue instead of listing the others: tests/helpers/perm_enum_worker.py"""
     import os
     import subprocess
     import sys

@@ -29,6 +29,10 @@ def lib():
     lib.lgo_binom_draw_many.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, u32p]
     lib.lgo_perm_ptail.restype = C.c_int
     lib.lgo_perm_ptail.argtypes = [u32p, f64p]
+    lib.lgo_perm_six.restype = C.c_int
+    lib.lgo_perm_six.argtypes = [u32p, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.lgo_set_six_pts.restype = C.c_uint32
+    lib.lgo_set_six_pts.argtypes = [C.c_uint32]
     return lib
 
 
@@ -412,7 +416,11 @@ def test_lockstep_tables_follow_the_null_distribution(lib, T):
 @pytest.mark.parametrize('T', LOCKSTEP_TABLES[:4])
 def test_lockstep_monte_carlo_p_agrees_with_enumeration(lib, T):
     S = 60000
-    p, ex = run_perm([T], S)
+    old = lib.lgo_set_six_pts(0)                    # (the six-cell path would take these rows: this is the sampling loop's test)
+    try:
+        p, ex = run_perm([T], S)
+    finally:
+        lib.lgo_set_six_pts(old)
     pmf = _lockstep_pmf(T)
     Tm = np.asarray(T, float).reshape(3, 3)
     g = lambda c: float((np.where(c > 0, c * np.log(np.maximum(c, 1)), 0.0)).sum())
@@ -517,3 +525,131 @@ def test_monte_carlo_and_enumeration_paths_agree(lib, T):
         lib.lgo_set_enum_max(old)
     _p, ex_enum = run_perm([T], S)
     assert abs(ex_mc[0] / S - exact) < 5 * sd + 2e-4 and abs(ex_enum[0] / S - exact) < 5 * sd + 2e-4
+
+
+# ---------------------------------------------------------------- six-cell tables: exact mass along the perimeter (round 4)
+def _six(lib, T, n_shuffles=10 ** 6):
+    """-> (takes the path, dict(area mass, points, chords, zero test, thr, walk mass))"""
+    out = (C.c_uint64 * 6)()
+    rc = lib.lgo_perm_six(np.asarray(T, np.uint32).ctypes.data_as(u32p), n_shuffles, out)
+    return rc, {'area': out[0] * 2.0 ** -62, 'points': out[1], 'chords': out[2], 'zero': out[3], 'thr': out[4],
+                'walk': out[5] * 2.0 ** -62}
+
+
+def brute_ptail_six(T):
+    """P(S >= S_obs) over every table with the margins of a 3 x 2 / 2 x 3 table, as one numpy grid over two free cells
+    (independent of the specification's code: no chords, no recurrences)"""
+    from scipy.special import gammaln
+    M = np.asarray(T, np.int64).reshape(3, 3)
+    R, Cm = M.sum(axis=1), M.sum(axis=0)
+    A, B = (R, Cm[Cm > 0]) if (R > 0).sum() == 3 else (Cm, R[R > 0])
+    N, B0 = int(A.sum()), int(B[0])
+    z = np.arange(0, min(A[0], B0) + 1)[:, None]
+    x = np.arange(0, min(A[1], B0) + 1)[None, :]
+    a2 = B0 - z - x
+    ok = (a2 >= 0) & (a2 <= A[2])
+    cells = [np.where(ok, c, 0) for c in (z + 0 * x, x + 0 * z, a2, A[0] - z + 0 * x, A[1] - x + 0 * z, A[2] - a2)]
+    const = gammaln(A + 1.0).sum() + gammaln(B + 1.0).sum() - gammaln(N + 1.0)
+    with np.errstate(over='ignore'):
+        pr = np.where(ok, np.exp(const - sum(gammaln(c + 1.0) for c in cells)), 0.0)
+    st = sum(np.where(c > 0, c * np.log(np.maximum(c, 1)), 0.0) for c in [c.astype(float) for c in cells])
+    sobs = float(sum(v * np.log(v) for v in M.ravel() if v > 0))
+    assert abs(pr.sum() - 1) < 1e-9
+    return float(pr[ok & (st >= sobs - 2e-13 * max(1.0, abs(sobs)))].sum())
+
+
+def _random_six_table(rng, N, assoc):
+    pa = rng.dirichlet([3, 3, 0.6])[rng.permutation(3)]
+    c = rng.uniform(0.1, 0.9)
+    la = rng.choice(3, N, p=pa)
+    lb = (rng.random(N) < c + assoc * (la == 0)).astype(int)
+    M = np.zeros((3, 3), int)
+    shape = rng.integers(4)
+    if shape < 2:                                    # 3 x 2, the empty column in either place
+        np.add.at(M, (la, lb + shape), 1)
+    else:                                            # 2 x 3, the empty row in either place
+        np.add.at(M, (lb + shape - 2, la), 1)
+    return M.ravel()
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_six_cell_mass_is_the_exact_tail_probability(lib, seed):
+    """both evaluations of the mass of {S < S_obs} — the sum over the area and the walk along the perimeter, which is what
+    the threshold is made of — against a brute-force grid over all tables, for 3 x 2 and 2 x 3 tables of 60 .. 8000 reads,
+    null and associated"""
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.choice([60, 300, 2000, 8000]))
+    T = _random_six_table(rng, N, [0.0, 0.0, 0.08, 0.15][seed % 4])
+    M = T.reshape(3, 3)
+    if (M.sum(axis=1) > 0).sum() * (M.sum(axis=0) > 0).sum() != 6:
+        pytest.skip('a class came out empty')
+    rc, o = _six(lib, T)
+    assert rc == 1
+    exact = brute_ptail_six(T)
+    if o['zero']:
+        assert exact < 2.0 ** -33 and o['thr'] == 0
+        return
+    assert abs((1 - o['walk']) - exact) < 2e-9 and abs((1 - o['area']) - exact) < 2e-9, (o, exact)
+    assert abs(o['walk'] - o['area']) < 1e-10
+    assert o['thr'] == (2 ** 62 - int(round(o['walk'] * 2.0 ** 62))) >> 30 or abs(o['thr'] * 2.0 ** -32 - exact) < 1e-8
+
+
+def test_six_cell_walk_equals_area_at_two_hundred_thousand_reads(lib):
+    """north-star sized tables (162,000 common reads, a 5 % third allele): the perimeter walk — ~100 affine maps chained
+    through 16-chord scans — against the plain sum over the ~1e4 tables of the area"""
+    rng = np.random.default_rng(1)
+    N, worst, pts = 162000, 0.0, []
+    for it in range(12):
+        e = rng.uniform(0.05, 0.5)
+        pa = np.array([0.95 * (1 - e), 0.95 * e, 0.05]) if it % 2 else np.array([0.475, 0.475, 0.05])
+        la = rng.choice(3, N, p=pa)
+        lb = (rng.random(N) < (0.5 if it % 2 else rng.uniform(0.05, 0.5))).astype(int)
+        M = np.zeros((3, 3), int)
+        np.add.at(M, (la, lb), 1)
+        rc, o = _six(lib, M.ravel())
+        assert rc == 1 and not o['zero']
+        worst = max(worst, abs(o['walk'] - o['area']))
+        pts.append(o['points'] / max(o['chords'], 1))
+    assert worst < 1e-9, worst
+    assert np.mean(pts) > 30            # the walk really skips work: tens of tables per chord are never visited
+
+
+def test_six_cell_zero_test_and_gate(lib):
+    # a tri-allelic het SNP against a linked het SNP: no table as extreme as the observed one weighs 2^-33
+    rc, o = _six(lib, [4000, 30, 0, 40, 3900, 0, 210, 190, 0], 1000)
+    assert rc == 1 and o['zero'] == 1 and o['thr'] == 0
+    # the gate: chords + central chord length against SIX_PTS n_shuffles / 16 (SIX_PTS = 16: as many chords as shuffles)
+    T = [12000, 11800, 0, 6100, 5900, 0, 1300, 1250, 0]
+    rc, o = _six(lib, T, 10 ** 6)
+    assert rc == 1 and o['chords'] > 20
+    need = o['chords'] + 1
+    assert _six(lib, T, need - 2)[0] == 0 and _six(lib, T, 40 * need)[0] == 1
+    old = lib.lgo_set_six_pts(0)
+    try:
+        assert _six(lib, T, 10 ** 6)[0] == 0
+    finally:
+        lib.lgo_set_six_pts(old)
+    # no table below S_obs (the observed table is the table of independence): inside = 0, thr = 2^32, p = 1
+    rc, o = _six(lib, [50, 50, 0, 30, 30, 0, 20, 20, 0], 1000)
+    assert rc == 1 and o['walk'] == 0.0 and o['thr'] == 2 ** 32
+    # 3 x 3 tables never take the path
+    assert _six(lib, [10, 3, 2, 2, 9, 4, 1, 3, 12])[0] == 0
+
+
+@pytest.mark.parametrize('T', LOCKSTEP_TABLES)
+def test_six_cell_path_and_sampling_path_agree(lib, T):
+    """the same rows through both paths of the specification: exceed / S of the lock-step sampling loop (six-cell path
+    switched off) and of the perimeter walk (one binomial variate) both sit on the exact tail probability"""
+    S = 40000
+    exact = brute_ptail_six(T)
+    sd = np.sqrt(max(exact * (1 - exact), 1e-12) / S)
+    old = lib.lgo_set_six_pts(0)
+    try:
+        _p, ex_mc = run_perm([T], S)
+    finally:
+        lib.lgo_set_six_pts(old)
+    rc, o = _six(lib, T, S)
+    assert rc == 1
+    _p, ex_six = run_perm([T], S)
+    assert abs(ex_mc[0] / S - exact) < 5 * sd + 2e-4 and abs(ex_six[0] / S - exact) < 5 * sd + 2e-4
+    assert abs(o['thr'] * 2.0 ** -32 - exact) < 1e-8
