@@ -66,7 +66,7 @@ def class_matrix(sites):
         order = sorted(range(len(depth)), key=lambda k: -depth[k][1])             # stable: ties keep dict order
         rank = {depth[k][0]: n for n, k in enumerate(order)}
         for allele, names in nt:                                                   # a later allele overwrites: last one wins
-            c = {0: 2, 1: 1}.get(rank[allele], 3)
+            c = {0: 2, 1: 1}.get(rank.get(allele), 3)          # absent from depth: 'other' too (defaultdict(int), :33-38)
             for r in names:
                 cls[s, reads[r]] = c
     typ = np.array([{'mismatch': 0, 'snp': 1, 'het_snp': 2}[s[1]] for s in sites], np.uint8)
