@@ -1065,9 +1065,23 @@ static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* 
         // shards are balanced by cost, not by row count: leave a third of slack on the estimate
         k = (int)std::ceil(1.35 * rows_work / room);
     }
-    if (want_p && pl.n_examined >= 0xFFFFFFFFull)
+    if (want_p && pl.n_examined >= 0xFFFFFFFFull) {
+        // the permutation kernels carry row numbers in 32 bits: every shard must examine fewer than 2^32 pairs.  Shards are
+        // balanced by COST (with p-values mostly the larger-than-2x2 rows), so their row counts can be far from even: the
+        // shards' plans are built (host only) and the count raised until every one of them fits.
         k = std::max<int>(k, (int)(pl.n_examined / 0xC0000000ull) + 1);
-    (void)db;
+        int ck; uint32_t xg;
+        plan_env(&ck, &xg);
+        for (; k < 1024; k += std::max(1, k / 4)) {
+            bool fits = true;
+            for (int r = 0; r < k && fits; ++r) {
+                Plan sp;
+                build_plan(plan_input(db), prm->het_only != 0, (uint32_t)r, (uint32_t)k, ck, xg, prm->n_shuffles, sp);
+                fits = sp.n_examined < 0xFFFFFFF0ull;
+            }
+            if (fits) break;
+        }
+    }
     return std::min(std::max(k, 1), 1024);
 }
 

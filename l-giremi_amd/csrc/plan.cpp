@@ -30,11 +30,12 @@ struct NeedMap {                       // which (x tile, y tile) of a block this
 
 }  // namespace
 
-// Cost of a pair in units of one pair-word of the count kernel, from the north-star stage times: count
-// 97 ms for 4.5e8 pairs x 3,125 words; emit + the 2 x 2 permutation path 85 ms for 4.5e8 pairs (22 ms without
-// p-values); 303 ms for 1.74e10 table draws of the pairs whose table is larger than 2 x 2 — approximated here by
-// "one of the two sites has a third class" (the tri flag).
-static const uint64_t COST_PAIR = 2750, COST_PAIR_NO_P = 700, COST_DRAW = 250;
+// Cost of a pair in units of one pair-word of the count kernel, from the north-star stage times:
+// count 95 ms for 4.5e8 pairs x 3,125 words; emit + the 2 x 2 permutation path 63 ms for 4.5e8 pairs (15 ms without
+// p-values); a pair whose table is larger than 2 x 2 — approximated here by "one of the two sites has a third class" (the
+// tri flag) — costs n_shuffles table draws (212 ms for 1.74e10 of them) or, from ~200 shuffles on, the perimeter walk of
+// the six-cell path whatever the shuffle count (k_perm_six + what it leaves to k_perm_general: 61 ms for 1.74e7 rows).
+static const uint64_t COST_PAIR = 2000, COST_PAIR_NO_P = 500, COST_DRAW = 180, COST_SIX = 50000;
 
 void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_t shard_world, int count_kernel,
                 uint32_t xg_override, uint32_t n_shuffles, Plan& pl)
@@ -111,7 +112,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                     else n_general = trix_pre[nxs] - trix_pre[pl.smap[s].xnext];
                 }
                 item_ncand.push_back(n_in_seg);
-                item_cost.push_back((uint64_t)n_in_seg * pair_cost + n_general * n_shuffles * COST_DRAW);
+                item_cost.push_back((uint64_t)n_in_seg * pair_cost + n_general * std::min<uint64_t>((uint64_t)n_shuffles * COST_DRAW, COST_SIX));
                 item_block.push_back((uint32_t)b);
             }
         }

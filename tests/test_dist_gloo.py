@@ -153,6 +153,57 @@ def test_socket_group_three_ranks():
     assert outs[0]['tab'] == [0, 1, 2, 10, 11, 12, 20, 21, 22] and outs[1]['tab'] is None
 
 
+def _eight_worker(rank, world, port, q):
+    """what the driver's 8-GPU launch does on the host side, without a GPU: the torch-free rendezvous with 8 ranks, every
+    rank planning ITS shard of one shared block with the C ABI's host-only planner, "computing" its rows (the oracle's rows
+    of the whole block that fall in its items) and the rows gathered in rank order onto rank 0"""
+    import lgmi
+    from lgmi.dist import SocketGroup, exchange_unique_id, gather_tables_host
+    from oracle import c_oracle
+    from test_shard_plan import item_of_rows
+    from util_synth import pack_class_matrix, random_block
+    g = SocketGroup(rank, world, '127.0.0.1', port, timeout=120.0)
+    uid = exchange_unique_id(g, (lambda: bytes(range(128))) if rank == 0 else None)
+    rng = np.random.Generator(np.random.PCG64(808))
+    pb = pack_class_matrix([random_block(rng, 400, 700, tri_frac=0.2, het_frac=0.3)])        # same block on every rank
+    ora = c_oracle.run(pb, min_common=5, het_only=True)
+    plan = lgmi.plan_shard(pb, True, (rank, world), n_shuffles=1000)
+    items = item_of_rows(pb, plan, ora['row_i'], ora['row_j'])
+    mine = (items >= plan['item_begin']) & (items < plan['item_end'])
+    got = gather_tables_host(g, {'row_i': ora['row_i'][mine], 'row_j': ora['row_j'][mine], 'row_mi': ora['row_mi'][mine],
+                                 'rank': np.full(int(mine.sum()), rank, np.uint32)}, root=0)
+    q.put({'rank': rank, 'uid_ok': uid == bytes(range(128)), 'n_mine': int(mine.sum()), 'n_examined': plan['n_examined'],
+           'n_examined_total': plan['n_examined_total'], 'items': (int(plan['item_begin']), int(plan['item_end'])),
+           'same': None if got is None else bool((got['row_i'] == ora['row_i']).all() and (got['row_j'] == ora['row_j']).all()
+                                                 and (got['row_mi'] == ora['row_mi']).all()
+                                                 and (np.diff(got['rank'].astype(int)) >= 0).all()),
+           'n_total': len(ora['row_i'])})
+    g.barrier()
+    g.close()
+
+
+def test_eight_ranks_share_one_block():
+    """world = 8, the size the driver's scaling run uses (a GPU box admits 6 processes on its card, so the 8-rank case of the
+    wire logic runs here on the CPU; tests/test_gpu_gather2.py carries 2, 3 and 6 ranks through the device code)"""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o['rank'])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(o['uid_ok'] for o in outs)
+    assert outs[0]['same'] is True and all(o['same'] is None for o in outs[1:])
+    assert sum(o['n_mine'] for o in outs) == outs[0]['n_total'] and all(o['n_mine'] > 0 for o in outs)
+    assert sum(o['n_examined'] for o in outs) == outs[0]['n_examined_total']
+    assert [o['items'][0] for o in outs[1:]] == [o['items'][1] for o in outs[:-1]]          # contiguous, in rank order
+    assert max(o['n_examined'] for o in outs) <= 2.5 * outs[0]['n_examined_total'] / world   # cost-balanced, not row-balanced
+
+
 def test_rendezvous_under_torch_distributed_run(tmp_path):
     """exactly how the driver launches bench.py --gpus N: torchrun's agent owns MASTER_PORT, so the ranks meet on
     an ephemeral port published through a file; the workers never import torch"""
