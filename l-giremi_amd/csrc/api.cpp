@@ -364,8 +364,11 @@ extern "C" int lgmi_ctx_synchronize(lgmi_ctx* ctx) {
 // ---------------------------------------------------------------- upload
 static void free_dbatch_device(lgmi_dbatch* db) {
     if (!db) return;
-    (void)hipFree(db->d.d_pos); (void)hipFree(db->d.d_type); (void)hipFree(db->d.d_tri);
-    (void)hipFree(db->d.d_cols); (void)hipFree(db->d.d_cplanes);
+    // (from the context's grow-only pool since round 4: a host that uploads batch after batch — one per chunk of footprints —
+    //  paid seven hipMalloc and as many hipFree, each a device synchronisation, per upload)
+    Pool& pool = db->ctx->pool;
+    pool.release(db->d.d_pos); pool.release(db->d.d_type); pool.release(db->d.d_tri);
+    pool.release(db->d.d_cols); pool.release(db->d.d_cplanes);
     db->d = DevBatch();
 }
 
@@ -413,10 +416,11 @@ static int validate_batch(const lgmi_batch* b) {
 }
 
 template <class T>
-static int dev_copy_new(T** dptr, const T* h, size_t n, hipStream_t st) {
+static int dev_copy_new(Pool& pool, T** dptr, const T* h, size_t n, hipStream_t st) {
     *dptr = nullptr;
     if (!n) return LGMI_OK;
-    HIPCHK(hipMalloc((void**)dptr, n * sizeof(T)));
+    int rc = pool.alloc((void**)dptr, n * sizeof(T));
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice, st));
     return LGMI_OK;
 }
@@ -427,8 +431,10 @@ static int dev_copy_new(T** dptr, const T* h, size_t n, hipStream_t st) {
 extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch** out) {
     if (!ctx || !out) return fail(LGMI_E_ARG, "ctx/out is NULL");
     *out = nullptr;
+    HostTrace tr;
     int rc = validate_batch(b);
     if (rc) return rc;
+    tr.mark("upload:validated");
     HIPCHK(hipSetDevice(ctx->device));
     lgmi_dbatch* db = new lgmi_dbatch();
     db->ctx = ctx;
@@ -445,48 +451,73 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
 
     hipStream_t st = ctx->stream;
     uint64_t* d_planes = nullptr; uint64_t* d_poff = nullptr; uint32_t* d_nw = nullptr; uint32_t* d_pseudo = nullptr;
-    struct Tmp { uint64_t** a; uint64_t** b; uint32_t** c; uint32_t** d;
-                 ~Tmp() { (void)hipFree(*a); (void)hipFree(*b); (void)hipFree(*c); (void)hipFree(*d); } } tmp{&d_planes, &d_poff, &d_nw, &d_pseudo};
-    if ((rc = dev_copy_new(&d_planes, b->planes, b->n_plane_words, st))) return rc;
-    if ((rc = dev_copy_new(&d_poff, b->site_plane_off, ns, st))) return rc;
-    if ((rc = dev_copy_new(&d_nw, b->site_n_words, ns, st))) return rc;
-    if ((rc = dev_copy_new(&db->d.d_pos, b->site_pos, ns, st))) return rc;
-    if ((rc = dev_copy_new(&db->d.d_type, b->site_type, ns, st))) return rc;
+    Pool& pool = ctx->pool;
+    struct Tmp { Pool& p; hipStream_t st; uint64_t** a; uint64_t** b; uint32_t** c; uint32_t** d;     // (released once the stream is past them)
+                 ~Tmp() { (void)hipStreamSynchronize(st); p.release(*a); p.release(*b); p.release(*c); p.release(*d); } } tmp{pool, st, &d_planes, &d_poff, &d_nw, &d_pseudo};
+    if ((rc = dev_copy_new(ctx->pool, &d_planes, b->planes, b->n_plane_words, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &d_poff, b->site_plane_off, ns, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &d_nw, b->site_n_words, ns, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &db->d.d_pos, b->site_pos, ns, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &db->d.d_type, b->site_type, ns, st))) return rc;
+    tr.mark("copies_enqueued");
     db->tri.assign(ns, 0);
     if (ns) {
-        HIPCHK(hipMalloc((void**)&db->d.d_tri, ns));
+        if ((rc = pool.alloc((void**)&db->d.d_tri, ns))) return rc;
         HIPCHK(hipMemsetAsync(db->d.d_tri, 0, ns, st));
         launch_tri_flags(st, (uint32_t)ns, d_nw, d_poff, d_planes, db->d.d_tri);
         HIPCHK(hipMemcpyAsync(db->tri.data(), db->d.d_tri, ns, hipMemcpyDeviceToHost, st));
         HIPCHK(wait_stream(st));
     }
-    // column table: real sites, then one pseudo column per tri site
+    tr.mark("tri_flags");
+    // column table: real sites, then one pseudo column per tri site.  On several threads over site ranges (a prefix over
+    // the ranges gives each its offsets): 1.1 M sites of 20,000 footprints were 4 - 7 ms of a one-shot call on one thread
     db->pseudo_of_site.assign(ns, NONE);
     uint64_t off = 0;
-    db->cols.resize(ns);
-    for (uint64_t s = 0; s < ns; ++s) {
-        db->cols[s] = Col{off, b->site_word_off[s], b->site_n_words[s]};
-        off += b->site_n_words[s];
-    }
-    for (uint64_t s = 0; s < ns; ++s) {
-        if (db->tri[s]) {
-            db->pseudo_of_site[s] = (uint32_t)(ns + db->pseudo_site.size());
-            db->pseudo_site.push_back((uint32_t)s);
-            db->cols.push_back(Col{off, b->site_word_off[s], b->site_n_words[s]});
-            off += b->site_n_words[s];
-        }
+    {
+        const unsigned T = plan_threads(ns / 64);
+        Team team(T);
+        std::vector<uint64_t> w_real(T + 1, 0), w_tri(T + 1, 0), n_tri(T + 1, 0);
+        db->cols.resize(ns);
+        team.run([&](unsigned t) {
+            const uint64_t s0 = ns * t / T, s1 = ns * (t + 1) / T;
+            uint64_t wr = 0, wt = 0, nt = 0;
+            for (uint64_t s = s0; s < s1; ++s) { wr += b->site_n_words[s]; if (db->tri[s]) { wt += b->site_n_words[s]; ++nt; } }
+            w_real[t + 1] = wr; w_tri[t + 1] = wt; n_tri[t + 1] = nt;
+            team.barrier();
+            if (t == 0) {
+                for (unsigned k = 0; k < T; ++k) { w_real[k + 1] += w_real[k]; w_tri[k + 1] += w_tri[k]; n_tri[k + 1] += n_tri[k]; }
+                db->pseudo_site.resize(n_tri[T]);
+                db->cols.resize(ns + n_tri[T]);
+            }
+            team.barrier();
+            uint64_t o = w_real[t], op = w_real[T] + w_tri[t], np = n_tri[t];
+            for (uint64_t s = s0; s < s1; ++s) {
+                db->cols[s] = Col{o, b->site_word_off[s], b->site_n_words[s]};
+                o += b->site_n_words[s];
+                if (db->tri[s]) {
+                    db->pseudo_of_site[s] = (uint32_t)(ns + np);
+                    db->pseudo_site[np] = (uint32_t)s;
+                    db->cols[ns + np] = Col{op, b->site_word_off[s], b->site_n_words[s]};
+                    op += b->site_n_words[s];
+                    ++np;
+                }
+            }
+        });
+        off = w_real[T] + w_tri[T];
     }
     if (db->cols.size() >= 0xFFFFFFF0ull) return fail(LGMI_E_ARG, "too many columns");
     db->d.n_cols = db->cols.size();
     db->d.n_pairs16 = off;
-    if ((rc = dev_copy_new(&db->d.d_cols, db->cols.data(), db->cols.size(), st))) return rc;
-    if ((rc = dev_copy_new(&d_pseudo, db->pseudo_site.data(), db->pseudo_site.size(), st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &db->d.d_cols, db->cols.data(), db->cols.size(), st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &d_pseudo, db->pseudo_site.data(), db->pseudo_site.size(), st))) return rc;
     // one all-zero entry after the last column: k_count_mfma reads it for words outside a column's band
-    HIPCHK(hipMalloc((void**)&db->d.d_cplanes, (off + 1) * sizeof(ulonglong2)));
+    if ((rc = pool.alloc((void**)&db->d.d_cplanes, (off + 1) * sizeof(ulonglong2)))) return rc;
     HIPCHK(hipMemsetAsync(db->d.d_cplanes + off, 0, sizeof(ulonglong2), st));
+    tr.mark("cols");
     launch_prep_cols(st, (uint32_t)db->d.n_cols, (uint32_t)ns, db->d.d_cols, d_pseudo, d_poff, d_planes, db->d.d_cplanes);
     HIPCHK(hipGetLastError());
     HIPCHK(wait_stream(st));
+    tr.mark("prep_done");
     guard.p = nullptr;
     *out = db;
     return LGMI_OK;
@@ -540,17 +571,18 @@ extern "C" int lgmi_synth_dense(lgmi_ctx* ctx, const lgmi_synth_spec* sp, lgmi_d
     db->d.n_pairs16 = (uint64_t)db->cols.size() * W;
     hipStream_t st = ctx->stream;
     int rc;
-    if ((rc = dev_copy_new(&db->d.d_pos, db->pos.data(), ns, st))) return rc;
-    if ((rc = dev_copy_new(&db->d.d_type, db->type.data(), ns, st))) return rc;
-    if ((rc = dev_copy_new(&db->d.d_tri, db->tri.data(), ns, st))) return rc;
-    if ((rc = dev_copy_new(&db->d.d_cols, db->cols.data(), db->cols.size(), st))) return rc;
-    HIPCHK(hipMalloc((void**)&db->d.d_cplanes, (db->d.n_pairs16 + 1) * sizeof(ulonglong2)));
+    if ((rc = dev_copy_new(ctx->pool, &db->d.d_pos, db->pos.data(), ns, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &db->d.d_type, db->type.data(), ns, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &db->d.d_tri, db->tri.data(), ns, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &db->d.d_cols, db->cols.data(), db->cols.size(), st))) return rc;
+    if ((rc = ctx->pool.alloc((void**)&db->d.d_cplanes, (db->d.n_pairs16 + 1) * sizeof(ulonglong2)))) return rc;
     HIPCHK(hipMemsetAsync(db->d.d_cplanes + db->d.n_pairs16, 0, sizeof(ulonglong2), st));
     uint32_t* d_depth = nullptr; uint32_t* d_pos_ = nullptr;
-    struct Tmp { uint32_t** a; uint32_t** b; ~Tmp() { (void)hipFree(*a); (void)hipFree(*b); } } tmp{&d_depth, &d_pos_};
-    HIPCHK(hipMalloc((void**)&d_depth, (size_t)ns * 3 * sizeof(uint32_t)));
+    struct Tmp { Pool& p; hipStream_t st; uint32_t** a; uint32_t** b;
+                 ~Tmp() { (void)hipStreamSynchronize(st); p.release(*a); p.release(*b); } } tmp{ctx->pool, st, &d_depth, &d_pos_};
+    if ((rc = ctx->pool.alloc((void**)&d_depth, (size_t)ns * 3 * sizeof(uint32_t)))) return rc;
     HIPCHK(hipMemsetAsync(d_depth, 0, (size_t)ns * 3 * sizeof(uint32_t), st));
-    if ((rc = dev_copy_new(&d_pos_, db->pseudo_of_site.data(), ns, st))) return rc;
+    if ((rc = dev_copy_new(ctx->pool, &d_pos_, db->pseudo_of_site.data(), ns, st))) return rc;
     for (uint32_t c = 0; c < nb; ++c) {
         lgmi_synth_spec bs = *sp;
         bs.seed = sp->seed + c;
@@ -1306,9 +1338,11 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
                         lgmi_run_info* info) {
     if (!out) return fail(LGMI_E_ARG, "out is NULL");
     memset(out, 0, sizeof *out);
+    HostTrace tr;
     lgmi_dbatch* db = nullptr;
     int rc = lgmi_batch_upload(ctx, batch, &db);
     if (rc) return rc;
+    tr.mark("run:uploaded");
     lgmi_dresult* dr = nullptr;
     bool split = false;
     if (prm && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
@@ -1318,14 +1352,19 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
         const uint64_t bound = pl.n_examined;               // (before the shards' plans may evict this one)
         if (k > 1) { split = true; rc = run_device_split(ctx, db, prm, k, bound, &dr); }
     }
+    tr.mark("planned");
     if (!split) rc = run_device_impl(ctx, db, prm, &dr, true);
+    tr.mark("rows");
     if (!rc) {
         HostResult* h = new HostResult();
         h->pool = ctx->pinned;
         hipStream_t cs = ctx_comm_stream(ctx);
         rc = fetch_part(dr, h, out, cs, 1);                 // in flight under the permutation stage
+        tr.mark("fetch1_posted");
         if (!rc) rc = lgmi_dresult_permute(ctx, dr);
+        tr.mark("permuted");
         if (!rc) rc = fetch_part(dr, h, out, cs, 2);
+        tr.mark("fetch2_posted");
         if (!rc && hipStreamSynchronize(cs) != hipSuccess) rc = fail(LGMI_E_HIP, "hipStreamSynchronize failed in lgmi_run");
         if (rc) { (void)hipStreamSynchronize(cs); delete h; memset(out, 0, sizeof *out); }
         else {

@@ -10,6 +10,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace lgmi {
 
@@ -37,89 +38,163 @@ struct NeedMap {                       // which (x tile, y tile) of a block this
 // the six-cell path whatever the shuffle count (k_perm_six + what it leaves to k_perm_general: 61 ms for 1.74e7 rows).
 static const uint64_t COST_PAIR = 2000, COST_PAIR_NO_P = 500, COST_DRAW = 180, COST_SIX = 50000;
 
+// Blocks are independent of one another, so every per-block phase runs on several threads over contiguous block ranges
+// (what a thread produces is laid down at offsets from a prefix over the blocks, or concatenated in thread = block order:
+// the plan is the same whatever the thread count).  On 20,000 footprint-sized blocks the single-threaded planner was
+// 29 ms of a 60 ms one-shot call (round 3); batches of a few blocks stay on the calling thread.
+unsigned plan_threads(uint64_t n_blocks)
+{
+    static const unsigned cap = [] {
+        const char* e = getenv("LGMI_PLAN_THREADS");
+        const int v = e ? atoi(e) : 0;
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (unsigned)(v > 0 ? v : std::min<unsigned>(hw ? hw : 1u, 16u));
+    }();
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(cap, n_blocks / 256));
+}
 void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_t shard_world, int count_kernel,
                 uint32_t xg_override, uint32_t n_shuffles, Plan& pl)
 {
     if (shard_world == 0) { shard_world = 1; shard_rank = 0; }
     const bool sharded = shard_world > 1;
     if (count_kernel == 3) pl.mfma_fp4 = false;
-    const uint64_t ns = in.n_sites;
-    pl.smap.assign(ns, SiteMap{NONE, NONE, NONE, NONE, 0, 0});
-    pl.plans.resize(in.n_blocks);
+    const uint64_t ns = in.n_sites, nb = in.n_blocks;
+    const unsigned T = plan_threads(nb);
+    Team team(T);
+    pl.smap.resize(ns);                                  // (PodVec: not initialised here — every site is written in pass 1b)
+    pl.plans.resize(nb);
 
-    // ---- pass 1: slot-matrix layout of every block, the work items of the whole batch and their costs
-    std::vector<uint64_t> item_cost;                     // partners x words of the block
-    std::vector<uint32_t> item_block, item_ncand;
-    for (uint64_t b = 0; b < in.n_blocks; ++b) {
-        const uint32_t sb = (uint32_t)in.block_site_begin[b], se = (uint32_t)in.block_site_begin[b + 1];
-        const uint32_t P = se - sb;
-        BlockPlan bp{};
-        bp.slot_base = pl.total_slots;
-        bp.xl_off = (uint32_t)pl.xlist.size();
-        bp.yl_off = (uint32_t)pl.ylist.size();
-        bp.site_begin = sb;
-        bp.site_end = se;
-        // x list: x sites in position order, then pseudo rows of the tri x sites
-        uint32_t nxs = 0;
-        for (uint32_t s = sb; s < se; ++s) {
-            const bool in_x = !het_only || in.type[s] == LGMI_TYPE_HET_SNP;
-            if (in_x) { pl.smap[s].xrow = nxs++; pl.xlist.push_back(s); }
-            pl.smap[s].xnext = nxs;
-            pl.smap[s].block = (uint32_t)b;
-        }
-        uint32_t nx = nxs;
-        for (uint32_t s = sb; s < se; ++s)
-            if (pl.smap[s].xrow != NONE && in.tri[s]) { pl.smap[s].prow = nx++; pl.xlist.push_back(in.pseudo_of_site[s]); }
-        // y list: non-x sites, x sites (same order as the x list), pseudo cols of every tri site
-        uint32_t ny = 0;
-        for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow == NONE) { pl.smap[s].ycol = ny++; pl.ylist.push_back(s); }
-        for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow != NONE) { pl.smap[s].ycol = ny++; pl.ylist.push_back(s); }
-        for (uint32_t s = sb; s < se; ++s) if (in.tri[s]) { pl.smap[s].pcol = ny++; pl.ylist.push_back(in.pseudo_of_site[s]); }
-        bp.nx = nx; bp.ny = ny; bp.nxs = nxs;
-        bp.ny_pad = (ny + 3u) & ~3u;
-        if (nxs == 0 || P < 2) { bp.nx = 0; }
-        pl.total_slots += (uint64_t)bp.nx * bp.ny_pad;
-        pl.plans[b] = bp;
-        // examined pairs: pairs a wave of the emit kernel will look at
-        const uint64_t W = std::max<uint64_t>(1, ((uint64_t)in.block_n_reads[b] + 63u) / 64u);
-        const uint64_t pair_cost = W + (n_shuffles ? COST_PAIR : COST_PAIR_NO_P);
-        // tri sites among the first k sites of the block / among the first k x sites: how many of an item's partners
-        // bring the Monte-Carlo path with them
-        std::vector<uint32_t> tri_pre(P + 1, 0), trix_pre(nxs + 1, 0);
-        if (sharded && n_shuffles) {
-            uint32_t xr = 0;
-            for (uint32_t k = 0; k < P; ++k) {
-                const bool t = in.tri[sb + k] != 0;
-                tri_pre[k + 1] = tri_pre[k] + (t ? 1u : 0u);
-                if (pl.smap[sb + k].xrow != NONE) { trix_pre[xr + 1] = trix_pre[xr] + (t ? 1u : 0u); ++xr; }
+    // ---- pass 1a: sizes of every block's lists (x rows, y columns, work items)
+    std::vector<uint64_t> blk_items(nb + 1, 0), blk_x(nb + 1, 0), blk_y(nb + 1, 0), blk_slots(nb + 1, 0);
+    PodVec<uint64_t> item_cost;                           // partners x words of the block (+ the table draws)
+    PodVec<uint32_t> item_ncand;
+    std::vector<uint64_t> examined_part(T, 0);
+    std::vector<std::vector<uint2>> part_units(T);
+    std::vector<std::vector<Tile>> part_tiles(T), part_mtiles(T);
+    std::vector<uint8_t> part_fp4(T, 1);
+    uint64_t n_items = 0;
+    team.run([&](unsigned t) {
+    const uint64_t b0 = nb * t / T, b1 = nb * (t + 1) / T;
+    {
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint32_t sb = (uint32_t)in.block_site_begin[b], se = (uint32_t)in.block_site_begin[b + 1];
+            const uint32_t P = se - sb;
+            uint32_t nxs = 0, ntri = 0, ntrix = 0;
+            for (uint32_t s = sb; s < se; ++s) {
+                const bool in_x = !het_only || in.type[s] == LGMI_TYPE_HET_SNP;
+                nxs += in_x ? 1u : 0u;
+                if (in.tri[s]) { ++ntri; if (in_x) ++ntrix; }
             }
-        }
-        for (uint32_t s = sb; s < se; ++s) {
-            const bool is_x = pl.smap[s].xrow != NONE;
-            const uint32_t ncand = is_x ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
-            pl.n_examined_total += ncand;
-            // an x site's row is cut into segments of EMIT_SEG partners; another site's row (at most nxs partners: a
-            // column walk of the slot matrix, done four sites at a time, emit.hip: emit_quad) is one item
-            const uint32_t seg_len = is_x ? EMIT_SEG : 0xFFFFFFFFu;
-            for (uint32_t g = 0; (uint64_t)g * seg_len < ncand; ++g) {
-                pl.items.push_back(make_uint2(s, g));
-                const uint32_t q_a = is_x ? g * EMIT_SEG : 0u;
-                const uint32_t n_in_seg = std::min<uint32_t>(seg_len, ncand - q_a);
-                uint64_t n_general = 0;
-                if (sharded && n_shuffles) {
-                    if (in.tri[s]) n_general = n_in_seg;
-                    else if (is_x) n_general = tri_pre[s + 1 + q_a + n_in_seg - sb] - tri_pre[s + 1 + q_a - sb];
-                    else n_general = trix_pre[nxs] - trix_pre[pl.smap[s].xnext];
-                }
-                item_ncand.push_back(n_in_seg);
-                item_cost.push_back((uint64_t)n_in_seg * pair_cost + n_general * std::min<uint64_t>((uint64_t)n_shuffles * COST_DRAW, COST_SIX));
-                item_block.push_back((uint32_t)b);
+            BlockPlan bp{};
+            bp.site_begin = sb; bp.site_end = se;
+            bp.nxs = nxs; bp.nx = nxs + ntrix; bp.ny = P + ntri;
+            bp.ny_pad = (bp.ny + 3u) & ~3u;
+            blk_x[b + 1] = bp.nx; blk_y[b + 1] = bp.ny;
+            if (nxs == 0 || P < 2) bp.nx = 0;
+            blk_slots[b + 1] = (uint64_t)bp.nx * bp.ny_pad;
+            uint64_t n_it = 0;
+            uint32_t xseen = 0;
+            for (uint32_t s = sb; s < se; ++s) {
+                const bool is_x = !het_only || in.type[s] == LGMI_TYPE_HET_SNP;
+                if (is_x) ++xseen;
+                const uint32_t ncand = is_x ? (se - 1 - s) : (nxs - xseen);
+                if (is_x) n_it += ((uint64_t)ncand + EMIT_SEG - 1) / EMIT_SEG; else n_it += ncand ? 1u : 0u;
             }
+            blk_items[b + 1] = n_it;
+            pl.plans[b] = bp;
         }
     }
+    team.barrier();
+    if (t == 0) {
+    for (uint64_t b = 0; b < nb; ++b) {
+        blk_items[b + 1] += blk_items[b]; blk_x[b + 1] += blk_x[b]; blk_y[b + 1] += blk_y[b]; blk_slots[b + 1] += blk_slots[b];
+        pl.plans[b].slot_base = blk_slots[b];
+        pl.plans[b].xl_off = (uint32_t)blk_x[b];
+        pl.plans[b].yl_off = (uint32_t)blk_y[b];
+    }
+    pl.total_slots = blk_slots[nb];
+    pl.xlist.resize(blk_x[nb]);
+    pl.ylist.resize(blk_y[nb]);
+    n_items = blk_items[nb];
+    pl.items.resize(n_items);
+    item_cost.resize(sharded ? n_items : 0);
+    item_ncand.resize(n_items);
+    }
+    team.barrier();
+
+    // ---- pass 1b: slot-matrix layout of every block, the work items of the whole batch and their costs
+    {
+        std::vector<uint32_t> tri_pre, trix_pre;
+        uint64_t examined = 0;
+        for (uint64_t b = b0; b < b1; ++b) {
+            const BlockPlan& bp = pl.plans[b];
+            const uint32_t sb = bp.site_begin, se = bp.site_end, P = se - sb;
+            uint32_t* const xl = pl.xlist.data() + bp.xl_off;
+            uint32_t* const yl = pl.ylist.data() + bp.yl_off;
+            for (uint32_t s = sb; s < se; ++s) pl.smap[s] = SiteMap{NONE, NONE, NONE, NONE, 0, 0};
+            // x list: x sites in position order, then pseudo rows of the tri x sites
+            uint32_t nxs = 0;
+            for (uint32_t s = sb; s < se; ++s) {
+                const bool in_x = !het_only || in.type[s] == LGMI_TYPE_HET_SNP;
+                if (in_x) { pl.smap[s].xrow = nxs; xl[nxs++] = s; }
+                pl.smap[s].xnext = nxs;
+                pl.smap[s].block = (uint32_t)b;
+            }
+            uint32_t nx = nxs;
+            for (uint32_t s = sb; s < se; ++s)
+                if (pl.smap[s].xrow != NONE && in.tri[s]) { pl.smap[s].prow = nx; xl[nx++] = in.pseudo_of_site[s]; }
+            // y list: non-x sites, x sites (same order as the x list), pseudo cols of every tri site
+            uint32_t ny = 0;
+            for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow == NONE) { pl.smap[s].ycol = ny; yl[ny++] = s; }
+            for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow != NONE) { pl.smap[s].ycol = ny; yl[ny++] = s; }
+            for (uint32_t s = sb; s < se; ++s) if (in.tri[s]) { pl.smap[s].pcol = ny; yl[ny++] = in.pseudo_of_site[s]; }
+            // examined pairs: pairs a wave of the emit kernel will look at
+            const uint64_t W = std::max<uint64_t>(1, ((uint64_t)in.block_n_reads[b] + 63u) / 64u);
+            const uint64_t pair_cost = W + (n_shuffles ? COST_PAIR : COST_PAIR_NO_P);
+            // tri sites among the first k sites of the block / among the first k x sites: how many of an item's partners
+            // bring the larger-than-2x2 paths with them
+            if (sharded && n_shuffles) {
+                tri_pre.assign(P + 1, 0); trix_pre.assign(nxs + 1, 0);
+                uint32_t xr = 0;
+                for (uint32_t k = 0; k < P; ++k) {
+                    const bool tr = in.tri[sb + k] != 0;
+                    tri_pre[k + 1] = tri_pre[k] + (tr ? 1u : 0u);
+                    if (pl.smap[sb + k].xrow != NONE) { trix_pre[xr + 1] = trix_pre[xr] + (tr ? 1u : 0u); ++xr; }
+                }
+            }
+            uint64_t it = blk_items[b];
+            for (uint32_t s = sb; s < se; ++s) {
+                const bool is_x = pl.smap[s].xrow != NONE;
+                const uint32_t ncand = is_x ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
+                examined += ncand;
+                // an x site's row is cut into segments of EMIT_SEG partners; another site's row (at most nxs partners: a
+                // column walk of the slot matrix, done four sites at a time, emit.hip: emit_quad) is one item
+                const uint32_t seg_len = is_x ? EMIT_SEG : 0xFFFFFFFFu;
+                for (uint32_t g = 0; (uint64_t)g * seg_len < ncand; ++g) {
+                    pl.items[it] = make_uint2(s, g);
+                    const uint32_t q_a = is_x ? g * EMIT_SEG : 0u;
+                    const uint32_t n_in_seg = std::min<uint32_t>(seg_len, ncand - q_a);
+                    item_ncand[it] = n_in_seg;
+                    if (sharded) {
+                        uint64_t n_general = 0;
+                        if (n_shuffles) {
+                            if (in.tri[s]) n_general = n_in_seg;
+                            else if (is_x) n_general = tri_pre[s + 1 + q_a + n_in_seg - sb] - tri_pre[s + 1 + q_a - sb];
+                            else n_general = trix_pre[nxs] - trix_pre[pl.smap[s].xnext];
+                        }
+                        item_cost[it] = (uint64_t)n_in_seg * pair_cost + n_general * std::min<uint64_t>((uint64_t)n_shuffles * COST_DRAW, COST_SIX);
+                    }
+                    ++it;
+                }
+            }
+        }
+        examined_part[t] = examined;
+    }
+    team.barrier();
+    if (t == 0) {
+    for (uint64_t e : examined_part) pl.n_examined_total += e;
 
     // ---- the shard: a contiguous, cost-balanced range of the work items
-    const uint64_t n_items = pl.items.size();
     pl.item_begin = 0;
     pl.item_end = n_items;
     if (sharded) {
@@ -132,33 +207,41 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         pl.item_begin = k;
         while (k < n_items && run < hi) run += item_cost[k++];
         pl.item_end = (shard_rank + 1u == shard_world) ? n_items : k;
+        for (uint64_t q = pl.item_begin; q < pl.item_end; ++q) pl.n_examined += item_ncand[q];
+    } else {
+        pl.n_examined = pl.n_examined_total;
     }
-    for (uint64_t k = pl.item_begin; k < pl.item_end; ++k) pl.n_examined += item_ncand[k];
+    }
+    team.barrier();
     // emit work units over the shard's items (indices relative to item_begin): an x site's item alone, or up to four
-    // consecutive items of other sites whose slot-matrix columns share one aligned group of four (one 64-byte line)
-    for (uint64_t k = pl.item_begin; k < pl.item_end;) {
-        const SiteMap& m = pl.smap[pl.items[k].x];
-        if (m.xrow != NONE) { pl.units.push_back(make_uint2((uint32_t)(k - pl.item_begin), 1u)); ++k; continue; }
-        uint32_t n = 1;
-        while (n < 4u && k + n < pl.item_end) {
-            const SiteMap& m2 = pl.smap[pl.items[k + n].x];
-            if (m2.xrow != NONE || m2.block != m.block || (m2.ycol >> 2) != (m.ycol >> 2) || m2.ycol != m.ycol + n) break;
-            ++n;
+    // consecutive items of other sites whose slot-matrix columns share one aligned group of four (one 64-byte line).
+    // A unit never spans two blocks, so the blocks' units are made side by side and concatenated in block order.
+    {
+        {
+            const uint64_t a = std::max(blk_items[b0], pl.item_begin), e = std::min(blk_items[b1], pl.item_end);
+            std::vector<uint2>& u = part_units[t];
+            for (uint64_t k = a; k < e;) {
+                const SiteMap& m = pl.smap[pl.items[k].x];
+                if (m.xrow != NONE) { u.push_back(make_uint2((uint32_t)(k - pl.item_begin), 1u)); ++k; continue; }
+                uint32_t n = 1;
+                while (n < 4u && k + n < e) {
+                    const SiteMap& m2 = pl.smap[pl.items[k + n].x];
+                    if (m2.xrow != NONE || m2.block != m.block || (m2.ycol >> 2) != (m.ycol >> 2) || m2.ycol != m.ycol + n) break;
+                    ++n;
+                }
+                u.push_back(make_uint2((uint32_t)(k - pl.item_begin), n | (1u << 16)));
+                k += n;
+            }
         }
-        pl.units.push_back(make_uint2((uint32_t)(k - pl.item_begin), n | (1u << 16)));
-        k += n;
     }
 
     // ---- pass 2: count tiles, block by block; a sharded run keeps the tiles its items read from
     std::vector<uint32_t> xmin, xmax, ymin, ymax, xbefore, tribefore, trix_before;
     NeedMap need;
-    uint64_t item_cursor = 0;          // items are in block order: walk them once
-    for (uint64_t b = 0; b < in.n_blocks; ++b) {
+    for (uint64_t b = b0; b < b1; ++b) {
         const BlockPlan& bp = pl.plans[b];
         const uint32_t sb = bp.site_begin, se = bp.site_end, P = se - sb, nxs = bp.nxs;
-        uint64_t blk_item_begin = item_cursor;
-        while (item_cursor < n_items && item_block[item_cursor] == b) ++item_cursor;
-        const uint64_t blk_item_end = item_cursor;
+        const uint64_t blk_item_begin = blk_items[b], blk_item_end = blk_items[b + 1];
         if (bp.nx == 0) continue;
         const uint32_t y_xpart = P - nxs;
         // which count kernel: the matrix-core kernel pays off on blocks with many columns and many reads
@@ -169,9 +252,9 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         if (count_kernel == 1) use_mfma = false;
         if (count_kernel >= 2) use_mfma = true;
         if (in.block_n_reads[b] >= (1u << 26)) use_mfma = false;   // the int8 kernel's accumulators hold 64 * count in 32 bits
-        if (use_mfma && in.block_n_reads[b] >= (1u << 24)) pl.mfma_fp4 = false;
+        if (use_mfma && in.block_n_reads[b] >= (1u << 24)) part_fp4[t] = 0;
         const uint32_t edge = use_mfma ? 128u : (uint32_t)TILE;
-        std::vector<Tile>& out_tiles = use_mfma ? pl.mtiles : pl.tiles;
+        std::vector<Tile>& out_tiles = use_mfma ? part_mtiles[t] : part_tiles[t];
         const uint32_t ntx = (bp.nx + edge - 1) / edge, nty = (bp.ny + edge - 1) / edge;
 
         if (sharded) {
@@ -245,6 +328,18 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                 }
             }
         }
+    }
+    });
+    {
+        size_t tot = 0;
+        for (auto& u : part_units) tot += u.size();
+        pl.units.reserve(tot);
+        for (auto& u : part_units) pl.units.insert(pl.units.end(), u.begin(), u.end());
+    }
+    for (unsigned t = 0; t < T; ++t) {
+        pl.tiles.insert(pl.tiles.end(), part_tiles[t].begin(), part_tiles[t].end());
+        pl.mtiles.insert(pl.mtiles.end(), part_mtiles[t].begin(), part_mtiles[t].end());
+        if (!part_fp4[t]) pl.mfma_fp4 = false;
     }
     for (uint64_t s = 0; s < ns; ++s) pl.bytes_in += 16ull * in.cols[s].nw + 17ull;
 

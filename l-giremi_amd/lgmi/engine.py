@@ -38,14 +38,34 @@ class MIResult:
         return len(self.row_i)
 
 
-def _copy_result(res: _lib.Result, info: dict) -> MIResult:
+class _HostRows:
+    """owner of one lgmi_result: the library's (pinned) host arrays live until the last numpy view of them is gone"""
+
+    def __init__(self, lib, res):
+        self.lib, self.res = lib, res
+
+    def __del__(self):
+        try:
+            self.lib.lgmi_result_free(C.byref(self.res))
+        except Exception:
+            pass
+
+
+def _copy_result(res: _lib.Result, info: dict, owner: _HostRows = None) -> MIResult:
+    """owner given: the arrays are VIEWS of the library's host buffers (no copy: the rows of a batch of footprints are
+    hundreds of megabytes) that keep the owner — and with it the buffers — alive; else copies"""
     n, ns = int(res.n_rows), int(res.n_sites)
+    ctype = {np.uint32: C.c_uint32, np.float64: C.c_double}
 
     def a(ptr, count, dt, shape=None, present=True):
         if not present:
             return None
         if count == 0 or not ptr:
             out = np.zeros(count if not ptr and count else 0, dt)
+        elif owner is not None:
+            buf = (ctype[dt] * count).from_address(C.addressof(ptr.contents))
+            buf._owner = owner                       # array -> memoryview -> buf -> owner
+            out = np.frombuffer(buf, dtype=dt)
         else:
             out = np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
         return out.reshape(shape) if shape else out
@@ -140,10 +160,7 @@ class DeviceResult:
     def fetch(self) -> MIResult:
         res = _lib.Result()
         _lib.check(self.engine.lib.lgmi_dresult_fetch(self.handle, C.byref(res)))
-        try:
-            return _copy_result(res, self.info())
-        finally:
-            self.engine.lib.lgmi_result_free(C.byref(res))
+        return _copy_result(res, self.info(), _HostRows(self.engine.lib, res))
 
     def free(self):
         if self.handle and self.engine.handle and os.getpid() == self.engine.pid:
@@ -220,12 +237,9 @@ class Engine:
         st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p)
         res, info = _lib.Result(), _lib.RunInfo()
         _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
-        try:
-            d = info.as_dict()
-            d['has_p'], d['has_counts'] = n_shuffles > 0 or bool(exact_2x2), bool(emit_counts)
-            return _copy_result(res, d)
-        finally:
-            self.lib.lgmi_result_free(C.byref(res))
+        d = info.as_dict()
+        d['has_p'], d['has_counts'] = n_shuffles > 0 or bool(exact_2x2), bool(emit_counts)
+        return _copy_result(res, d, _HostRows(self.lib, res))       # views: freed with the last of them
 
     def run_raw(self, batch: PackedBatch, **kw) -> dict:
         """lgmi_run (upload + kernels + fetch into library-owned host memory) without copying the rows into
