@@ -80,7 +80,25 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
-def _write_removed(df, path, header=True):
+class _RemovedWriter:
+    """the removed-site table written part by part, in footprint order, while the run is still extracting later footprints
+    (regions_mismatch_analysis: removed_sink): the header with the first part, every further part appended — the bytes of
+    one _write_removed over the whole table"""
+
+    def __init__(self, path):
+        self.path, self.parts = path, 0
+
+    def __call__(self, df):
+        _write_removed(df, self.path, header=(self.parts == 0), append=(self.parts > 0))
+        self.parts += 1
+
+    def close(self):
+        if not self.parts:
+            import pandas as pd
+            _write_removed(pd.DataFrame({c: [] for c in ('chromosome', 'strand', 'pos', 'removed')}), self.path)
+
+
+def _write_removed(df, path, header=True, append=False):
     """the removed-site table (strings and one integer column, millions of rows: one per covered position of every
     footprint) as pandas' to_csv(sep='\t', index=False) writes it, byte for byte, through pyarrow's CSV writer when it is
     there: the strings go in as dictionary codes (3.3 s -> 1.1 s for 3.85 M rows)"""
@@ -92,8 +110,9 @@ def _write_removed(df, path, header=True):
     import numpy as np
     import pandas as pd
     cols = list(df.columns)
+    mode = 'a' if append else 'w'
     if pa is None or cols != ['chromosome', 'strand', 'pos', 'removed'] or df['pos'].dtype != np.int64 or len(df) == 0:
-        df.to_csv(path, sep='\t', index=False, header=header)
+        df.to_csv(path, sep='\t', index=False, header=header, mode=mode)
         return
     arrays = []
     for c in cols:
@@ -103,15 +122,15 @@ def _write_removed(df, path, header=True):
         if isinstance(df[c].dtype, pd.CategoricalDtype):
             codes, uniq = df[c].cat.codes.to_numpy(), list(df[c].cat.categories)
             if (codes < 0).any():                                          # a missing value: pandas writes an empty field
-                df.to_csv(path, sep='\t', index=False, header=header)
+                df.to_csv(path, sep='\t', index=False, header=header, mode=mode)
                 return
         else:
             codes, uniq = pd.factorize(df[c].to_numpy())
         if any(not isinstance(u, str) or any(ch in u for ch in '\t\n\r"') for u in uniq):
-            df.to_csv(path, sep='\t', index=False, header=header)     # something pandas would quote
+            df.to_csv(path, sep='\t', index=False, header=header, mode=mode)     # something pandas would quote
             return
         arrays.append(pa.DictionaryArray.from_arrays(pa.array(codes.astype(np.int32)), pa.array(list(uniq))).cast(pa.string()))
-    with open(path, 'wb') as f:
+    with open(path, 'ab' if append else 'wb') as f:
         if header:
             f.write(('\t'.join(cols) + '\n').encode())
         pc.write_csv(pa.Table.from_arrays(arrays, names=cols), f,
@@ -246,10 +265,13 @@ def main(argv=None):
         if group is not None:
             made[0].comm_init_group(group)
         return made[0]
+    # one rank: the removed-site table (one row per covered position: most of what a run writes) goes out part by part
+    # while later footprints are still being extracted
+    removed_writer = _RemovedWriter(args.output_prefix + '.removed.txt') if world == 1 else None
     df_sites, df_mi, df_removed = regions_mismatch_analysis(
         jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
         engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta), timing=timing,
-        group=group,
+        group=group, removed_sink=removed_writer,
         keep_non_spliced_read=args.keep_non_spliced_read,
         min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
         min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
@@ -279,7 +301,7 @@ def main(argv=None):
     else:
         strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
         df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
-        _write_removed(df_removed, args.output_prefix + '.removed.txt')
+        removed_writer.close()                           # (its parts were written as the run went)
     if args.mip_table:
         # script/giremi.py:415-429: mip = ECDF of the het-SNP rows' mean_mi (those that have one) at every row's mean_mi.
         # Several ranks: the ECDF needs every rank's het-SNP means — the site tables go to rank 0 through the socket group.

@@ -232,9 +232,10 @@ class Engine:
         _lib.check(self.lib.lgmi_ctx_synchronize(self.handle))
 
     def run(self, batch: PackedBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-            emit_counts=False, exact_2x2=False, shard=None, no_row_p=True) -> MIResult:
+            emit_counts=False, exact_2x2=False, shard=None, no_row_p=True, stream_site_base=0) -> MIResult:
         self._alive()
-        st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p)
+        st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p,
+                                                 stream_site_base)
         res, info = _lib.Result(), _lib.RunInfo()
         _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
         d = info.as_dict()

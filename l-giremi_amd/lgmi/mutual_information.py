@@ -66,7 +66,7 @@ def mean_mismatch_pair_mutual_info(mismatch_pair_mi, engine: Optional[Engine] = 
     return [[pos, float(mean[k])] for pos, k in index.items()]
 
 
-def _run_regions(regions, min_common_reads, n_shuffles, seed, engine, batch=None):
+def _run_regions(regions, min_common_reads, n_shuffles, seed, engine, batch=None, site_base=0):
     """pack every (footprint, strand) of `regions` as one batch and run it -> (batch, result) or (None, None);
     `batch`: the same blocks already packed (the extraction workers of a whole run pack their own footprints)"""
     blocks = []
@@ -79,7 +79,8 @@ def _run_regions(regions, min_common_reads, n_shuffles, seed, engine, batch=None
         batch = pack_blocks(blocks)
     elif batch.n_blocks != len(blocks):
         raise ValueError('pre-packed batch has %d blocks for %d (footprint, strand) pairs' % (batch.n_blocks, len(blocks)))
-    res = eng.run(batch, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True)
+    res = eng.run(batch, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True,
+                  stream_site_base=site_base)
     if batch.bad_sites.any():
         # the reference ranks the alleles of BOTH sites of every qualifying pair — het-involved or not — before the
         # het filter (mutual_information.py:25-32, mismatch.py:392-396): a site whose depth dict has < 2 alleles raises
@@ -138,16 +139,19 @@ def regions_pair_mi(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: O
     return out
 
 
-def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None, batch=None):
+def regions_pair_mi_table(regions, min_common_reads=5, n_shuffles=0, seed=0, engine: Optional[Engine] = None, batch=None,
+                          site_base=0):
     """The same launch, returned the way a whole run consumes it: ONE table of all regions' pair rows in the
     reference's order (script/giremi.py:381-394 concatenates the per-footprint frames of mismatch.py:407-418) built
     column by column from the result arrays — no Python object per row, which is what 10^7 rows of tens of
     thousands of footprints need — plus the per-region ``mean_mi`` dictionaries.
+    ``site_base``: the number of sites of the run that precede this batch (a run fed to the GPU chunk by chunk): added to
+    the site indices in the permutation draws' counters, so that the chunks draw what the one batch of all of them draws.
     -> (DataFrame[chromosome, strand, site1_pos, site1_type, site2_pos, site2_type, mi (, p_perm)], [mean_mi])"""
     import pandas as pd
     regions = list(regions)
     cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
-    batch, res = _run_regions(regions, min_common_reads, n_shuffles, seed, engine, batch)
+    batch, res = _run_regions(regions, min_common_reads, n_shuffles, seed, engine, batch, site_base)
     if batch is None or res.n_rows == 0:
         df = pd.DataFrame({c: [] for c in cols})
         if n_shuffles:

@@ -403,9 +403,32 @@ def _extract_chunk(job, sam=None, genome=None):
     return out
 
 
+def _removed_frame(staged, chrom_code, reason_code):
+    """the removed-site table of some footprints: one row per covered position — tens of millions in a run — with its three
+    string columns as categoricals from small-integer codes (values, order and what to_csv writes are those of plain
+    string columns)"""
+    g_chrom, g_strand, g_pos, g_reason = [], [], [], []
+    for chrom, _sites, (gone, reasons) in staged:
+        cc = chrom_code.setdefault(chrom, len(chrom_code))
+        remap = np.array([reason_code.setdefault(r, len(reason_code)) for r in reasons], np.int8)
+        for k, strand in enumerate('+-'):
+            pos, codes = gone[strand]
+            if len(pos):
+                g_chrom.append(np.full(len(pos), cc, np.int32))
+                g_strand.append(np.full(len(pos), k, np.int8))
+                g_pos.append(pos)
+                g_reason.append(remap[codes])
+    cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+    as_cat = lambda parts, dt, names: pd.Categorical.from_codes(cat(parts, dt), categories=list(names))
+    return pd.DataFrame({'chromosome': as_cat(g_chrom, np.int32, chrom_code), 'strand': as_cat(g_strand, np.int8, '+-'),
+                         'pos': cat(g_pos, np.int64), 'removed': as_cat(g_reason, np.int8, reason_code)},
+                        columns=['chromosome', 'strand', 'pos', 'removed'])
+
+
 def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
-                              concat=False, threads=1, reopen=None, timing=None, group=None, **filter_kwargs):
-    """``region_mismatch_analysis`` over many footprints with ONE GPU batch for all their MI blocks — the shape the
+                              concat=False, threads=1, reopen=None, timing=None, group=None, removed_sink=None,
+                              **filter_kwargs):
+    """``region_mismatch_analysis`` over many footprints with the MI blocks of many footprints per GPU batch — the shape the
     reference's per-chunk loop (src/giremi/script/giremi.py:32-88) takes when the MI step is a device call.
 
     ``footprints``: iterable of dicts with ``chromosome``, ``start``, ``end`` and optionally the per-footprint inputs
@@ -413,22 +436,70 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     parameters of ``region_mismatch_analysis``.  Returns a list of (df_sites, df_pairs, df_removed) in footprint order,
     or with ``concat=True`` the three frames concatenated the way script/giremi.py:79-88 concatenates them.
     ``threads`` > 1 with ``reopen`` (a picklable callable returning fresh ``(sam, genome)`` objects) runs the host-side
-    extraction in a process pool; ``engine`` may then be a callable that creates the engine AFTER the pool has finished."""
+    extraction in a process pool; ``engine`` may then be a callable: it is called once the workers are forked (a HIP
+    context does not survive fork()).  With ``concat`` on one rank the run is a PIPELINE (round 4): the chunks of
+    footprints come back from the pool in order, and while the workers extract the later ones the parent runs each
+    chunk's own batch on the GPU (``stream_site_base`` = the sites before it: pair for pair the permutation draws of the one
+    batch holding every footprint), builds its rows of the two site tables and hands its part of the removed-site table to
+    ``removed_sink`` (a callable taking a DataFrame; the returned df_removed is then empty)."""
     import time
     t0 = time.perf_counter()
     footprints = list(footprints)
     staged = None
     prepacked = None                        # the footprints' blocks already packed by the extraction workers
+    multi_rank = group is not None and group.get_world_size() > 1
     if threads and threads > 1 and len(footprints) > 1 and reopen is not None:
         # host-side site extraction is per footprint and shares nothing: the reference maps it over a process pool
         # (script/giremi.py:367-380, -t); so does this, with the MI step kept OUT of the workers — they return site
-        # dictionaries, the parent packs every footprint's blocks into one GPU batch.  Workers reopen the files
-        # (`reopen()` -> (sam, genome)); the pool must be done before the parent creates its HIP context (fork).
+        # dictionaries and their footprints' packed blocks.  Workers reopen the files (`reopen()` -> (sam, genome)); the
+        # parent creates its HIP context only after the workers exist (fork).
         import multiprocessing as mp
         chunk = max(1, -(-len(footprints) // (4 * threads)))
         jobs = [(reopen, footprints[k:k + chunk], filter_kwargs, bool(concat), bool(concat))
                 for k in range(0, len(footprints), chunk)]
         with mp.get_context('fork').Pool(threads) as pool:
+            if concat and not multi_rank:
+                parts = pool.imap(_extract_chunk, jobs)               # in job order, as they finish
+                if callable(engine) and not hasattr(engine, 'run'):
+                    engine = engine()
+                t_gpu = t_tab = 0.0
+                site_base, site_rows, pair_frames, removed_frames = 0, [], [], []
+                chrom_code, reason_code = {}, {}
+                for part, b in parts:
+                    t1 = time.perf_counter()
+                    kw = {'site_base': site_base} if site_base else {}
+                    df_c, means_c = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in part], min_common_reads,
+                                                          n_shuffles=n_shuffles, seed=seed, engine=engine, batch=b, **kw)
+                    site_base += len(b.site_pos) if b is not None else 0
+                    pair_frames.append(df_c)
+                    t2 = time.perf_counter()
+                    for (chrom, sites, _gone), mean_mi in zip(part, means_c):
+                        site_rows.extend(_site_rows(chrom, sites, mean_mi))
+                    gone_frame = _removed_frame(part, chrom_code if removed_sink is None else {}, reason_code if removed_sink is None else {})
+                    if removed_sink is not None:
+                        removed_sink(gone_frame)
+                    else:
+                        removed_frames.append(gone_frame)
+                    t_gpu += t2 - t1
+                    t_tab += time.perf_counter() - t2
+                if removed_sink is not None:
+                    df_removed = _removed_frame([], {}, {})
+                elif len(removed_frames) == 1:
+                    df_removed = removed_frames[0]
+                else:                                                  # (categories grew from chunk to chunk: the last frame's hold them all)
+                    from pandas.api.types import union_categoricals
+                    df_removed = pd.DataFrame({c: (union_categoricals([f[c] for f in removed_frames]) if c != 'pos'
+                                                   else np.concatenate([f[c].to_numpy() for f in removed_frames]))
+                                               for c in ('chromosome', 'strand', 'pos', 'removed')}) if removed_frames \
+                        else _removed_frame([], {}, {})
+                if timing is not None:
+                    timing['extract_s'] = time.perf_counter() - t0          # the pipeline's wall time: extraction with the
+                    timing['pack_gpu_table_s'] = t_gpu                       # parent's GPU and table work (listed beside it)
+                    timing['site_tables_s'] = t_tab                          # running underneath
+                    timing['pipelined'] = True
+                full = [f for f in pair_frames if len(f)] or pair_frames[:1]       # (an empty frame has no dtypes to give)
+                df_pairs = pd.concat(full, axis=0, ignore_index=True) if len(full) > 1 else full[0]
+                return pd.DataFrame.from_records(site_rows, columns=_SITE_COLS), df_pairs, df_removed
             parts = pool.map(_extract_chunk, jobs)
         if concat:
             from .pack import concat_batches
@@ -447,7 +518,7 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     if concat:
         # a whole run: the pair table column by column from the result arrays, the two site tables from one row list each
         # (a DataFrame per footprint and a concat of thousands of them was most of the host time on 2,000 footprints)
-        if group is not None and group.get_world_size() > 1:
+        if multi_rank:
             # several ranks, each with its own contiguous run of footprints: the pair rows are gathered over RCCL onto
             # rank 0 (df_pairs is None elsewhere); the two site tables stay per rank (the caller concatenates them)
             df_pairs, means = regions_pair_mi_table_dist([(sites, chrom) for chrom, sites, _gone in staged], group, engine,
@@ -459,28 +530,13 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
             timing['pack_gpu_table_s'] = time.perf_counter() - t0
             t0 = time.perf_counter()
         site_rows = []
-        # the removed table is one row per covered position of every footprint — tens of millions in a run: its three
-        # string columns are built as categoricals from small-integer codes (values, order and what to_csv writes are
-        # those of plain string columns)
-        chrom_code, reason_code = {}, {}
-        g_chrom, g_strand, g_pos, g_reason = [], [], [], []
-        for (chrom, sites, (gone, reasons)), mean_mi in zip(staged, means):
+        for (chrom, sites, _gone), mean_mi in zip(staged, means):
             site_rows.extend(_site_rows(chrom, sites, mean_mi))
-            cc = chrom_code.setdefault(chrom, len(chrom_code))
-            remap = np.array([reason_code.setdefault(r, len(reason_code)) for r in reasons], np.int8)
-            for k, strand in enumerate('+-'):
-                pos, codes = gone[strand]
-                if len(pos):
-                    g_chrom.append(np.full(len(pos), cc, np.int32))
-                    g_strand.append(np.full(len(pos), k, np.int8))
-                    g_pos.append(pos)
-                    g_reason.append(remap[codes])
-        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
-        as_cat = lambda parts, dt, names: pd.Categorical.from_codes(cat(parts, dt), categories=list(names))
-        out = (pd.DataFrame.from_records(site_rows, columns=_SITE_COLS), df_pairs,
-               pd.DataFrame({'chromosome': as_cat(g_chrom, np.int32, chrom_code), 'strand': as_cat(g_strand, np.int8, '+-'),
-                             'pos': cat(g_pos, np.int64), 'removed': as_cat(g_reason, np.int8, reason_code)},
-                            columns=['chromosome', 'strand', 'pos', 'removed']))
+        df_removed = _removed_frame(staged, {}, {})
+        if removed_sink is not None:
+            removed_sink(df_removed)
+            df_removed = _removed_frame([], {}, {})
+        out = (pd.DataFrame.from_records(site_rows, columns=_SITE_COLS), df_pairs, df_removed)
         if timing is not None:
             timing['site_tables_s'] = time.perf_counter() - t0
         return out

@@ -149,7 +149,7 @@ def test_cli_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
-    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None):
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None, site_base=0):
         blocks = oracle_blocks(regions, mc)
         cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
         return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),
@@ -224,7 +224,7 @@ def test_cli_cfg1_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
-    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None):
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None, site_base=0):
         blocks = oracle_blocks(regions, mc)
         cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
         return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),

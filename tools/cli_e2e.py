@@ -211,6 +211,19 @@ def main():
                     removed_rows=sum(1 for _ in open(prefix + '.removed.txt')) - 1)
         print(json.dumps(line))
         sys.stdout.flush()
+    if len(args.threads) > 1:
+        # the pipelined run (-t > 1: chunks through the GPU while later footprints are extracted) against the others and the
+        # serial one (-t 1): the output files byte for byte
+        import hashlib
+        sums = {}
+        for t in args.threads:
+            prefix = os.path.join(args.workdir, 'out_t%d' % t)
+            try:
+                sums[t] = [hashlib.sha256(open(prefix + ext, 'rb').read()).hexdigest()[:16] for ext in ('.mi.txt', '.removed.txt', '.strand.txt')]
+            except OSError:
+                sums[t] = None
+        print(json.dumps({'identical_across_threads': len({tuple(v) for v in sums.values() if v}) == 1 and all(sums.values()),
+                          'sha256_16': {str(k): v for k, v in sums.items()}}))
     if args.compare_python_sites and args.threads:
         import filecmp
         native = os.path.join(args.workdir, 'out_t%d' % args.threads[-1])
