@@ -862,6 +862,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if (!pcache->on_device) {
         Pool& pp = pool;
         int e = 0;
+        pcache->release(pool);       // (a run that failed between these allocations and the upload left pointers behind: advice r3)
         if (!e) e = pp.alloc((void**)&pcache->d_plans, std::max<size_t>(pl.plans.size(), 1) * sizeof(BlockPlan));
         if (!e) e = pp.alloc((void**)&pcache->d_xlist, std::max<size_t>(pl.xlist.size(), 1) * 4);
         if (!e) e = pp.alloc((void**)&pcache->d_items, std::max<size_t>(n_items, 1) * sizeof(uint2));
@@ -1195,6 +1196,8 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
 }
 
 extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out) {
+    // (the batch's plans live in ITS context's pool: nothing of it is planned, evicted or released through another one)
+    if (ctx && db && db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
     if (ctx && db && prm && out && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
         const Plan& pl = plan_for(ctx, db, prm->het_only != 0, 0, 1, prm->n_shuffles, nullptr)->pl;   // (the one the run itself uses)
         const int k = split_count(ctx, db, prm, pl);

@@ -1124,6 +1124,12 @@ static int ref_intervals_impl(lgio_bam* b, int tid, int threads, lgio_intervals*
                     const size_t take = std::min(need, n);
                     stream.insert(stream.end(), d, d + take);
                     d += take; n -= take;
+                    if (take == need && stream.size() >= 4) {
+                        // the size word may have been completed by this very piece: it is checked before it is believed
+                        // (a record size of 0 would otherwise satisfy the completion test with nothing behind the word)
+                        const uint32_t bs = le32(stream.data());
+                        if (bs < 32 || bs > (1u << 29)) return fail(LGIO_E_FORMAT, "implausible BAM record size %u", bs);
+                    }
                     if (take == need && stream.size() >= 4 && stream.size() == 4 + (size_t)le32(stream.data())) {
                         const int rc = one_record(stream.data() + 4, le32(stream.data()));
                         if (rc < 0) return rc;

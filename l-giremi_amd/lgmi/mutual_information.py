@@ -186,7 +186,11 @@ def regions_pair_mi_table_dist(regions, group, engine: Engine, min_common_reads=
     blocks = []
     for mm, _chrom in regions:
         blocks.extend(mm.get(s, {}) for s in ('+', '-'))
-    if batch is None or batch.n_blocks != len(blocks) or not blocks:
+    if batch is not None and blocks and batch.n_blocks != len(blocks):
+        # (as _run_regions: the workers that packed the batch have replaced the read lists by counts — repacking from `regions`
+        #  here would silently pack empty sites)
+        raise ValueError('pre-packed batch has %d blocks for %d (footprint, strand) pairs' % (batch.n_blocks, len(blocks)))
+    if batch is None or not blocks:
         batch = pack_blocks(blocks) if blocks else pack_blocks([{}])
     n_sites = len(batch.site_pos)
     counts = group.allgather(int(n_sites))
@@ -195,6 +199,12 @@ def regions_pair_mi_table_dist(regions, group, engine: Engine, min_common_reads=
     dr = engine.run_device(db, min_common=_min_common(min_common_reads), n_shuffles=n_shuffles, seed=seed, het_only=True,
                            stream_site_base=base)       # pair for pair the permutation draws of the one batch holding every footprint
     local = dr.fetch()                                   # per-site means of this rank's own footprints (small)
+    if blocks and batch.bad_sites.any():
+        # the single-rank path's parity check (_run_regions): a site with < 2 alleles in a qualifying pair is the reference's
+        # IndexError (mutual_information.py:25-32); every rank checks its own footprints
+        chk = engine.run(batch, min_common=_min_common(min_common_reads), het_only=False)
+        if chk.n_rows and (batch.bad_sites[chk.row_i].any() or batch.bad_sites[chk.row_j].any()):
+            raise IndexError('list index out of range')
     gathered, _begins = engine.comm_gather(dr, root=root, site_base=base, same_batch=False)
     meta = group.gather({'pos': batch.site_pos, 'types': list(batch.type_names),
                          'bsb': batch.block_site_begin.astype(np.int64), 'chroms': [c for _mm, c in regions]}, root)

@@ -207,3 +207,33 @@ def test_interval_scan_with_threads_equals_the_sequential_fetch(tmp_path, index)
         shutil.copy(str(tmp_path / 'p.bam') + '.bai', str(bad) + '.bai')
         with pytest.raises(ValueError):
             BamReader(str(bad)).intervals('chr1', threads=4)
+
+
+def test_a_record_size_completed_across_blocks_is_checked_before_it_is_believed(tmp_path):
+    """crafted input for the straddling-record path of lgio_bam_ref_intervals (advice r3): the 4-byte size word of a record
+    is split over two BGZF blocks and says 0 — the completion test `stream.size() == 4 + size` then holds with nothing
+    behind the word.  The reader must answer with a format error, not walk a record that is not there (tools/asan_io.sh
+    runs this under AddressSanitizer)."""
+    import gzip
+    from lgmi.io import _bgzf_block
+    w = BamWriter(str(tmp_path / 'ok.bam'), [('chr1', 100_000)], index=False)
+    for k in range(3):
+        w.write('chr1', 100 + 50 * k, 'r%d' % k, False, [(0, 40)], 'A' * 40, ':40')
+    w.close()
+    raw = gzip.decompress(open(tmp_path / 'ok.bam', 'rb').read())          # BGZF is a multi-member gzip file
+    l_text = struct.unpack_from('<i', raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from('<i', raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from('<i', raw, p)[0]
+        p += 4 + l_name + 4
+    first = p + 4 + struct.unpack_from('<i', raw, p)[0]                      # end of the first record
+    for size_word in (0, 7, 1 << 30):
+        body = raw[:first] + struct.pack('<I', size_word) + b'\0' * 64
+        cut = first + 2                                                       # the size word straddles the two blocks
+        bad = tmp_path / ('straddle_%d.bam' % size_word)
+        bad.write_bytes(_bgzf_block(body[:cut]) + _bgzf_block(body[cut:]) +
+                        bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000'))
+        with pytest.raises(ValueError):
+            BamReader(str(bad)).intervals('chr1', threads=2)

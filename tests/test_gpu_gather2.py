@@ -140,3 +140,27 @@ def test_cli_on_several_ranks_writes_the_reference_tables(fake_rccl, tmp_path, w
               '--skip_strand_correction', '--n_shuffles', '20', '--seed', '4'])
     import pandas as pd
     pd.testing.assert_frame_equal(pd.read_table(one + '.mi.txt'), pd.read_table(prefix + '.mi.txt'))
+
+
+def test_cli_mip_table_on_two_ranks_equals_the_single_process_file(fake_rccl, tmp_path):
+    """--mip_table with --gpus 2 (advice r3: the multi-rank gather of the site table — astype(str) and a float64 round trip
+    over the socket group — had no test): the mismatch table with mean_mi and mip that rank 0 writes is the file one process
+    writes, byte for byte, and so are the three --mi_calculation_only files"""
+    import filecmp
+    sys.path.insert(0, HERE)
+    from test_cli import regions_fixture, write_inputs
+    root = os.path.dirname(HERE)
+    bam, fa, vcf = write_inputs(tmp_path, regions_fixture())
+    two, one = str(tmp_path / 'two'), str(tmp_path / 'one')
+    common = ['-b', bam, '-c', 'chrA', 'chrB', '--genome_fasta', fa, '--snp_bcf', vcf, '--mi_calculation_only',
+              '--skip_strand_correction', '--mip_table', '--n_shuffles', '20', '--seed', '4']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), '-m', 'lgmi.cli', '-o', two, '--gpus', '2', '--device', '0'] + common
+    env = dict(os.environ, LGMI_RCCL_LIB=fake_rccl, LGMI_ALLOW_RCCL_STANDIN='1',
+               PYTHONPATH=os.path.join(root, 'l-giremi_amd') + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    from lgmi import cli
+    cli.main(['-o', one] + common)
+    for ext in ('.mismatch_mip.txt', '.mi.txt', '.removed.txt', '.strand.txt'):
+        assert filecmp.cmp(one + ext, two + ext, shallow=False), ext

@@ -1,5 +1,9 @@
 # footprint regime: k_perm_enum / k_perm_general times for several (shuffles, LGMI_PERM_ENUM_MAX): bash tools/exp_fp_enum.sh
 set -u
+# the footprint workload's batch is built by a pool of forked workers: build (and cache) it with a plain python call BEFORE
+# any rocprofv3 line — under --pmc the profiler's library has initialised the GPU before bench.py starts, and a fork after
+# that is what bench.py's own "before anything touches the GPU" rule forbids (advice r3)
+python3 -c "import sys; sys.path[:0]=['$PWD','$PWD/l-giremi_amd']; from lgmi.synth import footprint_blocks; footprint_blocks(20000, seed=20250810, cache_dir='/tmp')"
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
 for cfg in "1000 4096" "2048 8192" "2048 0" "1000 0" "64 4096"; do

@@ -11,7 +11,9 @@ rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum $K --kernel-tr
 cd $ROOT
 python3 - <<'P'
 import csv,glob,collections
-for tag in 'abcd':   # (a fifth pass with the TA_* counters never returned on this pool: dropped)
+for tag in 'abcd':   # (round 3 had a fifth pass with TA_* counters that never returned: no counter list, log or dispatch record of it
+                     #  was kept, so its cause cannot be established after the fact — profiles/README.md lists the TA block as
+                     #  NOT COLLECTED on this pool; the TCP_TA_* / TCP_*_TA_* counters of passes b and c cover the TA-TCP interface)
     for f in glob.glob('gpurun_out/pmc_perm_l1/%s/**/*counter_collection.csv'%tag, recursive=True):
         acc=collections.defaultdict(float)
         for r in csv.DictReader(open(f)):

@@ -5,6 +5,12 @@ set -eu
 R=${1:-r02}; WL=${2:-north_star_dense_50kx200k}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/prof_${R}_$WL
 rm -rf $OUT; mkdir -p $OUT $ROOT/profiles $ROOT/gpurun_out/profiles_$R
+if [ "$WL" = footprints_20k ]; then
+# the footprint workload's batch is built by a pool of forked workers: build (and cache) it with a plain python call BEFORE
+# any rocprofv3 line — under --pmc the profiler's library has initialised the GPU before bench.py starts, and a fork after
+# that is what bench.py's own "before anything touches the GPU" rule forbids (advice r3)
+python3 -c "import sys; sys.path[:0]=['$PWD','$PWD/l-giremi_amd']; from lgmi.synth import footprint_blocks; footprint_blocks(20000, seed=20250810, cache_dir='/tmp')"
+fi
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --workload $WL --no-cpu-baseline --no-host-to-host"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.json 2> $OUT/trace.log
