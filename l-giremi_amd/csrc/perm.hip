@@ -820,6 +820,10 @@ __device__ __forceinline__ int first_true32(int lo, int hi, int g, P pred) {
     }
     return r;
 }
+#ifndef LGMI_SIXABL
+#define LGMI_SIXABL 0     // timing-only ablations of k_perm_six (results wrong by construction; tools/abl_six.sh): 1 the maps' sums
+                          // and pmf values replaced by constants, 2 the boundary searches replaced by their first guess
+#endif
 // inside (klo, khi) of {stat22(h, x) < s} around kc: the two monotone boundaries, searched from a half-width guess
 __device__ __forceinline__ void inside22(TabG G, const HG22& h, uint32_t kc, long long s, int& klo, int& khi) {
     const long long d0 = s - stat22(G, h, kc);
@@ -830,14 +834,23 @@ __device__ __forceinline__ void inside22(TabG G, const HG22& h, uint32_t kc, lon
         hw = (int)__fsqrt_rn(2.0f * var * (float)d0 * 3.7252903e-09f);
     }
     const int lo = (int)h.kmin - 1, hi = (int)kc, refl = lo + hi;
-    klo = refl - first_true32(lo, hi, refl - ((int)kc - hw), [&](int j) { return stat22(G, h, (uint32_t)(refl - j)) >= s; });
-    khi = first_true32((int)kc + 1, (int)h.kmax + 1, (int)kc + 1 + hw, [&](int k) { return stat22(G, h, (uint32_t)k) >= s; });
+#if LGMI_SIXABL & 2
+    klo = (int)kc - hw < lo ? lo : (int)kc - hw; khi = (int)kc + 1 + hw > (int)h.kmax + 1 ? (int)h.kmax + 1 : (int)kc + 1 + hw; return;
+#endif
+    // (one Newton step on each guess before the search — two more probes to save the gallop's — was measured slower: 56.6
+    //  against 48.3 ms at north-star; the quadratic guess is within a value of the boundary as it is)
+    const int gl = (int)kc - hw, gr = (int)kc + 1 + hw;
+    klo = refl - first_true32(lo, hi, refl - gl, [&](int j) { return stat22(G, h, (uint32_t)(refl - j)) >= s; });
+    khi = first_true32((int)kc + 1, (int)h.kmax + 1, gr, [&](int k) { return stat22(G, h, (uint32_t)k) >= s; });
 }
 
 // walk_sum of the oracle: J = pmf22 along lo .. hi (0 outside the support): first = J(lo), last = J(hi), rest = sum over lo + 1 .. hi
 __device__ __forceinline__ void walk_sum(TabLF LF, const HG22& h, int lo, int hi, double& first, double& last, double& rest) {
     const int lo2 = lo > (int)h.kmin ? lo : (int)h.kmin, hi2 = hi < (int)h.kmax ? hi : (int)h.kmax;
     first = 0.0; last = 0.0; rest = 0.0;
+#if LGMI_SIXABL & 1
+    first = 1e-5; last = 1.1e-5; rest = 2e-5 * (double)(hi2 - lo2); return;
+#endif
     if (lo2 > hi2) return;
     uint32_t k = (uint32_t)lo2;
     const double term0 = pmf22(LF, h, k);
@@ -856,8 +869,9 @@ __device__ __forceinline__ void walk_sum(TabLF LF, const HG22& h, int lo, int hi
             P = fma(P, den, Nn);
             num -= sn; den += sd; sn -= 2.0; sd += 2.0;
         }
-        sum += term * P / Q;
-        term = term * Nn / Q;
+        const double rQ = 1.0 / Q;                       // (one division per sub-block; unit_mass, the 2 x 2 rows' specification, keeps its two)
+        sum += (term * P) * rQ;
+        term = (term * Nn) * rQ;
         k += m;
         rem -= m;
     }
@@ -879,7 +893,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
     const SixLists ls = six_lists(pa);
     unsigned long long box_max = ((unsigned long long)pa.six_pts * (unsigned long long)n_shuffles) >> 4;
     if (box_max > 4194304ull) box_max = 4194304ull;
-    __shared__ uint32_t s_pre[65];                          // sub-chunks of 16 chords before each of the wave's rows
     __shared__ unsigned long long s_acc[64];                // the rows' inside masses (2^-62, integer sums)
     unsigned int* const next_row = pa.gen_count + 5;
     uint32_t q_next = 0u;
@@ -975,30 +988,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 if (lane >= (uint32_t)o) incl += v;
             }
             __syncthreads();                                 // (one wave per workgroup) the previous round's reads are over
-            s_pre[lane] = incl - my_sc;
-            if (lane == 63u) s_pre[64] = incl;
             s_acc[lane] = 0ull;
             __syncthreads();
-            const uint32_t TS = s_pre[64];                   // wave-uniform
+            const uint32_t my_pre = incl - my_sc;            // sub-chunks before this lane's row
+            const uint32_t TS = bcast32(incl, 63);           // wave-uniform
             const uint32_t grp = lane >> 4, sub = lane & 15u;
             double M_it = 0.0;                               // carried from lane 63 of the previous trip
             int a_it = 0, b_it = 0;
             for (uint32_t sid0 = 0u; sid0 < TS; sid0 += 4u) {
                 const uint32_t sid = sid0 + grp;
                 const bool valid = sid < TS;
-                uint32_t lo = 0u, hi = 63u;                  // the row of sub-chunk sid: the largest slot with pre[slot] <= sid
-                if (valid) {
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi + 1u) >> 1;
-                        if (s_pre[mid] <= sid) lo = mid; else hi = mid - 1u;
-                    }
+                // the row of sub-chunk sid: the largest slot with pre[slot] <= sid — pre[] does not decrease along the lanes, so
+                // it is the number of lanes with pre <= sid, minus one: a ballot per group instead of a search in LDS
+                uint32_t rs_u = 0u, pre_rs = 0u;
+#pragma unroll
+                for (uint32_t g = 0; g < 4u; ++g) {
+                    const unsigned long long le = __ballot(my_pre <= sid0 + g);      // (lane 0 holds pre = 0: never empty)
+                    const uint32_t slot = (uint32_t)__popcll(le) - 1u;
+                    if (grp == g) rs_u = slot;
                 }
-                const int rs = (int)lo;
+                const int rs = (int)rs_u;
+                pre_rs = __shfl(my_pre, rs);
                 const uint32_t rAo = __shfl(Ao, rs), rAp = __shfl(Ap, rs), rAq = __shfl(Aq, rs), rB0 = __shfl(B0, rs), rnz = __shfl(nz, rs);
                 const int rzlo = __shfl(zlo, rs);
                 const long long rsobs = __shfl(sobs, rs);
                 const double rcJ = __shfl(cJ, rs), rrN = __shfl(rN, rs);
-                const uint32_t j = valid ? 16u * (sid - s_pre[rs]) + sub : 0u;
+                const uint32_t j = valid ? 16u * (sid - pre_rs) + sub : 0u;
                 const bool active = valid && j < rnz;
                 const uint32_t Np = rAp + rAq, K = rAp;
                 HG22 h = {Np, K, 0u, 0u, 0u, 0.0};
@@ -1062,6 +1077,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 }
                 M_it = carry;
                 a_it = (int)bcast32((uint32_t)a, 63); b_it = (int)bcast32((uint32_t)b, 63);
+                // (adding the sub-chunk's masses inside its 16 lanes first, one atomic per sub-chunk, was no faster: 48.8 against 48.3 ms)
                 if (active && M > 0.0)
                     atomicAdd(&s_acc[rs], M >= 1.0 ? 4611686018427387904ull : (unsigned long long)(M * 4611686018427387904.0));
             }

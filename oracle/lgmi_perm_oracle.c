@@ -960,8 +960,11 @@ static void walk_sum(const perm_tables* t, const hg22* h, int64_t lo, int64_t hi
             P = fma(P, den, Nn);
             a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
         }
-        sum += term * P / Q;
-        term = term * Nn / Q;
+        {
+            const double rQ = 1.0 / Q;
+            sum += (term * P) * rQ;
+            term = (term * Nn) * rQ;
+        }
         k += (uint32_t)m;
         rem -= m;
     }
