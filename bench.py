@@ -308,12 +308,21 @@ def main():
                 'step_wall_ms': [round(i.get('wall_ms', 0.0), 3) for i in infos],      # this rank's; `value` uses the max over ranks of the whole region
                 'stage_ms': {k: sum(i.get(k, 0.0) for i in infos) / len(infos)
                              for k in ('ms_total', 'ms_prep', 'ms_plan_host', 'ms_count', 'ms_emit', 'ms_perm', 'ms_perm_fast',
-                                       'ms_perm_general', 'ms_mean', 'ms_gather')},
+                                       'ms_perm_general', 'ms_perm_exact', 'ms_mean', 'ms_gather')},
                 'n_seq_shards': info.get('n_seq_shards', 1),   # > 1: lgmi_run_device split the run to fit its memory budget
             }
             if world > 1 or args.force_gather:
                 out['per_rank'] = per_rank
                 out['verify'] = verify if verify is not None else 'not run (no gather, or weak scaling)'
+            st_ = out['stage_ms']
+            ex_ = sum(i.get('ms_perm_exact', 0.0) for i in infos) / len(infos)
+            parts = {'count (k_count*)': st_['ms_count'], 'emit (k_emit<1>, scans, k_emit<2>)': st_['ms_emit'],
+                     'perm 2 x 2 (k_perm_fast)': st_['ms_perm_fast'], 'perm exact larger tables (k_perm_enum, k_perm_six)': ex_,
+                     'perm sampled tables (k_perm_general)': max(st_['ms_perm_general'] - ex_, 0.0), 'prep (k_gather_ops, plan upload)': st_['ms_prep']}
+            tot_ = st_['ms_total'] or 1.0
+            out['step_breakdown'] = [{'stage': k, 'ms': round(v, 3), 'share': round(v / tot_, 4)}
+                                     for k, v in sorted(parts.items(), key=lambda kv: -kv[1])]
+            out['dominant_stage'] = out['step_breakdown'][0]['stage']
             out['rates'] = {'emitted_pairs_per_s': rows_job * args.steps / elapsed,
                             'blocks_per_s': n_blocks * (world if not strong else 1) * args.steps / elapsed}
             # how full the count kernels' tiles are: pairs examined / pairs inside the tiles computed (small footprints
@@ -322,38 +331,41 @@ def main():
                                        'frac': info['n_examined'] / info['n_tile_pairs'] if info['n_tile_pairs'] else None,
                                        'ms_plan_host': sum(i['ms_plan_host'] for i in infos) / len(infos)}
             if n_shuffles:
-                # the permutation stage, priced on what it really draws: a 2 x 2 row costs ONE binomial
-                # variate against its exact tail mass; only the larger tables draw n_shuffles tables each.  VALU issue
-                # and lane occupancy come from the committed SQ counter pass of this workload.
+                # the permutation stage, priced on what it really does: a 2 x 2 row costs ONE binomial variate
+                # against its exact tail mass (k_perm_fast); a 3 x 2 / 2 x 3 row behind the gate likewise, its mass from the
+                # perimeter walk (k_perm_six; small tables by enumeration, k_perm_enum); only what is left draws n_shuffles
+                # tables each (k_perm_general).  Instruction counts, lane occupancy and the instruction-class account come
+                # from the committed counter passes of this workload.
                 sq = committed_profile('pmc_sq_perm').get(args.workload, {})
-                ms_gen = sum(i['ms_perm_general'] for i in infos) / len(infos)
-                ms_fast = sum(i['ms_perm_fast'] for i in infos) / len(infos)
-                draws = general_job * n_shuffles
-                pr = {'general_rows': general_job, 'two_by_two_rows': info['n_rows'] - general_job,
-                      'table_draws': draws, 'ms_general': ms_gen, 'ms_fast': ms_fast,
-                      'table_draws_per_s': draws / (ms_gen * 1e-3) if ms_gen > 0 else None,
+                cls = committed_profile('pmc_class').get(args.workload, {})
+                avg = lambda k: sum(i.get(k, 0.0) for i in infos) / len(infos)
+                ms_fast, ms_exact = avg('ms_perm_fast'), avg('ms_perm_exact')
+                ms_sampled = max(avg('ms_perm_general') - ms_exact, 0.0)
+                six_job = info.get('n_six_rows', 0)
+                sampled_rows = max(general_job - six_job, 0)            # (enumerated rows included: a footprint-regime detail)
+                draws = sampled_rows * n_shuffles
+                pr = {'two_by_two_rows': info['n_rows'] - general_job, 'larger_rows': general_job, 'six_cell_exact_rows': six_job,
+                      'sampled_or_enumerated_rows': sampled_rows, 'table_draws_upper': draws,
+                      'ms_fast': ms_fast, 'ms_exact': ms_exact, 'ms_sampled': ms_sampled,
                       'two_by_two_rows_per_s': (info['n_rows'] - general_job) / (ms_fast * 1e-3) if ms_fast > 0 else None,
-                      'bound': 'VALU issue for both kernels; k_perm_general was bound by the L1 (TCP) rate of scattered 8-byte '
-                               'look-ups until the per-row cache and the squeeze took 10 of its 15 look-ups per draw away '
-                               '(DESIGN.md §8 round 3)',
-                      'unit': 'wave64 VALU instructions/s', 'peak': VALU_WAVE_INSTR_PEAK,
+                      'six_cell_rows_per_s': six_job / (ms_exact * 1e-3) if ms_exact > 0 and six_job else None,
+                      'table_draws_per_s_lower': draws / (ms_sampled * 1e-3) if ms_sampled > 0 else None,
+                      'bound': 'vector-instruction issue at partial lane occupancy for k_perm_fast and k_perm_six (f64 recurrences, '
+                               'divergent boundary searches); what bounds each is the instruction-class account below, not a '
+                               '4-cycle-per-instruction figure',
+                      'unit': 'wave64 VALU instructions/s', 'peak_at_4_cycles': VALU_WAVE_INSTR_PEAK,
                       'counters': sq.get('_file') or committed_profile('pmc_sq_perm').get('_file'),
-                      'source': 'the counter-derived fields below come from the committed profile named in `counters` '
-                                '(separate rocprofv3 --pmc passes of this workload), NOT from this run; times and rates are this run\'s'}
-                l1 = committed_profile('pmc_perm_general_final')
-                if l1.get('derived') and args.workload == 'north_star_dense_50kx200k':
-                    dd = l1['derived']
-                    pr['k_perm_general_l1'] = {k: dd.get(k) for k in ('l1_accesses_per_table_draw', 'l1_accesses_per_cu_cycle', 'l1_miss_frac',
-                                                                      'l2_hit_frac', 'l1_tagconflict_stall_frac_of_gated_cycles',
-                                                                      'wave_valu_insts_per_table_draw', 'salu_insts_per_valu_inst')}
-                    pr['k_perm_general_l1']['source'] = 'committed profile %s (separate rocprofv3 --pmc passes), not this run' % l1.get('_file')
-                for k in ('k_perm_general', 'k_perm_fast'):
+                      'source': 'the counter-derived fields below come from the committed profiles named in `counters` / '
+                                '`class_account.file` (separate rocprofv3 --pmc passes of this workload), NOT from this run; '
+                                'times and rates are this run\'s'}
+                for k in ('k_perm_fast', 'k_perm_six', 'k_perm_general'):
                     c = sq.get(k)
                     if c and c.get('valu_insts') and c.get('ms'):
-                        pr[k] = {'valu_issue_frac': c['valu_insts'] / (c['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
-                                 'active_lane_frac': c.get('active_lanes', 0) / 64.0,
-                                 'valu_insts_per_table_draw' if k == 'k_perm_general' else 'valu_insts_per_row':
-                                     c['valu_insts'] * 64.0 / (c.get('units') or 1)}
+                        pr[k] = {'ms_profiled': c['ms'], 'wave_valu_insts': c['valu_insts'],
+                                 'valu_issue_frac_at_4_cycles': c['valu_insts'] / (c['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
+                                 'active_lane_frac': c.get('active_lanes', 0) / 64.0}
+                        if cls.get(k):
+                            pr[k]['class_account'] = dict(cls[k], file=committed_profile('pmc_class').get('_file'))
                 out['perm_roofline'] = pr
             # the ordered emission (validity count + scan + MI and row write): priced like the permutation kernels, on VALU
             # issue from the committed SQ counter pass — nine f64 logarithms per row are most of its instructions
@@ -393,6 +405,7 @@ def main():
                                            + ('v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands and unit scales, exact in f32 below 2^24 reads; '
                                               if fp4 else 'v_mfma_i32_32x32x32_i8; ')
                                            + 'weighted-bit operands made from the bit planes in registers (AND / shift-AND per operand dword)'}
+                out['roofline']['share_of_step'] = ms_count / out['stage_ms']['ms_total'] if out['stage_ms']['ms_total'] else None
                 out['hbm_roofline'] = hbm
             else:
                 out['roofline'] = hbm

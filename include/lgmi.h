@@ -183,6 +183,9 @@ typedef struct lgmi_run_info {
                                   launch sequence would not fit the memory budget (LGMI_MEM_BUDGET_MB, default 70 % of
                                   the device memory) or p-values were asked for 2^32 candidate rows or more; the
                                   stage times are sums over the shards.  0 / 1: one sequence                  */
+    float ms_perm_exact;       /* of ms_perm_general: k_perm_enum + k_perm_six, the larger-than-2x2 rows whose tail mass is exact
+                                  (enumeration; perimeter walk of 3 x 2 / 2 x 3 tables); the rest is k_perm_general's sampling    */
+    uint32_t reserved2;
 } lgmi_run_info;
 
 /* device-side synthetic chromosome generator (SURVEY 8d "dense" regime):

@@ -990,6 +990,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     HIPCHK(hipEventRecord(ctx->ev[6], st));
+    bool exact_timed = false;
     if (defer_perm && want_p) {
         // split run: the rows are final here; the permutation stage runs later on this result (lgmi_dresult_permute)
         if ((rc = pool.alloc((void**)&res->d_nrows, 8))) return rc;
@@ -1008,8 +1009,9 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         launch_perm_fast(st, pa);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[6], st));
-        launch_perm_general(st, pa);
+        launch_perm_general(st, pa, ctx->ev[7]);
         HIPCHK(hipGetLastError());
+        exact_timed = true;
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
     launch_site_mean(st, ns, d_sum, d_cnt, res->d_mean);
@@ -1055,6 +1057,8 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HIPCHK(hipEventElapsedTime(&inf.ms_perm, ctx->ev[3], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&inf.ms_perm_fast, ctx->ev[3], ctx->ev[6]));
     HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));
+    inf.ms_perm_exact = 0.f;
+    if (exact_timed) HIPCHK(hipEventElapsedTime(&inf.ms_perm_exact, ctx->ev[6], ctx->ev[7]));
     HIPCHK(hipEventElapsedTime(&inf.ms_mean, ctx->ev[4], ctx->ev[5]));
     HIPCHK(hipEventElapsedTime(&inf.ms_total, ctx->ev[0], ctx->ev[5]));
     if (!want_counts && res->d_counts && !res->perm_pending) { pool.release(res->d_counts); res->d_counts = nullptr; }
@@ -1173,7 +1177,7 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
         if (s == 0) tot = pi;
         else {
             tot.n_rows += pi.n_rows; tot.n_examined += pi.n_examined; tot.n_tile_pairs += pi.n_tile_pairs;
-            tot.word_pairs += pi.word_pairs; tot.bytes_out += pi.bytes_out; tot.n_general_rows += pi.n_general_rows; tot.n_six_rows += pi.n_six_rows;
+            tot.word_pairs += pi.word_pairs; tot.bytes_out += pi.bytes_out; tot.n_general_rows += pi.n_general_rows; tot.n_six_rows += pi.n_six_rows; tot.ms_perm_exact += pi.ms_perm_exact;
             tot.ms_total += pi.ms_total; tot.ms_prep += pi.ms_prep; tot.ms_count += pi.ms_count; tot.ms_emit += pi.ms_emit;
             tot.ms_perm += pi.ms_perm; tot.ms_mean += pi.ms_mean; tot.ms_plan_host += pi.ms_plan_host;
             tot.ms_perm_fast += pi.ms_perm_fast; tot.ms_perm_general += pi.ms_perm_general;
@@ -1236,7 +1240,7 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
         launch_perm_fast(st, pa);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[6], st));
-        launch_perm_general(st, pa);
+        launch_perm_general(st, pa, ctx->ev[7]);
         HIPCHK(hipGetLastError());
         ctx->h_scal[1] = 0; ctx->h_scal[4] = 0;
         HIPCHK(hipMemcpyAsync(&ctx->h_scal[1], d_gencount, 4, hipMemcpyDeviceToHost, st));
@@ -1251,6 +1255,8 @@ extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
     HIPCHK(hipEventElapsedTime(&inf.ms_perm, ctx->ev[3], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&inf.ms_perm_fast, ctx->ev[3], ctx->ev[6]));
     HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));
+    inf.ms_perm_exact = 0.f;
+    if (res->cap_rows) HIPCHK(hipEventElapsedTime(&inf.ms_perm_exact, ctx->ev[6], ctx->ev[7]));
     inf.ms_total += inf.ms_perm;
     res->perm_pending = false;
     if (!res->has_counts && res->d_counts) { pool.release(res->d_counts); res->d_counts = nullptr; }

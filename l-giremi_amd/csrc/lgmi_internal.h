@@ -174,7 +174,7 @@ struct PermArgs {
                                                    // [4] rows k_perm_six leaves (third list), [5] its next row, [6] rows it finished (all zero at launch)
 };
 void launch_perm_fast(hipStream_t st, const PermArgs& a);
-void launch_perm_general(hipStream_t st, const PermArgs& a);
+void launch_perm_general(hipStream_t st, const PermArgs& a, hipEvent_t after_exact = nullptr);   // k_perm_enum, k_perm_six, [event], k_perm_general
 void launch_selftest_log(hipStream_t st, uint64_t n, const double* x, double* out);
 void launch_selftest_le_exp(hipStream_t st, uint64_t n, const double* x2, const double* t, uint8_t* fast, uint8_t* det,
                             double* e_hw, double* e_det);

@@ -1835,9 +1835,9 @@ void launch_perm_fast(hipStream_t st, const PermArgs& a)
     hipLaunchKernelGGL(k_perm_fast, dim3((uint32_t)std::min<uint64_t>(chunks, 256ull * 32ull)), dim3(64), 0, st, b);
 }
 
-void launch_perm_general(hipStream_t st, const PermArgs& a)
+void launch_perm_general(hipStream_t st, const PermArgs& a, hipEvent_t after_exact)
 {
-    if (!a.max_rows || !a.n_shuffles) return;
+    if (!a.max_rows || !a.n_shuffles) { if (after_exact) (void)hipEventRecord(after_exact, st); return; }
     // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
     // take the queued rows from a shared counter
     // (LGMI_PERM_WPC: one-wave workgroups per CU, for occupancy experiments — tools/abl_perm.sh; 16 = four per SIMD)
@@ -1858,6 +1858,7 @@ void launch_perm_general(hipStream_t st, const PermArgs& a)
     b.six_pts = perm_six_pts();
     if (b.enum_max) hipLaunchKernelGGL(k_perm_enum, dim3(256 * 16), dim3(64), 0, st, b);
     if (b.six_pts) hipLaunchKernelGGL(k_perm_six, dim3(256 * 4 * LGMI_SIX_WPS), dim3(64), 0, st, b);
+    if (after_exact) (void)hipEventRecord(after_exact, st);      // enumeration + perimeter walk done: what follows is sampling
     hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, b);
 }
 

@@ -51,7 +51,7 @@ class RunInfo(C.Structure):
                 ('mfma_dtype', C.c_uint32), ('n_six_rows', C.c_uint32),
                 ('n_examined_total', C.c_uint64), ('n_general_rows', C.c_uint64),
                 ('ms_plan_host', C.c_float), ('ms_perm_fast', C.c_float), ('ms_perm_general', C.c_float),
-                ('n_seq_shards', C.c_uint32)]
+                ('n_seq_shards', C.c_uint32), ('ms_perm_exact', C.c_float), ('reserved2', C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith('reserved')}

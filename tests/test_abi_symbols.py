@@ -47,7 +47,7 @@ def test_abi_version_and_struct_sizes():
     assert C.sizeof(_lib.Batch) == 88
     assert C.sizeof(_lib.Params) == 32
     assert C.sizeof(_lib.Result) == 96
-    assert C.sizeof(_lib.RunInfo) == 120
+    assert C.sizeof(_lib.RunInfo) == 128
     assert C.sizeof(_lib.ShardPlan) == 152
     assert C.sizeof(_lib.GatherOpts) == 8
     assert C.sizeof(_lib.SynthSpec) == 48
