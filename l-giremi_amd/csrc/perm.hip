@@ -363,6 +363,8 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int 
     return ((unsigned long long)bcast32((uint32_t)(v >> 32), L) << 32) | bcast32((uint32_t)v, L);
 }
 
+// (no amdgpu_waves_per_eu here: pinned to 4 waves per SIMD the kernel took 53.7 ms, to 5 — it fits without spilling —
+//  51.1, left to the compiler 50.1: profiles/r04_perm_occupancy.txt)
 __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
 {
     const uint64_t n_rows = *pa.n_rows_dev;
@@ -880,7 +882,7 @@ __device__ __forceinline__ void walk_sum(TabLF LF, const HG22& h, int lo, int hi
 }
 
 #ifndef LGMI_SIX_WPS
-#define LGMI_SIX_WPS 4
+#define LGMI_SIX_WPS 5     // waves per SIMD the register budget is set for: 4 (108 VGPRs) 46.1 ms, 5 (96 + 10 spilled) 41.7, 6 (80 + 38) 44.2
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS, LGMI_SIX_WPS))) void k_perm_six(PermArgs pa)
 {
