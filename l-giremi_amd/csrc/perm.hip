@@ -34,26 +34,17 @@
 #include "philox.h"
 
 #ifndef LGMI_PABL
-#define LGMI_PABL 0     // timing-only ablations (results wrong by construction), tools/abl_perm.sh.  Bits:
-//    1 candidate Philox with 5 rounds      2 exp in the HRUA test replaced by 1 + t      4 set-up sqrt in f32
-//    8 threshold-table draw replaced by a cheap hash      16 general rows not queued (k_perm_fast alone)
-//   32 exact-tail sums skipped      64 bisection skipped      128 binomial draw skipped
-// 1024 statistic look-ups skipped      4096 pmf look-ups not scattered      8192 streamlined 3x2 loop off
-// 16384 lock-step loop: no squeeze (every in-range candidate looks its four log-factorials up; same results)
-// 2048 lock-step loop: every LF / G look-up replaced by arithmetic (no vector-memory instruction; with 131072's hash)
-// 131072 lock-step loop: every LF / G look-up at index & 15 (always an L1 hit), acceptance from a hash (0.72)
-// 262144 lock-step loop: the accepted table's four G look-ups read LDS instead (what a per-row window in LDS could reach)
-// (262144 and 524288 meant something else in round 2's streamlined 3x2 loop — capped table search, fixed-stride
-//  shuffles; their measurements are in DESIGN.md §8 — and went with it when the lock-step streams came.)
-// Every bit keeps all table indices inside the range the normal path uses and keeps every rejection loop's acceptance
-// probability positive.  Round 1 also had bit 256 (HRUA set-up skipped): it left the acceptance test unsatisfiable, so
-// k_perm_general never returned; and uncommitted bits 2048/16384/32768/65536, one of which indexed LF[] with set-up
-// values it had skipped (GPU memory fault).  Those meanings are gone for good; 2048 and 16384 were given the new,
-// safe meanings above in round 3 (they only replace values or skip a shortcut, no index is derived from them).
+#define LGMI_PABL 0     // timing-only ablations of k_perm_fast (results wrong by construction), tools/abl_perm.sh.  Bits:
+//   16 larger tables not queued (k_perm_fast alone)      32 exact-tail sums skipped      64 boundary search skipped
+//  128 binomial draw skipped
+// Every bit keeps all table indices inside the range the normal path uses.  (Rounds 1 - 3 had fifteen more meanings, for
+// the sampling loops of k_perm_general: 1 2 4 8 1024 2048 4096 8192 16384 131072 262144, and 256 32768 65536, two of which
+// hung or faulted.  Since round 4 those loops run ~5 % of the step — the six-cell rows take the perimeter walk — and the
+// variants went; their measurements are in HISTORY.md.)
 #endif
-#define LGMI_PABL_KNOWN (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128 | 1024 | 2048 | 4096 | 8192 | 16384 | 131072 | 262144)
+#define LGMI_PABL_KNOWN (16 | 32 | 64 | 128)
 #if LGMI_PABL & ~LGMI_PABL_KNOWN
-#error "LGMI_PABL: unknown ablation bit (see the list above; 256, 32768, 65536 were removed: they hang or fault)"
+#error "LGMI_PABL: unknown ablation bit (16, 32, 64, 128 are left: see the list above)"
 #endif
 
 namespace lgmi {
@@ -66,25 +57,13 @@ template <class T> struct Tab {
     __device__ __forceinline__ T operator[](uint32_t i) const {
         return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + (size_t)(i * (uint32_t)sizeof(T)));
     }
-    // the look-ups of the lock-step loop (the timing ablations 2048 / 131072 apply to these only)
+    // the look-ups of the lock-step loop
     __device__ __forceinline__ T ls(uint32_t i) const {
-#if LGMI_PABL & 2048
-        return (T)(i & 15u);                      // no load at all
-#elif LGMI_PABL & 131072
-        return (*this)[i & 15u];                  // one L1-resident line
-#else
         return (*this)[i];
-#endif
     }
 };
 typedef Tab<long long> TabG;
 typedef Tab<double> TabLF;
-
-#if LGMI_PABL
-__device__ __forceinline__ U4 cheap_rng(uint32_t a, uint32_t b) {
-    U4 o; o.x = a * 2654435761u + b * 40503u; o.y = (o.x ^ (o.x >> 15)) * 2246822519u; o.x ^= o.y >> 13; o.z = o.x; o.w = o.y; return o;
-}
-#endif
 
 static const uint32_t TAG_PERM2X2 = 0x5eed0004u;
 static const uint32_t TAG_PERMGEN = 0x60000000u;
@@ -176,10 +155,6 @@ __device__ __forceinline__ long long stat22(TabG G, const HG22& h, uint32_t k) {
 }
 
 __device__ __forceinline__ double pmf22(TabLF LF, const HG22& h, uint32_t k) {
-#if LGMI_PABL & 4096
-    { const uint32_t md = h.N + 1u;   // LF[] has at least N + 1 entries
-      return det_exp(h.c0 - LF[(k & 15u) % md] - LF[((h.K - k) & 15u) % md] - LF[((h.n - k) & 15u) % md] - LF[((h.N - h.K - h.n + k) & 15u) % md] - 3.0e6); }
-#endif
     double e = h.c0;
     e -= LF[k];
     e -= LF[h.K - k];
@@ -1403,9 +1378,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 simple = (m2 >= 10u) && (R0 - xhi >= 1u) && (R0 - xlo < pop2);
             }
         }
-#if LGMI_PABL & 8192
-        simple = false;
-#endif
         if (simple) {
             const uint32_t pop2 = nr == 3 ? N - R0 : N - C0;
             HrRecip rc2;                                 // the second draw's population is the row's; nr == 3: its good too
@@ -1522,7 +1494,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                     // 65 instructions shorter per trip and pays everywhere: north-star 233 -> 215 ms, cfg5 1,260 -> 1,115,
                     // cfg3 145 -> 145, cfg2 7.7 -> 7.5 — the switch is gone.
                     bool decided = false;
-#if !(LGMI_PABL & 16384)
                     if (c0 < 0.0 && c0 >= -Bd) {
                         // x = u 2^-32; v_log_f32 is log2 to ~1 ulp (|log2| <= 32: 4e-6), far inside the 2e-4 margin
                         const double lx = (double)((__builtin_amdgcn_logf((float)u) - 32.0f) * 1.3862943611198906f);
@@ -1539,24 +1510,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                         acc = yes;
                         decided = yes | no;
                     }
-#endif
                     if (!decided) {
                         const double l3 = LF.ls(mxm + zc), l2 = LF.ls(m - zc), l1 = LF.ls(mn - zc), l0 = LF.ls(zc);
                         const double tt = d10 - (l0 + l1 + l2 + l3);
                         const double x = u * 2.3283064365386963e-10;
                         acc = le_exp(x * x, tt);                     // 2 ln x <= tt
                     }
-#if LGMI_PABL & (131072 | 2048)
-                    exceed += acc; acc = (wy & 0xFFu) < 184u;
-#endif
                 }
                 const unsigned long long bal = __ballot(acc);
                 if (acc) {
-#if LGMI_PABL & 262144
-                    const long long g3 = tab_thr[(mxm + zc) & 1023u], g2 = tab_thr[(m - zc) & 1023u], g1 = tab_thr[(mn - zc) & 1023u], g0 = tab_thr[zc & 1023u];
-#else
                     const long long g3 = G.ls(mxm + zc), g2 = G.ls(m - zc), g1 = G.ls(mn - zc), g0 = G.ls(zc);
-#endif
                     const long long gx_this = gx;                    // (before the set-up below overwrites it)
                     const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                     setup(x_ring[(next + rank) & (XRING - 1u)], false);
@@ -1599,14 +1562,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
         uint32_t z = 0;
         // the first real draw of a shuffle when the row has a threshold table: one 32-bit word, inverse CDF
         auto table_draw = [&]() {
-#if LGMI_PABL & 8
-            const U4 o = cheap_rng(g.s + ci, g.call + cj);
-            g.call++;
-            { g.sp1 = o.y; g.sp2 = o.z; g.sp3 = o.w; g.spare = 2; g.aft = 1;
-              const uint32_t e_ = (tab_n >> 1) + (o.x & 7u); return tab_klo + (e_ < tab_n ? e_ : tab_n - 1u); }   // stays inside the window
-#else
             const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
-#endif
             g.call++;
             g.sp1 = o.y; g.sp2 = o.z; g.sp3 = o.w; g.spare = 2; g.aft = 1;   // the next two pairs of uniforms come from this call
             // smallest e with u < thr[e] (the last entry when there is none); the guide table narrows the
@@ -1632,11 +1588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
             double ux = 0.5, uy = 0.5;
             if (in_draw) {
                 if (g.spare == 0) {
-#if LGMI_PABL & 1
-                    const U4 o = philox4x32_r<5>(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
-#else
                     const U4 o = philox4x32_10(g.s, ci, cj, TAG_PERMGEN + g.call, k0, k1);
-#endif
                     g.call++;
                     g.sp1 = o.y; g.sp2 = o.z; g.sp3 = o.w; g.spare = 2;
                 }
@@ -1654,11 +1606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                 if (!(w < 0.0 || w >= g.d11)) {
                     const uint32_t zc = (uint32_t)floor(w);
                     const double tt = g.d10 - (LF[zc] + LF[g.mn - zc] + LF[g.m - zc] + LF[g.mx - g.m + zc]);
-#if LGMI_PABL & 2
-                    const bool acc = (x * x <= 1.0 + tt);
-#else
                     const bool acc = le_exp(x * x, tt);   // 2 ln x <= tt
-#endif
                     if (acc) {
                         z = zc;
                         if (g.good > g.pop - g.good) z = g.m - z;   // z counted the minority kind
@@ -1714,11 +1662,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                             column_done = true;
                         }
                         if (column_done) {
-#if LGMI_PABL & 1024
-                            g.ss += x0 + x1 + x2;
-#else
                             g.ss += G[x0] + G[x1] + G[x2];
-#endif
                             g.rr0 -= x0; g.rr1 -= x1; rr2 -= x2;
                             g.pop_all -= ((g.d >> 1) == 0 ? C0 : C1);
                             g.d = (g.d | 1) + 1;                     // first row of the next column
@@ -1754,13 +1698,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_PERM_WP
                         g.mn = good < bad ? good : bad;
                         g.mx = good < bad ? bad : good;
                         g.d6 = (double)g.m * hb.d4 + 0.5;
-#if LGMI_PABL & 4
-                        const double d7 = (double)__fsqrt_rn((float)((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5));
-#else
                         // the draw right after the table draw of a 3 x 2 / 2 x 3 row takes the row's hat width
                         const bool bounded = d7max > 0.0 && g.aft && pop == key_pop2 && (nr == 3 ? good == key2 : sample == key2);
                         const double d7 = bounded ? d7max : det_sqrt((double)(pop - g.m) * (double)g.m * hb.cvar + 0.5);
-#endif
                         const uint32_t d9 = (uint32_t)floor((double)(g.m + 1u) * hb.c9);
                         g.d10 = LF[d9] + LF[g.mn - d9] + LF[g.m - d9] + LF[g.mx - g.m + d9];
                         g.d8 = HRUA_D1 * d7 + HRUA_D2;
