@@ -21,7 +21,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
 cd $ROOT
 python3 tools/pmc_summary.py stats $OUT/trace profiles/${R}_${WL}_kernel_stats.csv
 python3 tools/pmc_summary.py count $WL $OUT/fetch $OUT/write profiles/${R}_pmc_k_count.json
-DRAWS=$(python3 -c "import json; d=json.load(open('$OUT/sq.json')); print(d['perm_roofline']['table_draws'])")
+DRAWS=$(python3 -c "import json; d=json.load(open('$OUT/sq.json')); print(d['perm_roofline']['table_draws_upper'])")
 ROWS=$(python3 -c "import json; d=json.load(open('$OUT/sq.json')); print(d['perm_roofline']['two_by_two_rows'])")
 python3 tools/pmc_summary.py sq $WL $OUT/sq $DRAWS $ROWS profiles/${R}_pmc_sq_perm.json
 cp $OUT/trace.json profiles/${R}_bench_under_rocprof_${WL}.json
