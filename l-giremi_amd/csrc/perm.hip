@@ -310,8 +310,9 @@ __device__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned long long thr, uin
         const double b = 1.15 + 2.53 * spq;
         const double a = -0.0873 + 0.0248 * b + 0.01 * p;
         const double c = np + 0.5;
-        const double vr = 0.92 - 4.2 / b;
-        const double alpha = (2.83 + 5.1 / b) * spq;
+        const double rb = 1.0 / b;                          // (round 4: one reciprocal for the two quotients by b, one per
+        const double vr = 0.92 - 4.2 * rb;                  //  candidate for the two by us — five divisions per row were a
+        const double alpha = (2.83 + 5.1 * rb) * spq;       //  quarter of this routine's instructions)
         const uint32_t m = (uint32_t)floor((double)(n + 1u) * p);
         const double lr = det_log(p / q);
         const double hm = LF[m] + LF[n - m];
@@ -320,11 +321,12 @@ __device__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned long long thr, uin
             const double u = ((double)o.x + 0.5) * 2.3283064365386963e-10 - 0.5;
             double v = ((double)o.y + 0.5) * 2.3283064365386963e-10;
             const double us = 0.5 - fabs(u);
-            const double kf = floor((2.0 * a / us + b) * u + c);
+            const double rus = 1.0 / us;
+            const double kf = floor((2.0 * a * rus + b) * u + c);
             if (kf < 0.0 || kf > (double)n) continue;
             k = (uint32_t)kf;
             if (us >= 0.07 && v <= vr) break;
-            v = v * alpha / (a / (us * us) + b);
+            v = v * alpha / (a * rus * rus + b);
             const double h = hm - LF[k] - LF[n - k] + ((double)k - (double)m) * lr;
             if (v <= det_exp(h)) break;
         }

@@ -481,7 +481,8 @@ static uint64_t ptail22(const perm_tables* t, const hg22* h, uint32_t kobs, doub
  *   thr == 0 -> 0;  thr >= 2^32 -> n;  thr > 2^31: n - Binomial(n, 1 - p)  (1 - p is exact)
  *   n p < 10 : sequential inversion from 0 (BINV; restart with fresh uniforms beyond np + 10 sqrt(npq + 1))
  *   else     : Hoermann's transformed rejection BTRS (1993), the acceptance test taken against the exact
- *              log-factorial table: v alpha / (a / us^2 + b) <= f(k) / f(m)
+ *              log-factorial table: v alpha / (a / us^2 + b) <= f(k) / f(m); its quotients by b and by us are products
+ *              with ONE reciprocal each (rb = 1 / b, rus = 1 / us: round 4)
  * Uniforms: Philox4x32-10, counter (call, row_i, row_j, TAG_PERM2X2), call = 0, 1, ... one call per BTRS
  * candidate (words 0 and 1 -> (w + 0.5) 2^-32) or per inversion run (words 0, 1 -> 52 bits + half an ulp). */
 static uint32_t binom_draw(const perm_tables* t, uint32_t n, uint64_t thr, uint32_t row_i, uint32_t row_j,
@@ -518,22 +519,24 @@ static uint32_t binom_draw(const perm_tables* t, uint32_t n, uint64_t thr, uint3
         const double b = 1.15 + 2.53 * spq;
         const double a = -0.0873 + 0.0248 * b + 0.01 * p;
         const double c = np + 0.5;
-        const double vr = 0.92 - 4.2 / b;
-        const double alpha = (2.83 + 5.1 / b) * spq;
+        const double rb = 1.0 / b;
+        const double vr = 0.92 - 4.2 * rb;
+        const double alpha = (2.83 + 5.1 * rb) * spq;
         const uint32_t m = (uint32_t)floor((double)(n + 1u) * p);
         const double lr = lgo_det_log(p / q);
         const double hm = t->LF[m] + t->LF[n - m];
         for (;;) {
-            double u, v, us, kf, h;
+            double u, v, us, rus, kf, h;
             philox(call++, row_i, row_j, TAG_PERM2X2, k0, k1, out);
             u = ((double)out[0] + 0.5) * 2.3283064365386963e-10 - 0.5;
             v = ((double)out[1] + 0.5) * 2.3283064365386963e-10;
             us = 0.5 - fabs(u);
-            kf = floor((2.0 * a / us + b) * u + c);
+            rus = 1.0 / us;
+            kf = floor((2.0 * a * rus + b) * u + c);
             if (kf < 0.0 || kf > (double)n) continue;
             k = (uint32_t)kf;
             if (us >= 0.07 && v <= vr) break;
-            v = v * alpha / (a / (us * us) + b);
+            v = v * alpha / (a * rus * rus + b);
             h = hm - t->LF[k] - t->LF[n - k] + ((double)k - (double)m) * lr;
             if (v <= lgo_det_exp(h)) break;
         }
