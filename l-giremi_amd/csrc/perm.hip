@@ -357,6 +357,104 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     __shared__ uint32_t s_queue[128];                       // rows waiting to be queued for k_perm_general
     uint32_t qn = 0u;                                       // how many (wave-uniform)
     bool any_small = false;                                 // a queued row small enough for k_perm_enum (one store per wave, at the end)
+    // Round 4: the rows that have tail sums to make are COMPACTED across chunks before the sums and the
+    // binomial draw — 12 - 22 % of a chunk's lanes (larger tables, degenerate tables, linked pairs whose tail is below 2^-33,
+    // centre forms with nothing between the bounds) used to sit idle through both phases.  Such rows are finished where they
+    // are classified; the others wait in LDS (WREC dwords each) and are processed 64 at a time with every lane busy.
+    enum { WREC = 12 };                                     // r, N, K, n, start1, len1, start2, len2, c0 (2), centre, -
+    __shared__ uint32_t s_work[128 * WREC];
+    uint32_t wn = 0u;                                       // rows waiting (wave-uniform)
+    __shared__ uint32_t s_pre[65];
+    __shared__ unsigned long long s_acc[64];
+
+    // phases B and C for the first `cnt` waiting rows (one lane per row)
+    auto process = [&](uint32_t cnt) {
+        const bool have = lane < cnt;
+        HG22 h = {1u, 0u, 0u, 0u, 0u, 0.0};
+        uint32_t r = 0u, start1 = 0u, len1 = 0u, start2 = 0u, len2 = 0u;
+        int centre = 1;
+        if (have) {
+            const uint32_t* w = s_work + lane * WREC;
+            r = w[0]; h.N = w[1]; h.K = w[2]; h.n = w[3];
+            start1 = w[4]; len1 = w[5]; start2 = w[6]; len2 = w[7];
+            h.c0 = __longlong_as_double((long long)(((unsigned long long)w[9] << 32) | w[8]));
+            centre = (int)w[10];
+        }
+        // ---- phase B: exact mass of the "as or more extreme" set, or of its complement when that is the short side.
+        //      Each row lists up to two ranges of k; the ranges are cut into units of 64 values and the units of the
+        //      wave's rows are dealt to the lanes 64 at a time, so every lane has the same amount of work whatever
+        //      the rows' range lengths are.  Unit masses are integers (2^-62) added with LDS atomics: exact, any order.
+        const uint32_t units1 = (len1 + UNIT - 1u) / UNIT;
+        const uint32_t my_units = units1 + (len2 + UNIT - 1u) / UNIT;
+        uint32_t incl = my_units;                               // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        s_pre[lane] = incl - my_units;
+        if (lane == 63u) s_pre[64] = incl;
+        s_acc[lane] = 0ull;
+        __syncthreads();
+        const uint32_t total = s_pre[64];                    // wave-uniform
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t id = base + lane;
+            const bool active = id < total;
+            // the row of unit id: the largest r with pre[r] <= id (its successor starts beyond id, so it owns units)
+            uint32_t lo = 0u, hi = 63u;
+            if (active) {
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (s_pre[mid] <= id) lo = mid; else hi = mid - 1u;
+                }
+            }
+            const int rr = (int)lo;
+            HG22 hb;
+            hb.N = __shfl(h.N, rr); hb.K = __shfl(h.K, rr); hb.n = __shfl(h.n, rr);
+            hb.kmin = 0u; hb.kmax = 0u;
+            hb.c0 = __shfl(h.c0, rr);
+            const uint32_t r_start1 = __shfl(start1, rr), r_len1 = __shfl(len1, rr);
+            const uint32_t r_start2 = __shfl(start2, rr), r_len2 = __shfl(len2, rr);
+            if (active) {
+                uint32_t u = id - s_pre[rr];
+                const uint32_t r_units1 = (r_len1 + UNIT - 1u) / UNIT;
+                uint32_t k0, len;
+                if (u < r_units1) { k0 = r_start1 + UNIT * u; len = r_len1 - UNIT * u; }
+                else { u -= r_units1; k0 = r_start2 + UNIT * u; len = r_len2 - UNIT * u; }
+                if (len > UNIT) len = UNIT;
+                atomicAdd(&s_acc[rr], unit_mass(LF, hb, k0, len));
+            }
+        }
+        __syncthreads();
+        if (have) {
+            const unsigned long long sm = s_acc[lane];
+            if (pa.exact_2x2) {
+                // the exact p: the mass itself (oracle/lgmi_perm_oracle.c: ptail22's p_out), no Monte-Carlo draw
+                double p = centre ? 1.0 - (double)sm * 2.168404344971009e-19 : (double)sm * 2.168404344971009e-19;
+                if (p > 1.0) p = 1.0;
+                if (p < 0.0) p = 0.0;
+                out_exceed[r] = LGMI_EXCEED_EXACT;
+                out_p[r] = p;                                   // (the exact p is never derivable: out_p is there)
+            } else {
+                unsigned long long thr;
+                if (centre) thr = sm <= 4611686018427387904ull ? (4611686018427387904ull - sm) >> 30 : 0ull;
+                else { thr = sm >> 30; if (thr > 4294967296ull) thr = 4294967296ull; }
+#if LGMI_PABL & 32
+                thr = 1589137899ull;
+#endif
+                // ---- phase C: the shuffles
+#if LGMI_PABL & 128
+                const uint32_t exceed = (uint32_t)(thr >> 24);
+#else
+                const uint32_t exceed = binom_draw(LF, n_shuffles, thr, row_i[r] + pa.site_base, row_j[r] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
+#endif
+                out_exceed[r] = exceed;
+                if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+            }
+        }
+        __syncthreads();                                        // s_pre / s_acc / s_work are reused
+    };
+
     // (a fixed stride: taking the chunks from a shared counter, as k_perm_general takes its rows, was measured
     // slower here — 79 ms against 63 with 4 chunks per atomic, 139 ms with one)
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // wave-uniform trip count: the grid drains
@@ -421,14 +519,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
         }
     }
 #endif
-    // ---- phase B: exact mass of the "as or more extreme" set, or of its complement when that is the short side.
-    //      Each row lists up to two ranges of k; the ranges are cut into units of 64 values and the units of the
-    //      wave's 64 rows are dealt to the lanes 64 at a time, so every lane has the same amount of work whatever
-    //      the rows' range lengths are.  Unit masses are integers (2^-62) added with LDS atomics: exact, any order.
-    // (one wave per workgroup: the barriers below cost nothing and no wave waits for another's rows)
-    __shared__ uint32_t s_pre[1][65];
-    __shared__ unsigned long long s_acc[1][64];
-    const uint32_t w = 0u;
+    // ---- the ranges to sum; rows without any are finished here
     uint32_t start1 = 0, len1 = 0, start2 = 0, len2 = 0;
     if (kind == 2) {
 #if !(LGMI_PABL & 32)
@@ -451,87 +542,53 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
         }
 #endif
     }
-    const uint32_t units1 = (len1 + UNIT - 1u) / UNIT;
-    const uint32_t my_units = units1 + (len2 + UNIT - 1u) / UNIT;
-    uint32_t incl = my_units;                               // inclusive scan over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o);
-        if (lane >= (uint32_t)o) incl += v;
+    const bool work = kind == 2 && (len1 | len2) != 0u;
+    if ((kind == 1 || kind == 2) && !work) {
+        // degenerate table: every shuffle gives it again.  2 x 2 with nothing to sum: the mass is 0 — the centre form's
+        // complement is everything (thr = 2^32: every shuffle), the tail form's set weighs nothing (thr = 0: none).
+        const bool all = kind == 1 || tb.centre;
+        if (pa.exact_2x2) { out_exceed[r] = LGMI_EXCEED_EXACT; out_p[r] = all ? 1.0 : 0.0; }
+        else {
+#if LGMI_PABL & 32
+            const uint32_t exceed = kind == 1 ? n_shuffles : (uint32_t)(1589137899ull >> 24);
+#else
+            const uint32_t exceed = all ? n_shuffles : 0u;
+#endif
+            out_exceed[r] = exceed;
+            if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+        }
     }
-    s_pre[w][lane] = incl - my_units;
-    if (lane == 63u) s_pre[w][64] = incl;
-    s_acc[w][lane] = 0ull;
-    __syncthreads();
-    const uint32_t total = s_pre[w][64];                    // wave-uniform
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t id = base + lane;
-        const bool active = id < total;
-        // the row of unit id: the largest r with pre[r] <= id (its successor starts beyond id, so it owns units)
-        uint32_t lo = 0u, hi = 63u;
-        if (active) {
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1u) >> 1;
-                if (s_pre[w][mid] <= id) lo = mid; else hi = mid - 1u;
+    {
+        const unsigned long long wb = __ballot(work);
+        if (wb) {
+            if (work) {
+                uint32_t* w = s_work + (wn + (uint32_t)__popcll(wb & ((1ull << lane) - 1ull))) * WREC;
+                const unsigned long long cb = (unsigned long long)__double_as_longlong(h.c0);
+                w[0] = (uint32_t)r; w[1] = h.N; w[2] = h.K; w[3] = h.n; w[4] = start1; w[5] = len1; w[6] = start2; w[7] = len2;
+                w[8] = (uint32_t)cb; w[9] = (uint32_t)(cb >> 32); w[10] = (uint32_t)tb.centre;
+            }
+            wn += (uint32_t)__popcll(wb);
+            __syncthreads();
+            if (wn >= 64u) {
+                process(64u);
+                const uint32_t rest = wn - 64u;                  // < 64: moved to the front
+                uint32_t keep[WREC];
+                if (lane < rest) {
+#pragma unroll
+                    for (int k = 0; k < WREC; ++k) keep[k] = s_work[(64u + lane) * WREC + k];
+                }
+                __syncthreads();
+                if (lane < rest) {
+#pragma unroll
+                    for (int k = 0; k < WREC; ++k) s_work[lane * WREC + k] = keep[k];
+                }
+                wn = rest;
+                __syncthreads();
             }
         }
-        const int rr = (int)lo;
-        HG22 hb;
-        hb.N = __shfl(h.N, rr); hb.K = __shfl(h.K, rr); hb.n = __shfl(h.n, rr);
-        hb.kmin = 0u; hb.kmax = 0u;
-        hb.c0 = __shfl(h.c0, rr);
-        const uint32_t r_start1 = __shfl(start1, rr), r_len1 = __shfl(len1, rr);
-        const uint32_t r_start2 = __shfl(start2, rr), r_len2 = __shfl(len2, rr);
-        if (active) {
-            uint32_t u = id - s_pre[w][rr];
-            const uint32_t r_units1 = (r_len1 + UNIT - 1u) / UNIT;
-            uint32_t k0, len;
-            if (u < r_units1) { k0 = r_start1 + UNIT * u; len = r_len1 - UNIT * u; }
-            else { u -= r_units1; k0 = r_start2 + UNIT * u; len = r_len2 - UNIT * u; }
-            if (len > UNIT) len = UNIT;
-            atomicAdd(&s_acc[w][rr], unit_mass(LF, hb, k0, len));
-        }
     }
-    __syncthreads();
-    unsigned long long thr = 0ull;
-    if (pa.exact_2x2 && (kind == 1 || kind == 2)) {
-        // the exact p: the mass itself (oracle/lgmi_perm_oracle.c: ptail22's p_out), no Monte-Carlo draw
-        double p = 1.0;
-        if (kind == 2) {
-            const unsigned long long sm = s_acc[w][lane];
-            p = tb.centre ? 1.0 - (double)sm * 2.168404344971009e-19 : (double)sm * 2.168404344971009e-19;
-            if (p > 1.0) p = 1.0;
-            if (p < 0.0) p = 0.0;
-        }
-        out_exceed[r] = LGMI_EXCEED_EXACT;
-        out_p[r] = p;                                       // (the exact p is never derivable: out_p is there)
-        kind = 0;                                           // done with this row
-    }
-    if (kind == 2) {
-        const unsigned long long sm = s_acc[w][lane];
-        if (tb.centre) thr = sm <= 4611686018427387904ull ? (4611686018427387904ull - sm) >> 30 : 0ull;
-        else { thr = sm >> 30; if (thr > 4294967296ull) thr = 4294967296ull; }
-#if LGMI_PABL & 32
-        thr = 1589137899ull;
-#endif
-    }
-    // ---- phase C (one lane per row): the shuffles
-    if (kind == 1 || kind == 2) {
-    uint32_t exceed;
-    if (kind == 1) {
-        exceed = n_shuffles;
-    } else {
-#if LGMI_PABL & 128
-        exceed = (uint32_t)(thr >> 24);
-#else
-        exceed = binom_draw(LF, n_shuffles, thr, row_i[r] + pa.site_base, row_j[r] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
-#endif
-    }
-    out_exceed[r] = exceed;
-    if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
-    }
-    __syncthreads();                                        // s_pre / s_acc are reused by the next chunk
     }   // chunk loop
+    if (wn) process(wn);
     // (thousands of waves storing to one address are served one after the other: 0.3 ms on the footprint batch — a wave
     //  stores only while it still reads 0 there)
     if (__any(any_small) && lane == 0u && __atomic_load_n(pa.gen_count + 3, __ATOMIC_RELAXED) == 0u) pa.gen_count[3] = 1u;
