@@ -77,6 +77,22 @@ def committed_profile(name):
     return {}
 
 
+def gpu_clocks():
+    """sclk / mclk as rocm-smi reports them right after the timed steps (the peaks in this file are priced at 2.4 GHz; the
+    boxes of the pool grant 2.1 - 2.4): read by a child process, outside every timed region; None when rocm-smi is not there"""
+    import subprocess
+    try:
+        txt = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
+        out = {}
+        for ln in txt.splitlines():
+            for key in ('sclk', 'mclk'):
+                if key + ' clock level' in ln and '(' in ln and key not in out:
+                    out[key] = ln[ln.rindex('(') + 1:ln.rindex(')')]
+        return out or None
+    except Exception:      # noqa: BLE001 — a missing tool must not cost the bench line
+        return None
+
+
 def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
     """The CPU oracle (oracle/lgmi_oracle.c, OpenMP) timed on a bounded sample of the
     same workload: same read count, fewer sites, so it finishes in ~10-30 s."""
@@ -430,6 +446,7 @@ def main():
                 del pb
             if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
                 out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)
+            out['clocks'] = gpu_clocks()       # what the box grants: the count kernel's fraction of the nominal peak follows it
             return out
 
     def degrade(line, tag, text):
