@@ -77,20 +77,55 @@ def committed_profile(name):
     return {}
 
 
-def gpu_clocks():
-    """sclk / mclk as rocm-smi reports them right after the timed steps (the peaks in this file are priced at 2.4 GHz; the
-    boxes of the pool grant 2.1 - 2.4): read by a child process, outside every timed region; None when rocm-smi is not there"""
-    import subprocess
-    try:
-        txt = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
-        out = {}
-        for ln in txt.splitlines():
-            for key in ('sclk', 'mclk'):
-                if key + ' clock level' in ln and '(' in ln and key not in out:
-                    out[key] = ln[ln.rindex('(') + 1:ln.rindex(')')]
-        return out or None
-    except Exception:      # noqa: BLE001 — a missing tool must not cost the bench line
+class ClockSampler:
+    """sclk / mclk of the device WHILE the timed steps run, read from sysfs (pp_dpm_sclk / pp_dpm_mclk: the level marked
+    `*`) by a thread of this process every 50 ms — no child process (a program exec'ed from a process in which the profiler
+    has initialised the GPU is refused on the test pool) and no GPU call.  The peaks in this file are priced at 2.4 GHz; what a
+    box grants under load is what the count kernel's fraction of the nominal peak follows."""
+
+    def __init__(self, device=0):
+        import glob
+        import threading
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
+        self.path = os.path.dirname(cards[min(device, len(cards) - 1)]) if cards else None
+        self.samples = {'sclk': [], 'mclk': []}
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.path else None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.path, 'pp_dpm_' + name)) as f:
+                for ln in f:
+                    if '*' in ln:
+                        return int(''.join(ch for ch in ln.split(':')[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
         return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            for k in self.samples:
+                v = self._read(k)
+                if v:
+                    self.samples[k].append(v)
+            self._stop.wait(0.05)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join(1.0)
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                v = sorted(v)
+                out[k + '_mhz'] = {'median': v[len(v) // 2], 'min': v[0], 'max': v[-1], 'samples': len(v)}
+        return out or None
 
 
 def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
@@ -241,11 +276,14 @@ def main():
         dr.free()
         return info
 
+    clock_state = {}
+
     def measure():
         """W untimed + K timed steps between barriers; -> (infos, max-over-ranks seconds, per-rank stage means)"""
         for _ in range(args.warmup):
             step()
         sync()
+        sampler = ClockSampler(device).start() if rank == 0 else None
         t0 = time.perf_counter()
         infos_ = []
         for _ in range(args.steps):
@@ -254,6 +292,8 @@ def main():
             infos_[-1]['wall_ms'] = 1e3 * (time.perf_counter() - t_)
         sync()
         elapsed_ = group.allreduce_max(time.perf_counter() - t0)
+        if sampler is not None:
+            clock_state['clocks'] = sampler.stop()
         per_rank_ = group.gather({k: sum(i[k] for i in infos_) / len(infos_) for k in
                                   ('ms_total', 'ms_count', 'ms_emit', 'ms_perm', 'n_examined', 'n_rows', 'n_tile_pairs')})
         return infos_, elapsed_, per_rank_
@@ -446,7 +486,16 @@ def main():
                 del pb
             if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
                 out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)
-            out['clocks'] = gpu_clocks()       # what the box grants: the count kernel's fraction of the nominal peak follows it
+            out['clocks'] = clock_state.get('clocks')       # sampled during the timed steps (ClockSampler)
+            try:
+                med = out['clocks']['sclk_mhz']['median']
+                if out['roofline'].get('bound') == 'mfma' and med:
+                    # the nominal peak is priced at 2.4 GHz; under this load the box runs slower (power), and the matrix pipe's
+                    # rate follows the clock: the same kernel time against the peak at the clock the box actually granted
+                    out['roofline']['frac_at_sampled_sclk'] = out['roofline']['frac'] * 2400.0 / med
+                    out['roofline']['sampled_sclk_mhz'] = med
+            except (KeyError, TypeError):
+                pass
             return out
 
     def degrade(line, tag, text):

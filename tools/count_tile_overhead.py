@@ -3,7 +3,6 @@ read counts — time = tiles_per_cu x (a + b x words).  `a` is everything a pers
 launch, ring prologue, 256-store epilogue); VERDICT r3 item 4.   python tools/count_tile_overhead.py"""
 import json
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -14,11 +13,15 @@ import lgmi  # noqa: E402
 
 
 def clocks():
-    try:
-        out = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
-        return [ln.strip() for ln in out.splitlines() if 'sclk' in ln or 'mclk' in ln][:4]
-    except Exception as e:      # noqa: BLE001
-        return ['rocm-smi: %s' % e]
+    """the active sclk / mclk levels from sysfs (no child process: see bench.py ClockSampler)"""
+    import glob
+    out = []
+    for f in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_[sm]clk'))[:2]:
+        try:
+            out += ['%s %s' % (os.path.basename(f), ln.strip()) for ln in open(f) if '*' in ln]
+        except OSError:
+            pass
+    return out
 
 
 eng = lgmi.Engine(0)
