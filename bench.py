@@ -489,7 +489,7 @@ def main():
             out['clocks'] = clock_state.get('clocks')       # sampled during the timed steps (ClockSampler)
             try:
                 med = out['clocks']['sclk_mhz']['median']
-                if out['roofline'].get('bound') == 'mfma' and med:
+                if out['roofline'].get('bound') == 'mfma' and med and out['clocks']['sclk_mhz']['samples'] >= 8 and ms_count >= 10.0:
                     # the nominal peak is priced at 2.4 GHz; under this load the box runs slower (power), and the matrix pipe's
                     # rate follows the clock: the same kernel time against the peak at the clock the box actually granted
                     out['roofline']['frac_at_sampled_sclk'] = out['roofline']['frac'] * 2400.0 / med
