@@ -617,3 +617,27 @@ def test_permutation_p_in_the_other_configurations(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith('OK') and int(last.split('general=')[1]) > 100
+
+
+def test_host_rows_are_views_that_outlive_the_device_result(engine):
+    """round 4: MIResult's arrays are zero-copy views of the library's pinned host buffers (a batch of footprints returns
+    hundreds of megabytes); they stay valid after the device result, other results and the MIResult object itself are
+    gone, and the buffers go back to the pool with the last view"""
+    import gc
+    pb = random_batch(77, n_blocks=3)
+    dr = engine.run_device(engine.upload(pb), min_common=3, het_only=True, n_shuffles=50, seed=5)
+    res = dr.fetch()
+    keep_mi, keep_i, keep_e = res.row_mi, res.row_i, res.row_exceed
+    copy_mi, copy_i, copy_e = keep_mi.copy(), keep_i.copy(), keep_e.copy()
+    assert not keep_mi.flags.owndata and res.n_rows > 10
+    dr.free()
+    del res
+    gc.collect()
+    for seed in range(3):                                   # other results come and go through the same pinned pool
+        other = engine.run(random_batch(78 + seed, n_blocks=2), min_common=3, het_only=True, n_shuffles=50, seed=5)
+        assert other.n_rows >= 0
+        del other
+    gc.collect()
+    np.testing.assert_array_equal(keep_mi, copy_mi)
+    np.testing.assert_array_equal(keep_i, copy_i)
+    np.testing.assert_array_equal(keep_e, copy_e)
