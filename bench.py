@@ -428,9 +428,10 @@ def main():
             sq_e = committed_profile('pmc_sq_perm').get(args.workload, {}).get('k_emit<2>')
             ms_emit = sum(i['ms_emit'] for i in infos) / len(infos)
             if world == 1 and sq_e and sq_e.get('valu_insts') and sq_e.get('ms') and info['n_rows']:
-                out['emit_roofline'] = {'kernel': 'k_emit<2>', 'bound': 'valu_issue', 'ms_emit_stage': ms_emit,
+                out['emit_roofline'] = {'kernel': 'k_emit<2>', 'bound': 'vector issue + look-up latency (class_account)', 'ms_emit_stage': ms_emit,
                                         'rows_per_s': info['n_rows'] / (ms_emit * 1e-3) if ms_emit > 0 else None,
-                                        'valu_issue_frac': sq_e['valu_insts'] / (sq_e['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
+                                        'valu_issue_frac_at_4_cycles': sq_e['valu_insts'] / (sq_e['ms'] * 1e-3) / VALU_WAVE_INSTR_PEAK,
+                                        'class_account': committed_profile('pmc_class').get(args.workload, {}).get('k_emit<2>'),
                                         'active_lane_frac': sq_e.get('active_lanes', 0) / 64.0,
                                         'valu_insts_per_row': sq_e['valu_insts'] * 64.0 / info['n_rows'],
                                         'peak': VALU_WAVE_INSTR_PEAK, 'unit': 'wave64 VALU instructions/s',
