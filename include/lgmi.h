@@ -102,11 +102,14 @@ typedef struct lgmi_params {
     uint8_t  het_only;     /* 1: only pairs with >=1 het_snp side (mismatch.py:392-396);
                               0: all P(P-1)/2 pairs (mutual_information.py:12)   */
     uint8_t  emit_counts;  /* 1: fill row_counts (3x3 table per row)              */
-    uint8_t  exact_2x2;    /* 1: rows whose table has at most 2 non-empty classes per site get the EXACT
-                              permutation p (the hypergeometric mass of the tables with MI >= observed,
-                              summed from log-factorials) instead of a Monte-Carlo estimate; their
-                              row_exceed is LGMI_EXCEED_EXACT.  Larger tables keep the n_shuffles
-                              estimate (row_p NaN, row_exceed LGMI_EXCEED_EXACT when n_shuffles == 0) */
+    uint8_t  exact_2x2;    /* 1: rows whose permutation p has an exact form within reach get the EXACT p (the
+                              hypergeometric mass of the tables with MI >= observed) instead of a Monte-Carlo
+                              estimate; their row_exceed is LGMI_EXCEED_EXACT.  These are: tables with at most 2
+                              non-empty classes per site (summed from log-factorials); since ABI 5 also larger
+                              tables with few candidate tables (enumeration) and 3 x 2 / 2 x 3 tables whose region
+                              {MI < observed} has at most 2^20 chords (perimeter walk).  The other
+                              larger tables keep the n_shuffles estimate (row_p NaN, row_exceed LGMI_EXCEED_EXACT
+                              when n_shuffles == 0) */
     uint8_t  no_row_p;     /* 1: when every row_p is a function of its row_exceed — Monte-Carlo estimates,
                               p = (1 + row_exceed) / (n_shuffles + 1), i.e. n_shuffles > 0 without exact_2x2 — the
                               p array is not made at all: lgmi_result.row_p is NULL, row_p_derived is 1 and the

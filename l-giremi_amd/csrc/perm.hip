@@ -487,14 +487,14 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
         } else if (kind == 3) {
             // is any queued row small enough to be enumerated?  (k_perm_enum does nothing otherwise: at north-star its pass
             // over 1.7e7 queued rows, none of which qualifies, was 3 ms)
-            if (rc.y <= pa.enum_max && (unsigned long long)rc.y <= 4ull * (unsigned long long)n_shuffles) any_small = true;
+            if (rc.y <= pa.enum_max && (pa.exact_2x2 || (unsigned long long)rc.y <= 4ull * (unsigned long long)n_shuffles)) any_small = true;
 #if !(LGMI_PABL & 16)
             if (!n_shuffles) { out_exceed[r] = LGMI_EXCEED_EXACT; if (out_p) out_p[r] = __longlong_as_double(0x7ff8000000000000ll); }   // exact_2x2 only: no estimate
 #endif
         }
     }
 #if !(LGMI_PABL & 16)
-    if (n_shuffles) {
+    if (n_shuffles || pa.exact_2x2) {                        // (exact mode: the exact paths for larger tables run without shuffles too)
         // queue the larger tables for k_perm_general.  They are collected in LDS over the wave's chunks and go out 64
         // at a time: one atomic on the queue counter per 64 queued rows.  (One atomic per chunk — 73 % of the chunks
         // have such a row — was 2.6 million atomics on one address, which the L2 serves at ~60 M/s: 14 of this
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64) void k_perm_enum(PermArgs pa)
                 en_mine = en_mine && nt <= pa.enum_max;
                 if (!en_mine) nt = 1ull;
             }
-            en_mine = en_mine && nt <= 4ull * (unsigned long long)n_shuffles;
+            en_mine = en_mine && (pa.exact_2x2 || nt <= 4ull * (unsigned long long)n_shuffles);
             nt_mine = (uint32_t)nt;
         }
         if (second) {
@@ -737,11 +737,21 @@ __global__ __launch_bounds__(64) void k_perm_enum(PermArgs pa)
             if (have) {
                 unsigned long long thr = mass >> 30;
                 if (thr > 4294967296ull) thr = 4294967296ull;
+                if (pa.exact_2x2) {                              // the exact p: the enumerated mass itself
+                    if (sub == 0u) {
+                        double p = (double)mass * 2.168404344971009e-19;
+                        if (p > 1.0) p = 1.0;
+                        out_exceed[r] = LGMI_EXCEED_EXACT;
+                        out_p[r] = p;
+                        if (!second) gen_list[base + (uint32_t)L] = 0xFFFFFFFFu;
+                    }
+                } else {
                 const uint32_t exceed = binom_draw(LF, n_shuffles, thr, ci, cj, k0, k1);   // (every lane of the group the same)
                 if (sub == 0u) {
                     out_exceed[r] = exceed;
                     if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
                     if (!second) gen_list[base + (uint32_t)L] = 0xFFFFFFFFu;   // no second list: k_perm_general skips the row
+                }
                 }
             }
         };
@@ -929,6 +939,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
     const SixLists ls = six_lists(pa);
     unsigned long long box_max = ((unsigned long long)pa.six_pts * (unsigned long long)n_shuffles) >> 4;
     if (box_max > 4194304ull) box_max = 4194304ull;
+    if (pa.exact_2x2) box_max = 1048576ull;                 // the exact-p mode: whatever the walk reaches, with or without shuffles
     __shared__ unsigned long long s_acc[64];                // the rows' inside masses (2^-62, integer sums)
     unsigned int* const next_row = pa.gen_count + 5;
     uint32_t q_next = 0u;
@@ -946,7 +957,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
         int zlo = 0;
         long long sobs = 0;
         double cJ = 0.0, rN = 0.0;
-        unsigned long long thr = 0ull;
+        unsigned long long thr = 0ull, ins_x = 0ull;         // ins_x: the inside mass (2^-62), for the exact-p mode
         if (r != 0xFFFFFFFFu) {
             uint32_t T[9];
 #pragma unroll
@@ -976,7 +987,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 b += (double)N;
                 b += det_log(((double)Ao + 1.0) * ((double)Ap + 1.0));
                 b -= (double)sobs * 3.725290298461914e-09;
-                if (b < -23.1) { st = 3; thr = 0ull; }
+                if (b < -23.1) { st = 3; thr = 0ull; ins_x = 4611686018427387904ull; }
                 else {
                     HG22 hc;
                     hg22_set(hc, N, Ao, B0, 0.0);
@@ -984,7 +995,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                     const uint32_t kcc = kc22(hc);
                     int zhi;
                     inside22(G, hc, kcc, sc, zlo, zhi);
-                    if (zhi - zlo - 1 <= 0) { st = 3; thr = 4294967296ull; }
+                    if (zhi - zlo - 1 <= 0) { st = 3; thr = 4294967296ull; ins_x = 0ull; }
                     else {
                         int zc = (int)kcc;
                         if (zc <= zlo) zc = zlo + 1;
@@ -1121,14 +1132,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
             if (st == 2) {
                 const unsigned long long ins = s_acc[lane];
                 thr = ins <= 4611686018427387904ull ? (4611686018427387904ull - ins) >> 30 : 0ull;
+                ins_x = ins;
                 st = 3;
             }
         }
         // ---- phase D
         if (st == 3) {
-            const uint32_t exceed = binom_draw(LF, n_shuffles, thr, row_i[r] + pa.site_base, row_j[r] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
-            out_exceed[r] = exceed;
-            if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+            if (pa.exact_2x2) {                              // the exact p: one minus the inside mass (six_thr's p_out in the oracle)
+                double p = 1.0 - (double)ins_x * 2.168404344971009e-19;
+                if (p < 0.0) p = 0.0;
+                out_exceed[r] = LGMI_EXCEED_EXACT;
+                out_p[r] = p;
+            } else {
+                const uint32_t exceed = binom_draw(LF, n_shuffles, thr, row_i[r] + pa.site_base, row_j[r] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
+                out_exceed[r] = exceed;
+                if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+            }
             if (!ls.third) ls.in[q] = 0xFFFFFFFFu;          // no third list: k_perm_general skips the row
         }
         const uint32_t done = (uint32_t)__popcll(__ballot(st == 3));        // (statistics)
@@ -1838,7 +1857,7 @@ void launch_perm_fast(hipStream_t st, const PermArgs& a)
 
 void launch_perm_general(hipStream_t st, const PermArgs& a, hipEvent_t after_exact)
 {
-    if (!a.max_rows || !a.n_shuffles) { if (after_exact) (void)hipEventRecord(after_exact, st); return; }
+    if (!a.max_rows || (!a.n_shuffles && !a.exact_2x2)) { if (after_exact) (void)hipEventRecord(after_exact, st); return; }
     // a fixed grid (16 one-wave workgroups per CU, 8 KB of LDS each) whose waves
     // take the queued rows from a shared counter
     // (LGMI_PERM_WPC: one-wave workgroups per CU, for occupancy experiments — tools/abl_perm.sh; 16 = four per SIMD)
@@ -1860,7 +1879,7 @@ void launch_perm_general(hipStream_t st, const PermArgs& a, hipEvent_t after_exa
     if (b.enum_max) hipLaunchKernelGGL(k_perm_enum, dim3(256 * 16), dim3(64), 0, st, b);
     if (b.six_pts) hipLaunchKernelGGL(k_perm_six, dim3(256 * 4 * LGMI_SIX_WPS), dim3(64), 0, st, b);
     if (after_exact) (void)hipEventRecord(after_exact, st);      // enumeration + perimeter walk done: what follows is sampling
-    hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, b);
+    if (a.n_shuffles) hipLaunchKernelGGL(k_perm_general, dim3(256 * wpc), dim3(64), 0, st, b);   // (exact-p mode without shuffles: nothing to sample)
 }
 
 }  // namespace lgmi

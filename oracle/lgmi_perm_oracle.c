@@ -726,8 +726,8 @@ static uint32_t perm_lockstep(const perm_tables* t, const first_table* ft, uint3
  *   exceed   = binom_draw(n_shuffles, min(2^32, mass >> 30), ...)      (the 2 x 2 rows' stream: a row is one or the other)
  */
 static uint32_t ENUM_MAX = 4096u;   /* (a variable only so that tests can switch the enumeration off: lgo_set_enum_max) */
-static int enum_plan(const uint32_t R[3], const uint32_t C[3], uint32_t n_shuffles, uint32_t fa[2], uint32_t fb[2],
-                     uint32_t* la_out, uint32_t* lb_out, uint32_t radix[4], uint64_t* n_tables)
+static int enum_plan_x(const uint32_t R[3], const uint32_t C[3], uint32_t n_shuffles, int exact, uint32_t fa[2], uint32_t fb[2],
+                       uint32_t* la_out, uint32_t* lb_out, uint32_t radix[4], uint64_t* n_tables)
 {
     uint32_t la = 0, lb = 0, a, k = 0;
     uint64_t n = 1;
@@ -741,7 +741,12 @@ static int enum_plan(const uint32_t R[3], const uint32_t C[3], uint32_t n_shuffl
         if (n > ENUM_MAX) return 0;
     }
     *la_out = la; *lb_out = lb; *n_tables = n;
-    return n <= 4ull * (uint64_t)n_shuffles;
+    return exact || n <= 4ull * (uint64_t)n_shuffles;      /* (the exact-p entry enumerates whatever fits ENUM_MAX) */
+}
+static int enum_plan(const uint32_t R[3], const uint32_t C[3], uint32_t n_shuffles, uint32_t fa[2], uint32_t fb[2],
+                     uint32_t* la_out, uint32_t* lb_out, uint32_t radix[4], uint64_t* n_tables)
+{
+    return enum_plan_x(R, C, n_shuffles, 0, fa, fb, la_out, lb_out, radix, n_tables);
 }
 
 static uint64_t enum_mass(const perm_tables* t, const uint32_t R[3], const uint32_t C[3], uint32_t N, int64_t sobs,
@@ -872,7 +877,13 @@ static void six_chord(const perm_tables* t, const six_row* s, int64_t z, hg22* h
 }
 
 /* returns 1 when the row takes the six-cell path at this n_shuffles */
+static int six_plan_x(const perm_tables* t, const uint32_t T[9], uint32_t n_shuffles, int exact, six_row* s);
 static int six_plan(const perm_tables* t, const uint32_t T[9], uint32_t n_shuffles, six_row* s)
+{
+    return six_plan_x(t, T, n_shuffles, 0, s);
+}
+/* exact: the exact-p entry (lgmi_params.exact_2x2): the gate is 2^20 chords + central chord length whatever n_shuffles is */
+static int six_plan_x(const perm_tables* t, const uint32_t T[9], uint32_t n_shuffles, int exact, six_row* s)
 {
     uint32_t R[3], C[3], nzr[3], nzc[3], nr = 0, nc = 0, a, N = 0;
     uint64_t box_max, box;
@@ -915,6 +926,7 @@ static int six_plan(const perm_tables* t, const uint32_t T[9], uint32_t n_shuffl
     box = (uint64_t)(s->zhi - s->zlo - 1) + (uint64_t)(len > 1 ? len : 1);
     box_max = ((uint64_t)SIX_PTS * (uint64_t)n_shuffles) >> 4;
     if (box_max > 4194304ull) box_max = 4194304ull;         /* 2^22 */
+    if (exact) box_max = 1048576ull;                        /* 2^20 */
     return box <= box_max;
 }
 
@@ -1104,17 +1116,24 @@ static uint32_t perm_one(const perm_tables* t, const uint32_t T[9], uint32_t row
         {
             uint32_t fa[2], fb[2], la, lb, radix[4];
             uint64_t n_tables;
-            if (enum_plan(R, C, n_shuffles, fa, fb, &la, &lb, radix, &n_tables)) {
-                uint64_t thr = enum_mass(t, R, C, N, sobs, fa, fb, la, lb, radix, n_tables) >> 30;
+            if (enum_plan_x(R, C, n_shuffles, ptail_out != NULL, fa, fb, &la, &lb, radix, &n_tables)) {
+                const uint64_t mass = enum_mass(t, R, C, N, sobs, fa, fb, la, lb, radix, n_tables);
+                uint64_t thr = mass >> 30;
                 if (thr > 4294967296ull) thr = 4294967296ull;
+                if (ptail_out) { *ptail_out = (double)mass * 2.168404344971009e-19; if (*ptail_out > 1.0) *ptail_out = 1.0; return 0; }
                 return binom_draw(t, n_shuffles, thr, row_i, row_j, k0, k1);
             }
         }
-        if (!ptail_out) {          /* (the exact-p entry keeps NaN for every larger table) */
+        {
+            /* (the exact-p entry, round 4 late: larger tables whose exact mass is within reach — enumeration above, the
+             *  perimeter walk here — return it; the others keep NaN) */
             six_row sx;
-            if (six_plan(t, T, n_shuffles, &sx))
+            if (six_plan_x(t, T, n_shuffles, ptail_out != NULL, &sx)) {
+                if (ptail_out) { (void)six_thr(t, &sx, ptail_out); return 0; }
                 return binom_draw(t, n_shuffles, six_thr(t, &sx, NULL), row_i, row_j, k0, k1);
+            }
         }
+        if (ptail_out) return 0;     /* no exact form within reach: NaN */
         first_table_build(t, N, R[nzr[0]], C[nzc[0]], &ft);   /* the first non-empty row and column */
         if (ft.valid && nr * nc == 6 && N - R[nzr[0]] > 1 && N - C[nzc[0]] > 1)
             hrua_width_bound(&ft, N, (int)nr, R[nzr[0]], R[nzr[1]], C[nzc[0]], C[nzc[1]]);
@@ -1172,9 +1191,10 @@ int lgo_perm_rows(uint64_t n_rows, const uint32_t* row_i, const uint32_t* row_j,
     return 0;
 }
 
-/* exact permutation p of the rows with at most 2 x 2 non-empty classes (lgmi_params.exact_2x2): the mass of the tables
- * with S >= S_obs, summed as in ptail22; 1.0 for degenerate tables; NaN for larger tables (they keep the Monte-Carlo
- * estimate) */
+/* exact permutation p of the rows that have one within reach (lgmi_params.exact_2x2): tables with at most 2 x 2 non-empty
+ * classes (the mass of the tables with S >= S_obs, summed as in ptail22; 1.0 for degenerate tables); larger tables with at
+ * most ENUM_MAX candidate tables (enum_mass); 3 x 2 / 2 x 3 tables whose chords + central chord length are at most 2^20 (one
+ * minus six_inside_walk; 0 when the zero test fires).  NaN for the others (they keep the Monte-Carlo estimate). */
 int lgo_perm_rows_exact(uint64_t n_rows, const uint32_t* counts, double* p_out)
 {
     perm_tables t;

@@ -272,7 +272,8 @@ def test_permutation_p_large_counts_and_tri_sites(engine, n_reads, S):
 def test_exact_2x2_p_matches_cpu_specification(engine):
     """lgmi_params.exact_2x2: rows with at most 2 x 2 non-empty classes return the exact mass of the tables at least
     as extreme (bit-equal to the CPU specification, itself checked against brute-force enumeration in
-    tests/test_perm_oracle.py); larger tables keep the Monte-Carlo estimate, or NaN when n_shuffles == 0"""
+    tests/test_perm_oracle.py); so do, since round 4, larger tables within reach of the enumeration or of the six-cell
+    perimeter walk; the other larger tables keep the Monte-Carlo estimate, or NaN when n_shuffles == 0"""
     from lgmi._lib import EXCEED_EXACT
     from oracle import c_oracle
     pb = random_batch(8181, n_blocks=3, tri_frac=0.3, R=(6, 900))
@@ -280,6 +281,9 @@ def test_exact_2x2_p_matches_cpu_specification(engine):
     exact = c_oracle.perm_rows_exact(base.row_counts)
     small = ~np.isnan(exact)
     assert small.any() and (~small).any()
+    c = base.row_counts.reshape(-1, 3, 3)
+    shape = (c.sum(axis=2) > 0).sum(axis=1) * (c.sum(axis=1) > 0).sum(axis=1)
+    assert (small & (shape == 6)).sum() > 20 and (small & (shape == 9)).any()      # exact p of 3 x 2 / 2 x 3 and of small 3 x 3 tables
     only = engine.run(pb, min_common=3, het_only=False, n_shuffles=0, exact_2x2=True, emit_counts=True)
     np.testing.assert_array_equal(only.row_counts, base.row_counts)
     np.testing.assert_array_equal(only.row_p, exact)                         # NaN-aware, bit for bit

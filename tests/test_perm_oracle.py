@@ -653,3 +653,16 @@ def test_six_cell_path_and_sampling_path_agree(lib, T):
     _p, ex_six = run_perm([T], S)
     assert abs(ex_mc[0] / S - exact) < 5 * sd + 2e-4 and abs(ex_six[0] / S - exact) < 5 * sd + 2e-4
     assert abs(o['thr'] * 2.0 ** -32 - exact) < 1e-8
+
+
+def test_exact_p_entry_covers_enumerated_and_six_cell_tables():
+    """what lgmi_params.exact_2x2 returns for larger tables (round 4): the enumerated mass for tables with few candidates,
+    one minus the perimeter walk's inside mass for 3 x 2 / 2 x 3 tables, NaN where neither reaches — against brute force"""
+    small = ENUM_TABLES[:4] + ENUM_TABLES[5:7]              # (ENUM_TABLES[4] has more than 4096 candidate tables)
+    tables = small + LOCKSTEP_TABLES + [ENUM_TABLES[4], [300, 200, 100, 150, 250, 90, 80, 120, 310]]
+    p = c_oracle.perm_rows_exact(np.array(tables))
+    for T, got in zip(small, p[:6]):
+        assert abs(got - exact_p_fast(T)) < 1e-10, T
+    for T, got in zip(LOCKSTEP_TABLES, p[6:11]):
+        assert abs(got - brute_ptail_six(T)) < 2e-9, T
+    assert np.isnan(p[11]) and np.isnan(p[12])              # 3 x 3 tables beyond the enumeration: no exact form within reach
