@@ -184,7 +184,7 @@ def _eight_worker(rank, world, port, q):
 
 def test_eight_ranks_share_one_block():
     """world = 8, the size the driver's scaling run uses (a GPU box admits 6 processes on its card, so the 8-rank case of the
-    wire logic runs here on the CPU; tests/test_gpu_gather2.py carries 2, 3 and 5 ranks through the device code)"""
+    wire logic runs here on the CPU; tests/test_gpu_gather2.py carries 2, 3 and 4 ranks through the device code)"""
     world = 8
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -31,7 +31,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('world', [2, 3, 5])      # (a test box admits 6 processes on its card, the test runner being one; 8 ranks: tests/test_dist_gloo.py)
+@pytest.mark.parametrize('world', [2, 3, 4])      # (a test box admits 6 processes on its card, the test runner being one: 4 leaves a margin; 8 ranks: tests/test_dist_gloo.py)
 def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world):
     port = free_port()
     procs = []
