@@ -233,7 +233,7 @@ __device__ Tail22 bounds22(TabG G, const HG22& h, uint32_t kobs) {
 // Exact mass of UNIT = 64 consecutive values k0 .. k0 + len - 1 in units of 2^-62: first term from the
 // log-factorials (four table lines per unit — scattered 8-byte look-ups are what the L2 charges for), the
 // following ones through the hypergeometric ratio carried division-free over sub-blocks of SUB = 16 steps
-// (N <- N num, Q <- Q den, P <- fma(P, den, N); then sum += t P / Q, t <- t N / Q), truncated to the fixed-point
+// (N <- N num, Q <- Q den, P <- fma(P, den, N); then rQ = 1 / Q, sum += (t P) rQ, t <- (t N) rQ), truncated to the fixed-point
 // grid.  The mass of a range is the INTEGER sum of its units: it does not depend on which lane sums which unit
 // or on the order of the additions (CPU specification: unit_mass / range_mass in oracle/lgmi_perm_oracle.c).
 #ifndef LGMI_UNIT
@@ -264,8 +264,9 @@ __device__ __forceinline__ double unit_sum(TabLF LF, const HG22& h, uint32_t k0,
             P = fma(P, den, Nn);
             num -= sn; den += sd; sn -= 2.0; sd += 2.0;
         }
-        sum += term * P / Q;
-        term = term * Nn / Q;
+        const double rQ = 1.0 / Q;                       // (round 4: one division per sub-block instead of two, both sides)
+        sum += (term * P) * rQ;
+        term = (term * Nn) * rQ;
         k += m;
         rem -= m;
     }
@@ -915,7 +916,7 @@ __device__ __forceinline__ void walk_sum(TabLF LF, const HG22& h, int lo, int hi
             P = fma(P, den, Nn);
             num -= sn; den += sd; sn -= 2.0; sd += 2.0;
         }
-        const double rQ = 1.0 / Q;                       // (one division per sub-block; unit_mass, the 2 x 2 rows' specification, keeps its two)
+        const double rQ = 1.0 / Q;                       // (one division per sub-block, as unit_sum)
         sum += (term * P) * rQ;
         term = (term * Nn) * rQ;
         k += m;

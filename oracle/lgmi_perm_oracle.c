@@ -378,7 +378,7 @@ static double pmf22(const perm_tables* t, const hg22* h, uint32_t k)
  * (one look-up of four table lines per 64 values), the following ones through the hypergeometric ratio
  *     pmf(k+1) = pmf(k) (K-k)(n-k) / ((k+1)(N-K-n+k+1))
  * carried division-free over sub-blocks of SUB = 16 steps:  N <- N num,  Q <- Q den,  P <- fma(P, den, N), then
- * sum += t P / Q and t <- t N / Q (products of 16 factors below 2^52 stay inside the double range) — and
+ * rQ = 1 / Q, sum += (t P) rQ and t <- (t N) rQ (products of 16 factors below 2^52 stay inside the double range) — and
  * truncated to the fixed-point grid.  The mass of a range is the INTEGER sum of its units, so it does not depend
  * on how units are dealt to GPU lanes or in which order they are added. */
 #define UNIT 64
@@ -400,8 +400,11 @@ static uint64_t unit_mass(const perm_tables* t, const hg22* h, int64_t k0, int64
             P = fma(P, den, Nn);
             a -= 1.0; b -= 1.0; c += 1.0; d += 1.0;
         }
-        sum += term * P / Q;
-        term = term * Nn / Q;
+        {
+            const double rQ = 1.0 / Q;                   /* (round 4: one division per sub-block, two products) */
+            sum += (term * P) * rQ;
+            term = (term * Nn) * rQ;
+        }
         k += (uint32_t)m;
         rem -= m;
     }
