@@ -257,7 +257,10 @@ __device__ __forceinline__ double unit_sum(TabLF LF, const HG22& h, uint32_t k0,
         // (unrolling the full sub-blocks — no per-step loop test on the per-lane trip count, 7 instead of 9 vector
         //  instructions per value — was measured SLOWER, 56 ms against 51: the full and the partial sub-blocks of a
         //  wave's lanes then run one after the other; so were units of 128 or 256 values, 60 / 63 ms)
-#pragma unroll 1
+#ifndef LGMI_UNIT_UNROLL
+#define LGMI_UNIT_UNROLL 2      // (1: 46.9 ms, 2: 46.1, 4: 46.6 for k_perm_fast at north-star; the same arithmetic in the same order)
+#endif
+#pragma unroll LGMI_UNIT_UNROLL
         for (uint32_t j = 0; j < m; ++j) {
             Nn = Nn * num;
             Q = Q * den;
