@@ -173,31 +173,32 @@ struct Tail22 { long long klo, khi; int centre; double var; };
 // a monotone predicate, whatever the search order, so it is the one the specification's plain bisection finds — in
 // ~6 probes instead of log2(range) ~ 16 when the guess is a few values off.  (Each probe is four dependent scattered
 // look-ups of G[]: the plain bisection was 50 of k_perm_fast's 85 ms at north-star, tools/abl_perm.sh 80.)
+// (32-bit integers: every count here is below 2^28)
 template <class P>
-__device__ __forceinline__ long long first_true(long long lo, long long hi, long long g, P pred) {
+__device__ __forceinline__ int first_true32(int lo, int hi, int g, P pred) {
     if (g < lo) g = lo;
     if (g > hi) g = hi;
-    long long l, r;                                    // pred(r) holds; pred(l) does not (or l == lo - 1)
-    if (g == hi || pred(g)) {                          // the boundary is at g or left of it
+    int l, r;                                          // pred(r) holds; pred(l) does not (or l == lo - 1)
+    if (g == hi || pred(g)) {
         r = g; l = lo - 1;
-        long long step = 1;
+        int step = 1;
         while (r > lo) {
-            long long c = r - step;
+            int c = r - step;
             if (c < lo) c = lo;
             if (pred(c)) { r = c; step <<= 1; } else { l = c; break; }
         }
-    } else {                                           // right of it
+    } else {
         l = g; r = hi;
-        long long step = 1;
+        int step = 1;
         for (;;) {
-            const long long c = l + step;
+            const int c = l + step;
             if (c >= hi) break;
             if (pred(c)) { r = c; break; }
             l = c; step <<= 1;
         }
     }
     while (r - l > 1) {
-        const long long mid = l + (r - l) / 2;
+        const int mid = l + ((r - l) >> 1);
         if (pred(mid)) r = mid; else l = mid;
     }
     return r;
@@ -214,13 +215,13 @@ __device__ Tail22 bounds22(TabG G, const HG22& h, uint32_t kobs) {
     if (kobs <= kc) {
         // first k in [kc + 1, kmax + 1] with S(k) >= sobs (kmax + 1: none)
         t.klo = kobs;
-        t.khi = first_true((long long)kc + 1, (long long)h.kmax + 1, mirror,
-                           [&](long long k) { return stat22(G, h, (uint32_t)k) >= sobs; });
+        t.khi = first_true32((int)kc + 1, (int)h.kmax + 1, (int)mirror,
+                             [&](int k) { return stat22(G, h, (uint32_t)k) >= sobs; });
     } else {
         // last k in [kmin - 1, kc] with S(k) >= sobs (kmin - 1: none): the same search on the reflected axis
-        const long long lo = (long long)h.kmin - 1, hi = (long long)kc, refl = lo + hi;
+        const int lo = (int)h.kmin - 1, hi = (int)kc, refl = lo + hi;
         t.khi = kobs;
-        t.klo = refl - first_true(lo, hi, refl - mirror, [&](long long j) { return stat22(G, h, (uint32_t)(refl - j)) >= sobs; });
+        t.klo = refl - first_true32(lo, hi, refl - (int)mirror, [&](int j) { return stat22(G, h, (uint32_t)(refl - j)) >= sobs; });
     }
     const double var = (double)h.n * (double)h.K * (double)(h.N - h.K) * (double)(h.N - h.n) /
                        ((double)h.N * (double)h.N * (double)(h.N > 1 ? h.N - 1 : 1));
@@ -839,36 +840,6 @@ __device__ __forceinline__ void hg22_set(HG22& h, uint32_t N, uint32_t K, uint32
     h.kmin = K + n > N ? K + n - N : 0u;
     h.kmax = K < n ? K : n;
     h.c0 = c0;
-}
-// first_true on 32-bit integers (every count here is below 2^28)
-template <class P>
-__device__ __forceinline__ int first_true32(int lo, int hi, int g, P pred) {
-    if (g < lo) g = lo;
-    if (g > hi) g = hi;
-    int l, r;                                          // pred(r) holds; pred(l) does not (or l == lo - 1)
-    if (g == hi || pred(g)) {
-        r = g; l = lo - 1;
-        int step = 1;
-        while (r > lo) {
-            int c = r - step;
-            if (c < lo) c = lo;
-            if (pred(c)) { r = c; step <<= 1; } else { l = c; break; }
-        }
-    } else {
-        l = g; r = hi;
-        int step = 1;
-        for (;;) {
-            const int c = l + step;
-            if (c >= hi) break;
-            if (pred(c)) { r = c; break; }
-            l = c; step <<= 1;
-        }
-    }
-    while (r - l > 1) {
-        const int mid = l + ((r - l) >> 1);
-        if (pred(mid)) r = mid; else l = mid;
-    }
-    return r;
 }
 #ifndef LGMI_SIXABL
 #define LGMI_SIXABL 0     // timing-only ablations of k_perm_six (results wrong by construction; tools/abl_six.sh): 1 the maps' sums
