@@ -666,3 +666,26 @@ def test_exact_p_entry_covers_enumerated_and_six_cell_tables():
     for T, got in zip(LOCKSTEP_TABLES, p[6:11]):
         assert abs(got - brute_ptail_six(T)) < 2e-9, T
     assert np.isnan(p[11]) and np.isnan(p[12])              # 3 x 3 tables beyond the enumeration: no exact form within reach
+
+
+@pytest.mark.parametrize('T', [[0, 0, 0, 0, 30, 14, 0, 12, 28], [12, 30, 0, 60, 45, 0, 40, 28, 0], [0, 0, 0, 40, 35, 20, 25, 60, 18],
+                               [10, 3, 2, 2, 9, 4, 1, 3, 12]], ids=['2x2', '3x2', '2x3', '3x3'])
+def test_p_is_the_literal_label_shuffle_test_of_the_references_statistic(T):
+    """the DEFINITION, literally and independently of every table-level shortcut of the specification: expand the table into
+    the two label vectors the reference hands to scikit-learn (src/giremi/mutual_information.py:25-41), shuffle one of them
+    with numpy, recompute sklearn.metrics.mutual_info_score, count MI_s >= MI_obs.  The specification's exceed / S (2 x 2:
+    exact tail + binomial; 3 x 2 / 2 x 3: perimeter walk + binomial; 3 x 3: enumeration or sampled tables) must agree with
+    that proportion within binomial noise — on both sides of the comparison"""
+    from sklearn.metrics import mutual_info_score
+    M = np.asarray(T).reshape(3, 3)
+    a = np.repeat(np.arange(3), M.sum(axis=1))
+    b = np.concatenate([np.repeat(np.arange(3), M[k]) for k in range(3)])
+    obs = mutual_info_score(a, b)
+    rng = np.random.default_rng(99)
+    S_lit = 4000
+    hits = sum(mutual_info_score(a, rng.permutation(b)) >= obs - 1e-12 for _ in range(S_lit))
+    S = 40000
+    _p, ex = run_perm([T], S)
+    p_lit, p_spec = hits / S_lit, ex[0] / S
+    sd = np.sqrt(p_lit * (1 - p_lit) / S_lit + p_spec * (1 - p_spec) / S + 1e-9)
+    assert abs(p_lit - p_spec) < 4.5 * sd + 1e-3, (p_lit, p_spec)
