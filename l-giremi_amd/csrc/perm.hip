@@ -345,9 +345,14 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int 
     return ((unsigned long long)bcast32((uint32_t)(v >> 32), L) << 32) | bcast32((uint32_t)v, L);
 }
 
-// (no amdgpu_waves_per_eu here: pinned to 4 waves per SIMD the kernel took 53.7 ms, to 5 — it fits without spilling —
-//  51.1, left to the compiler 50.1: profiles/r04_perm_occupancy.txt)
+// (no amdgpu_waves_per_eu by default: pinned to 4 waves per SIMD the kernel took 53.7 ms, to 5 51.1, left to the compiler 50.1;
+//  after the compaction of round 4 — 105 VGPRs — 47.0 as it is, 48.3 at five waves (96 + 2 spilled), 53.9 at six:
+//  profiles/r04_perm_occupancy.txt.  -DLGMI_FAST_WPS=n pins it for such experiments.)
+#ifdef LGMI_FAST_WPS
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_FAST_WPS, LGMI_FAST_WPS))) void k_perm_fast(PermArgs pa)
+#else
 __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
+#endif
 {
     const uint64_t n_rows = *pa.n_rows_dev;
     const uint32_t* __restrict__ row_i = pa.row_i; const uint32_t* __restrict__ row_j = pa.row_j;
