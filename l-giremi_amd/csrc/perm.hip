@@ -284,7 +284,7 @@ __device__ __forceinline__ unsigned long long unit_mass(TabLF LF, const HG22& h,
 // variate instead of n_shuffles Bernoulli trials (the CPU specification is binom_draw in
 // oracle/lgmi_perm_oracle.c).  thr = trunc(P * 2^32).  n p < 10: sequential inversion (BINV), otherwise
 // Hoermann's transformed rejection (BTRS) tested against the exact log-factorials.  One lane per row.
-__device__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned long long thr, uint32_t ci,
+__device__ __forceinline__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned long long thr, uint32_t ci,
                                uint32_t cj, uint32_t k0, uint32_t k1) {
     if (thr == 0ull || n == 0u) return 0u;
     if (thr >= 4294967296ull) return n;
@@ -293,22 +293,28 @@ __device__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned long long thr, uin
     const double p = (double)tt * 2.3283064365386963e-10;
     const double q = 1.0 - p;
     const double np = (double)n * p;
-    uint32_t call = 0u, k = 0u;
+    uint32_t trip = 0u, k = 0u;
+    // trial t takes words (0, 1) of Philox call t / 2 when t is even, words (2, 3) of the same call when odd: the trials of a
+    // wave's lanes run in step, so a call is made on every other trip only, and the first one serves both algorithms
+    U4 o = philox4x32_10(0u, ci, cj, TAG_PERM2X2, k0, k1);
     if (np < 10.0) {
         const double qn = det_exp((double)n * det_log(q));
         const double lim = np + 10.0 * det_sqrt(np * q + 1.0);
         const uint32_t bound = lim < (double)n ? (uint32_t)lim : n;
+        const double pq = p / q;
         for (;;) {
-            const U4 o = philox4x32_10(call++, ci, cj, TAG_PERM2X2, k0, k1);
-            double u = ((double)(((unsigned long long)o.x << 20) | (unsigned long long)(o.y >> 12)) + 0.5) * 2.220446049250313e-16;
-            double px = qn;
+            const uint32_t w0 = (trip & 1u) ? o.z : o.x, w1 = (trip & 1u) ? o.w : o.y;
+            // inversion on the scale of x!: U = x! (u - F(x - 1)), T = x! f(x) — no division per step
+            double U = ((double)(((unsigned long long)w0 << 20) | (unsigned long long)(w1 >> 12)) + 0.5) * 2.220446049250313e-16;
+            double T = qn;
             uint32_t x = 0u;
-            while (u > px && x <= bound) {
+            while (U > T && x <= bound) {
                 ++x;
-                u -= px;
-                px = ((double)(n - x + 1u) * p * px) / ((double)x * q);
+                U = (U - T) * (double)x;
+                T = T * ((double)(n - x + 1u) * pq);
             }
             if (x <= bound) { k = x; break; }
+            if (!(++trip & 1u)) o = philox4x32_10(trip >> 1, ci, cj, TAG_PERM2X2, k0, k1);
         }
     } else {
         const double spq = det_sqrt(np * q);
@@ -322,18 +328,20 @@ __device__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned long long thr, uin
         const double lr = det_log(p / q);
         const double hm = LF[m] + LF[n - m];
         for (;;) {
-            const U4 o = philox4x32_10(call++, ci, cj, TAG_PERM2X2, k0, k1);
-            const double u = ((double)o.x + 0.5) * 2.3283064365386963e-10 - 0.5;
-            double v = ((double)o.y + 0.5) * 2.3283064365386963e-10;
+            const uint32_t w0 = (trip & 1u) ? o.z : o.x, w1 = (trip & 1u) ? o.w : o.y;
+            const double u = ((double)w0 + 0.5) * 2.3283064365386963e-10 - 0.5;
+            double v = ((double)w1 + 0.5) * 2.3283064365386963e-10;
             const double us = 0.5 - fabs(u);
             const double rus = 1.0 / us;
             const double kf = floor((2.0 * a * rus + b) * u + c);
-            if (kf < 0.0 || kf > (double)n) continue;
-            k = (uint32_t)kf;
-            if (us >= 0.07 && v <= vr) break;
-            v = v * alpha / (a * rus * rus + b);
-            const double h = hm - LF[k] - LF[n - k] + ((double)k - (double)m) * lr;
-            if (v <= det_exp(h)) break;
+            if (kf >= 0.0 && kf <= (double)n) {
+                k = (uint32_t)kf;
+                if (us >= 0.07 && v <= vr) break;
+                v = v * alpha / (a * rus * rus + b);
+                const double h = hm - LF[k] - LF[n - k] + ((double)k - (double)m) * lr;
+                if (v <= det_exp(h)) break;
+            }
+            if (!(++trip & 1u)) o = philox4x32_10(trip >> 1, ci, cj, TAG_PERM2X2, k0, k1);
         }
     }
     return flip ? n - k : k;

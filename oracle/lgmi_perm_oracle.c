@@ -482,16 +482,19 @@ static uint64_t ptail22(const perm_tables* t, const hg22* h, uint32_t kobs, doub
  * number of such shuffles among n_shuffles is Binomial(n_shuffles, P) and is drawn as ONE binomial variate
  * instead of n_shuffles Bernoulli trials.  P enters as thr = trunc(P * 2^32) in units of 2^-32.
  *   thr == 0 -> 0;  thr >= 2^32 -> n;  thr > 2^31: n - Binomial(n, 1 - p)  (1 - p is exact)
- *   n p < 10 : sequential inversion from 0 (BINV; restart with fresh uniforms beyond np + 10 sqrt(npq + 1))
+ *   n p < 10 : sequential inversion from 0 (BINV; restart with fresh uniforms beyond np + 10 sqrt(npq + 1)), carried on
+ *              the scale of x! — U = x! (u - F(x - 1)) against T = x! f(x): U <- (U - T) x, T <- T (n - x + 1) (p / q) —
+ *              so that a step has no division (round 4; 44! = 2.7e54 is the largest factor)
  *   else     : Hoermann's transformed rejection BTRS (1993), the acceptance test taken against the exact
  *              log-factorial table: v alpha / (a / us^2 + b) <= f(k) / f(m); its quotients by b and by us are products
  *              with ONE reciprocal each (rb = 1 / b, rus = 1 / us: round 4)
- * Uniforms: Philox4x32-10, counter (call, row_i, row_j, TAG_PERM2X2), call = 0, 1, ... one call per BTRS
- * candidate (words 0 and 1 -> (w + 0.5) 2^-32) or per inversion run (words 0, 1 -> 52 bits + half an ulp). */
+ * Uniforms: Philox4x32-10, counter (call, row_i, row_j, TAG_PERM2X2): trial t = 0, 1, ... (a BTRS candidate or an
+ * inversion run) takes words (0, 1) of call t / 2 when t is even and words (2, 3) of the same call when t is odd
+ * (round 4: half the calls) — (w + 0.5) 2^-32 each for BTRS, 52 bits + half an ulp for the inversion. */
 static uint32_t binom_draw(const perm_tables* t, uint32_t n, uint64_t thr, uint32_t row_i, uint32_t row_j,
                            uint32_t k0, uint32_t k1)
 {
-    uint32_t out[4], call = 0, k, tt;
+    uint32_t out[4], trip = 0, k, tt;
     int flip;
     double p, q, np;
     if (thr == 0 || n == 0) return 0;
@@ -501,21 +504,23 @@ static uint32_t binom_draw(const perm_tables* t, uint32_t n, uint64_t thr, uint3
     p = (double)tt * 2.3283064365386963e-10;
     q = 1.0 - p;
     np = (double)n * p;
+    philox(0, row_i, row_j, TAG_PERM2X2, k0, k1, out);
     if (np < 10.0) {
         const double qn = lgo_det_exp((double)n * lgo_det_log(q));
         const double lim = np + 10.0 * lgo_det_sqrt(np * q + 1.0);
         const uint32_t bound = lim < (double)n ? (uint32_t)lim : n;
+        const double pq = p / q;
         for (;;) {
-            double px = qn, u;
+            const uint32_t w0 = out[(trip & 1u) * 2u], w1 = out[(trip & 1u) * 2u + 1u];
+            double U = ((double)(((uint64_t)w0 << 20) | (w1 >> 12)) + 0.5) * 2.220446049250313e-16, T = qn;
             uint32_t x = 0;
-            philox(call++, row_i, row_j, TAG_PERM2X2, k0, k1, out);
-            u = ((double)(((uint64_t)out[0] << 20) | (out[1] >> 12)) + 0.5) * 2.220446049250313e-16;
-            while (u > px && x <= bound) {
+            while (U > T && x <= bound) {
                 ++x;
-                u -= px;
-                px = ((double)(n - x + 1u) * p * px) / ((double)x * q);
+                U = (U - T) * (double)x;
+                T = T * ((double)(n - x + 1u) * pq);
             }
             if (x <= bound) { k = x; break; }
+            if (!(++trip & 1u)) philox(trip >> 1, row_i, row_j, TAG_PERM2X2, k0, k1, out);
         }
     } else {
         const double spq = lgo_det_sqrt(np * q);
@@ -529,19 +534,21 @@ static uint32_t binom_draw(const perm_tables* t, uint32_t n, uint64_t thr, uint3
         const double lr = lgo_det_log(p / q);
         const double hm = t->LF[m] + t->LF[n - m];
         for (;;) {
-            double u, v, us, rus, kf, h;
-            philox(call++, row_i, row_j, TAG_PERM2X2, k0, k1, out);
-            u = ((double)out[0] + 0.5) * 2.3283064365386963e-10 - 0.5;
-            v = ((double)out[1] + 0.5) * 2.3283064365386963e-10;
-            us = 0.5 - fabs(u);
-            rus = 1.0 / us;
-            kf = floor((2.0 * a * rus + b) * u + c);
-            if (kf < 0.0 || kf > (double)n) continue;
-            k = (uint32_t)kf;
-            if (us >= 0.07 && v <= vr) break;
-            v = v * alpha / (a * rus * rus + b);
-            h = hm - t->LF[k] - t->LF[n - k] + ((double)k - (double)m) * lr;
-            if (v <= lgo_det_exp(h)) break;
+            const uint32_t w0 = out[(trip & 1u) * 2u], w1 = out[(trip & 1u) * 2u + 1u];
+            const double u = ((double)w0 + 0.5) * 2.3283064365386963e-10 - 0.5;
+            double v = ((double)w1 + 0.5) * 2.3283064365386963e-10;
+            const double us = 0.5 - fabs(u);
+            const double rus = 1.0 / us;
+            const double kf = floor((2.0 * a * rus + b) * u + c);
+            if (kf >= 0.0 && kf <= (double)n) {
+                double h;
+                k = (uint32_t)kf;
+                if (us >= 0.07 && v <= vr) break;
+                v = v * alpha / (a * rus * rus + b);
+                h = hm - t->LF[k] - t->LF[n - k] + ((double)k - (double)m) * lr;
+                if (v <= lgo_det_exp(h)) break;
+            }
+            if (!(++trip & 1u)) philox(trip >> 1, row_i, row_j, TAG_PERM2X2, k0, k1, out);
         }
     }
     return flip ? n - k : k;
