@@ -198,9 +198,9 @@ struct lgmi_dbatch {
     std::vector<uint32_t> block_n_reads;
     std::vector<int64_t> pos;
     std::vector<uint8_t> type, tri;
-    std::vector<Col> cols;               // [n_cols]
-    std::vector<uint32_t> pseudo_site;   // site of each pseudo column
-    std::vector<uint32_t> pseudo_of_site;// column id of the site's pseudo column or NONE
+    PodVec<Col> cols;                    // [n_cols]  (PodVec: written once, in parallel — a value-initialising resize of 27 MB
+    PodVec<uint32_t> pseudo_site;        // site of each pseudo column          and a second one that moved it were 4 of the
+    PodVec<uint32_t> pseudo_of_site;     // column id of the site's pseudo column or NONE       upload's 11 ms on 1.1 M sites)
     uint32_t max_reads = 0;
     // download buffers
     std::vector<uint32_t> dl_word_off, dl_n_words;
@@ -396,22 +396,52 @@ static int validate_batch(const lgmi_batch* b) {
     }
     if (b->block_site_begin[0] != 0 || b->block_site_begin[b->n_blocks] != b->n_sites)
         return fail(LGMI_E_ARG, "block_site_begin must start at 0 and end at n_sites");
-    for (uint64_t k = 0; k < b->n_blocks; ++k) {
+    // one block's checks; says == false only finds out whether the block is good (the threads of a large batch), true
+    // reports the first defect through fail() (on the caller's thread: the message is thread-local)
+    auto check_block = [&](uint64_t k, bool says) -> int {
         uint64_t sb = b->block_site_begin[k], se = b->block_site_begin[k + 1];
-        if (se < sb) return fail(LGMI_E_ARG, "block_site_begin not monotone at block %llu", (unsigned long long)k);
+        if (se < sb || se > b->n_sites) return says ? fail(LGMI_E_ARG, "block_site_begin not monotone at block %llu", (unsigned long long)k) : LGMI_E_ARG;
         uint64_t W = ((uint64_t)b->block_n_reads[k] + 63) / 64;
         for (uint64_t s = sb; s < se; ++s) {
-            if (b->site_type[s] > 2) return fail(LGMI_E_ARG, "site %llu: type %u", (unsigned long long)s, b->site_type[s]);
-            if ((uint64_t)b->site_word_off[s] + b->site_n_words[s] > W)
+            const bool bad_type = b->site_type[s] > 2, bad_band = (uint64_t)b->site_word_off[s] + b->site_n_words[s] > W,
+                       bad_planes = b->site_plane_off[s] + 2ull * b->site_n_words[s] > b->n_plane_words,
+                       bad_pos = s > sb && b->site_pos[s] <= b->site_pos[s - 1];
+            if (!(bad_type | bad_band | bad_planes | bad_pos)) continue;
+            if (!says) return LGMI_E_ARG;
+            if (bad_type) return fail(LGMI_E_ARG, "site %llu: type %u", (unsigned long long)s, b->site_type[s]);
+            if (bad_band)
                 return fail(LGMI_E_ARG, "site %llu: band [%u,+%u) exceeds %llu words of block %llu",
                             (unsigned long long)s, b->site_word_off[s], b->site_n_words[s], (unsigned long long)W,
                             (unsigned long long)k);
-            if (b->site_plane_off[s] + 2ull * b->site_n_words[s] > b->n_plane_words)
-                return fail(LGMI_E_ARG, "site %llu: planes exceed n_plane_words", (unsigned long long)s);
-            if (s > sb && b->site_pos[s] <= b->site_pos[s - 1])
-                return fail(LGMI_E_ARG, "site %llu: positions must increase strictly inside a block", (unsigned long long)s);
+            if (bad_planes) return fail(LGMI_E_ARG, "site %llu: planes exceed n_plane_words", (unsigned long long)s);
+            return fail(LGMI_E_ARG, "site %llu: positions must increase strictly inside a block", (unsigned long long)s);
         }
+        return LGMI_OK;
+    };
+    const unsigned T = b->n_sites >= (1u << 16) ? plan_threads(b->n_blocks) : 1u;
+    if (T <= 1) {
+        for (uint64_t k = 0; k < b->n_blocks; ++k) { const int rc = check_block(k, true); if (rc) return rc; }
+        return LGMI_OK;
     }
+    // a million sites were 1 ms of a one-shot call on one thread: blocks in ranges of equal site counts, the first bad block
+    // of every range, the earliest of them reported exactly as the serial loop would
+    std::vector<uint64_t> first_bad(T, ~0ull);
+    Team team(T);
+    team.run([&](unsigned t) {
+        const uint64_t s_lo = b->n_sites * t / T, s_hi = b->n_sites * (t + 1) / T;
+        // the blocks whose first site lies in [s_lo, s_hi): block_site_begin is only trusted as far as it has been checked,
+        // so the range is found by a bounded binary search over indices and every block re-checks its own bounds
+        auto lower = [&](uint64_t v) { uint64_t lo = 0, hi = b->n_blocks; while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (b->block_site_begin[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
+        const uint64_t k0 = t == 0 ? 0 : lower(s_lo), k1 = t + 1 == T ? b->n_blocks : lower(s_hi);
+        for (uint64_t k = k0; k < k1; ++k) if (check_block(k, false)) { first_bad[t] = k; break; }
+    });
+    // (a non-monotone block_site_begin can make the ranges overlap or leave gaps: the blocks are then checked one by one)
+    bool monotone = true;
+    for (uint64_t k = 0; k < b->n_blocks && monotone; ++k) monotone = b->block_site_begin[k] <= b->block_site_begin[k + 1];
+    if (!monotone) { for (uint64_t k = 0; k < b->n_blocks; ++k) { const int rc = check_block(k, true); if (rc) return rc; } return LGMI_OK; }
+    uint64_t kb = ~0ull;
+    for (unsigned t = 0; t < T; ++t) kb = std::min(kb, first_bad[t]);
+    if (kb != ~0ull) return check_block(kb, true);
     return LGMI_OK;
 }
 
@@ -448,6 +478,7 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     db->pos.assign(b->site_pos, b->site_pos + ns);
     db->type.assign(b->site_type, b->site_type + ns);
     for (uint64_t k = 0; k < b->n_blocks; ++k) db->max_reads = std::max(db->max_reads, b->block_n_reads[k]);
+    tr.mark("host_copies");
 
     hipStream_t st = ctx->stream;
     uint64_t* d_planes = nullptr; uint64_t* d_poff = nullptr; uint32_t* d_nw = nullptr; uint32_t* d_pseudo = nullptr;
@@ -471,13 +502,12 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     tr.mark("tri_flags");
     // column table: real sites, then one pseudo column per tri site.  On several threads over site ranges (a prefix over
     // the ranges gives each its offsets): 1.1 M sites of 20,000 footprints were 4 - 7 ms of a one-shot call on one thread
-    db->pseudo_of_site.assign(ns, NONE);
+    db->pseudo_of_site.resize(ns);
     uint64_t off = 0;
     {
         const unsigned T = plan_threads(ns / 64);
         Team team(T);
         std::vector<uint64_t> w_real(T + 1, 0), w_tri(T + 1, 0), n_tri(T + 1, 0);
-        db->cols.resize(ns);
         team.run([&](unsigned t) {
             const uint64_t s0 = ns * t / T, s1 = ns * (t + 1) / T;
             uint64_t wr = 0, wt = 0, nt = 0;
@@ -494,22 +524,26 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
             for (uint64_t s = s0; s < s1; ++s) {
                 db->cols[s] = Col{o, b->site_word_off[s], b->site_n_words[s]};
                 o += b->site_n_words[s];
+                uint32_t pc = NONE;
                 if (db->tri[s]) {
-                    db->pseudo_of_site[s] = (uint32_t)(ns + np);
+                    pc = (uint32_t)(ns + np);
                     db->pseudo_site[np] = (uint32_t)s;
                     db->cols[ns + np] = Col{op, b->site_word_off[s], b->site_n_words[s]};
                     op += b->site_n_words[s];
                     ++np;
                 }
+                db->pseudo_of_site[s] = pc;
             }
         });
         off = w_real[T] + w_tri[T];
     }
+    tr.mark("cols_built");
     if (db->cols.size() >= 0xFFFFFFF0ull) return fail(LGMI_E_ARG, "too many columns");
     db->d.n_cols = db->cols.size();
     db->d.n_pairs16 = off;
     if ((rc = dev_copy_new(ctx->pool, &db->d.d_cols, db->cols.data(), db->cols.size(), st))) return rc;
     if ((rc = dev_copy_new(ctx->pool, &d_pseudo, db->pseudo_site.data(), db->pseudo_site.size(), st))) return rc;
+    tr.mark("cols_up");
     // one all-zero entry after the last column: k_count_mfma reads it for words outside a column's band
     if ((rc = pool.alloc((void**)&db->d.d_cplanes, (off + 1) * sizeof(ulonglong2)))) return rc;
     HIPCHK(hipMemsetAsync(db->d.d_cplanes + off, 0, sizeof(ulonglong2), st));

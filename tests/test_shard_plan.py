@@ -9,7 +9,7 @@ from oracle import c_oracle
 from util_synth import pack_class_matrix, random_batch, random_block
 
 import lgmi
-from lgmi._lib import EMIT_SEG, NONE
+from lgmi._lib import EMIT_SEG, NONE, LgmiError
 
 
 def item_of_rows(pb, plan, row_i, row_j):
@@ -140,3 +140,49 @@ def test_balance_and_degenerate_inputs():
     assert sum(p['item_end'] - p['item_begin'] for p in got) == got[0]['n_items_total']
     with pytest.raises(lgmi._lib.LgmiError):
         lgmi.plan_shard(tiny, False, (3, 3))
+
+
+def _wide_batch(n_blocks=2200, sites=32, reads=64):
+    """a batch large enough (>= 2^16 sites) for the validation to run on several threads: n_blocks blocks of `sites` sites
+    over one word of reads, every plane word zero"""
+    from lgmi.pack import PackedBatch
+    ns = n_blocks * sites
+    return PackedBatch(block_site_begin=np.arange(0, ns + 1, sites, dtype=np.uint64),
+                       block_n_reads=np.full(n_blocks, reads, np.uint32),
+                       site_pos=np.tile(np.arange(sites, dtype=np.int64) * 7 + 100, n_blocks),
+                       site_type=np.zeros(ns, np.uint8), site_word_off=np.zeros(ns, np.uint32),
+                       site_n_words=np.ones(ns, np.uint32), site_plane_off=np.arange(ns, dtype=np.uint64) * 2,
+                       planes=np.zeros(2 * ns, np.uint64))
+
+
+def test_batch_validation_on_several_threads_reports_what_the_serial_loop_would():
+    """round 4: a million sites were 1 ms of a one-shot call, so batches of 2^16 sites and more are validated block range by
+    block range on a thread team; the EARLIEST defect is reported, in the words of the one-thread loop (small batches)"""
+    pb = _wide_batch()
+    assert pb.n_sites >= 1 << 16
+    assert lgmi.plan_shard(pb, True, (0, 1))['n_items_total'] == 0          # valid (and no het site: nothing to do)
+
+    def message(mutate, batch=None):
+        b = batch if batch is not None else _wide_batch()
+        mutate(b)
+        with pytest.raises(LgmiError) as e:
+            lgmi.plan_shard(b, True, (0, 1))
+        return str(e.value)
+
+    def two(b, late=True):                                # two defects: the earlier one is the one reported
+        b.site_type[123] = 7
+        if late:
+            b.site_word_off[60000] = 5
+    assert 'site 123: type 7' in message(two)
+    assert 'site 60000: band [5,+1) exceeds 1 words of block 1875' in message(lambda b: b.site_word_off.__setitem__(60000, 5))
+    assert 'site 70399: planes exceed n_plane_words' in message(lambda b: b.site_plane_off.__setitem__(70399, 2 * 70400))
+    assert 'site 33: positions must increase strictly inside a block' in message(lambda b: b.site_pos.__setitem__(33, 0))
+    assert 'site 32' not in message(lambda b: b.site_pos.__setitem__(33, 0))     # (a block's first site has no predecessor)
+
+    def swap(b):                                          # a block table that goes backwards: found whatever the ranges were
+        b.block_site_begin[1001] = b.block_site_begin[999]
+    assert 'block_site_begin not monotone at block 1000' in message(swap)
+    # the same defects in a batch small enough for the one-thread loop: the same words
+    small = lambda: _wide_batch(n_blocks=8)               # noqa: E731
+    assert 'site 123: type 7' in message(lambda b: two(b, late=False), small())
+    assert 'site 33: positions must increase strictly inside a block' in message(lambda b: b.site_pos.__setitem__(33, 0), small())
