@@ -341,11 +341,12 @@ def main():
             examined_job = info['n_examined_total'] if strong else sum(int(p['n_examined']) for p in per_rank)
             rows_job = sum(info['world_rows']) if 'world_rows' in info else sum(int(p['n_rows']) for p in per_rank)
             general_job = info['n_general_rows']                    # this rank's; scaled below for the job-wide rate
-            # dominant kernel: k_count.  Algorithmic HBM bytes per launch:
-            # every column's planes once (16 B per 64-read word) + site metadata + the 4 count planes
-            # of every computed slot (16 B).
+            # the count kernel's algorithmic HBM bytes per launch: every column's planes once
+            # (16 B per 64-read word) + site metadata + the 4 counts (16 B) of every EXAMINED pair.  (Up to round 4 this
+            # credited every slot of every tile, padding included: 7.4x the examined pairs on the footprint batch, where a
+            # tile is 14 % full — the padding is traffic, not algorithm; tile_utilisation in the line says how much.)
             mfma = info.get('n_mfma_tiles', 0) > 0
-            alg_bytes = info['bytes_in'] + 16 * info['n_tile_pairs']
+            alg_bytes = info['bytes_in'] + 16 * info['n_examined']
             word_ops = 4 * info['word_pairs']                      # 4 mandatory AND+POPC per pair-word
             secs = ms_count * 1e-3
             out = {
