@@ -15,6 +15,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
+#include <sys/mman.h>
 #include <vector>
 
 #include <chrono>
@@ -123,13 +125,48 @@ struct Pool {
     }
 };
 
-// Grow-only cache of PINNED host buffers for fetched results.  Pinning is what costs (0.9 s per 4 GiB measured,
-// tools/ubench_copy.hip) and a fresh pageable destination copies at 12 GB/s instead of 50: a caller that fetches
-// result after result (every footprint batch of a run) pays the pinning once.  Shared between the context and
-// the results it handed out, so either may die first.
+// Grow-only cache of PINNED host buffers for fetched results.  A fresh pageable destination copies at 12 - 15 GB/s instead
+// of 57: a caller that fetches result after result (every footprint batch of a run) pays the pinning once.  Shared between
+// the context and the results it handed out, so either may die first.
+// How a buffer is pinned (round 4, tools/ubench_pin.hip on the box): hipHostMalloc of 400 MB takes 52 - 72 ms — 50 of them
+// the kernel faulting in 100,000 small pages one by one, which eight threads do not speed up — and was 60 of the 91 - 109 ms
+// of a context's first lgmi_run on the footprint batch.  The same 400 MB as 2-MB-aligned memory with MADV_HUGEPAGE
+// (transparent huge pages are in `madvise` mode on these boxes), touched by eight threads and then registered with
+// hipHostRegister: 2.9 + 0.8 ms, and a D2H copy into it runs at the same 57 GB/s.  Without huge pages the same path costs
+// 35 + 13 ms: still below hipHostMalloc, which stays the fallback (and the path for small buffers).
 struct PinnedPool {
     std::mutex mu;
     std::multimap<size_t, void*> free_;
+    std::unordered_set<void*> registered_;                 // buffers of the aligned_alloc + hipHostRegister kind
+    static constexpr size_t HUGE_PAGE = size_t(2) << 20;
+    void* pin_new(size_t n, size_t* got) {
+        void* p = nullptr;
+        if (n >= 4 * HUGE_PAGE) {
+            const size_t n2 = (n + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1);
+            p = aligned_alloc(HUGE_PAGE, n2);
+            if (p) {
+                (void)madvise(p, n2, MADV_HUGEPAGE);            // (advice: the path is the same without it, only slower)
+                const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(8, n2 >> 24));
+                char* const c = static_cast<char*>(p);
+                std::vector<std::thread> th;
+                auto touch = [c, n2, T](unsigned t) { for (size_t i = n2 * t / T; i < n2 * (t + 1) / T; i += 4096) c[i] = 0; };
+                for (unsigned t = 1; t < T; ++t) th.emplace_back(touch, t);
+                touch(0u);
+                for (auto& x : th) x.join();
+                if (hipHostRegister(p, n2, hipHostRegisterDefault) == hipSuccess) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    registered_.insert(p);
+                    *got = n2;
+                    return p;
+                }
+                (void)hipGetLastError();
+                free(p);
+            }
+        }
+        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *got = n;
+        return p;
+    }
     void* take(size_t bytes, size_t* got) {
         const size_t n = std::max<size_t>(4096, (bytes + 4095) & ~size_t(4095));
         {
@@ -139,13 +176,15 @@ struct PinnedPool {
                 void* p = it->second; *got = it->first; free_.erase(it); return p;
             }
         }
-        void* p = nullptr;
-        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        *got = n;
-        return p;
+        return pin_new(n, got);
     }
     void give(void* p, size_t n) { if (p) { std::lock_guard<std::mutex> lk(mu); free_.emplace(n, p); } }
-    ~PinnedPool() { for (auto& kv : free_) (void)hipHostFree(kv.second); }
+    ~PinnedPool() {
+        for (auto& kv : free_) {
+            if (registered_.count(kv.second)) { (void)hipHostUnregister(kv.second); free(kv.second); }
+            else (void)hipHostFree(kv.second);
+        }
+    }
 };
 
 // ---------------------------------------------------------------- objects
