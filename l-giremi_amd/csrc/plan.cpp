@@ -37,6 +37,13 @@ struct NeedMap {                       // which (x tile, y tile) of a block this
 // tri flag) — costs n_shuffles table draws (212 ms for 1.74e10 of them) or, from ~200 shuffles on, the perimeter walk of
 // the six-cell path whatever the shuffle count (k_perm_six + what it leaves to k_perm_general: 61 ms for 1.74e7 rows).
 static const uint64_t COST_PAIR = 2000, COST_PAIR_NO_P = 500, COST_DRAW = 180, COST_SIX = 50000;
+// A row of a site that is not an x site reads its slot by a walk down a column of the slot matrix, one row pitch (ny x 16
+// bytes: 800 KB at north-star) per step: the further the walk reaches (x ranks xnext .. nxs), the more of it misses the TLB —
+// and the more operand groups the shard's tiles make k_gather_ops lay out.  Eight shards of the north-star one after the
+// other: k_emit<2> 3.56 -> 1.69 ms and k_gather_ops 1.62 -> 0.55 ms from the first shard to the last, for the same number
+// of rows.  COST_WALK x (the walk's share of the x list) is added per such row (fitted to that profile), scaled down
+// for blocks whose slot matrix is smaller than 4 GB.
+static const uint64_t COST_WALK = 2000;
 
 // Blocks are independent of one another, so every per-block phase runs on several threads over contiguous block ranges
 // (what a thread produces is laid down at offsets from a prefix over the blocks, or concatenated in thread = block order:
@@ -151,6 +158,10 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
             // examined pairs: pairs a wave of the emit kernel will look at
             const uint64_t W = std::max<uint64_t>(1, ((uint64_t)in.block_n_reads[b] + 63u) / 64u);
             const uint64_t pair_cost = W + (n_shuffles ? COST_PAIR : COST_PAIR_NO_P);
+            // (in proportion to the block's slot matrix up to 4 GB — 8.2 GB at north-star: a matrix of a few hundred
+            //  megabytes stays within the TLB's reach whichever way it is walked)
+            const uint64_t slot_bytes = (uint64_t)bp.nx * bp.ny_pad * 16ull;
+            const uint64_t walk_cost = slot_bytes >= (1ull << 32) ? COST_WALK : COST_WALK * (slot_bytes >> 12) / (1ull << 20);
             // tri sites among the first k sites of the block / among the first k x sites: how many of an item's partners
             // bring the larger-than-2x2 paths with them
             if (sharded && n_shuffles) {
@@ -183,6 +194,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                             else n_general = trix_pre[nxs] - trix_pre[pl.smap[s].xnext];
                         }
                         item_cost[it] = (uint64_t)n_in_seg * pair_cost + n_general * std::min<uint64_t>((uint64_t)n_shuffles * COST_DRAW, COST_SIX);
+                        if (!is_x && nxs) item_cost[it] += (uint64_t)n_in_seg * walk_cost * ncand / nxs;
                     }
                     ++it;
                 }

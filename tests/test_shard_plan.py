@@ -102,9 +102,14 @@ def test_tile_redundancy_at_scale():
         parts = [lgmi.plan_shard(pb, True, (r, world)) for r in range(world)]
         total = parts[0]['n_tiles_total']
         assert total <= sum(p['n_tiles'] for p in parts) <= 1.25 * total
-        assert max(p['n_tiles'] for p in parts) <= 1.4 * total / world
+        assert max(p['n_tiles'] for p in parts) <= 1.45 * total / world
+        # (rows are NOT equal across the shards since round 4: a row of a non-x site reads its slot by a column walk that
+        #  costs more the further it reaches — plan.cpp: COST_WALK, fitted on the GPU — so the first shards get fewer rows;
+        #  the shards still partition the items, and no shard is far from its share)
         ex = [p['n_examined'] for p in parts]
-        assert max(ex) - min(ex) <= 2 * EMIT_SEG
+        assert sum(ex) == parts[0]['n_examined_total']
+        assert max(ex) <= 1.35 * sum(ex) / world and min(ex) >= 0.65 * sum(ex) / world
+        assert ex == sorted(ex)                               # more rows to the later shards
 
 
 def test_rows_longer_than_one_segment():
