@@ -141,7 +141,8 @@ struct PinnedPool {
     static constexpr size_t HUGE_PAGE = size_t(2) << 20;
     void* pin_new(size_t n, size_t* got) {
         void* p = nullptr;
-        if (n >= 4 * HUGE_PAGE) {
+        static const bool plain = [] { const char* e = getenv("LGMI_PINNED"); return e && !strcmp(e, "hostmalloc"); }();
+        if (n >= 4 * HUGE_PAGE && !plain) {
             const size_t n2 = (n + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1);
             p = aligned_alloc(HUGE_PAGE, n2);
             if (p) {

@@ -2,6 +2,9 @@
 vectors and against the CPU oracle on the same seeded inputs.
 
 Bar (BASELINE.json north_star): counts bit-exact, MI / mean MI within 1e-6."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -621,6 +624,24 @@ def test_permutation_p_in_the_other_configurations(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith('OK') and int(last.split('general=')[1]) > 100
+
+
+def test_pinned_pool_both_ways_of_pinning_give_the_same_rows():
+    """round 4: result buffers from 8 MB on are huge-page memory registered with hipHostRegister (3.7 ms per 400 MB instead
+    of 52 - 72 with hipHostMalloc, tools/ubench_pin.hip); LGMI_PINNED=hostmalloc keeps the old way, which is also the
+    fallback.  The same runs fetched through either: the same bytes (tests/helpers/pinned_worker.py)"""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = []
+    for mode in (None, 'hostmalloc'):
+        env = {k: v for k, v in os.environ.items() if k != 'LGMI_PINNED'}
+        if mode:
+            env['LGMI_PINNED'] = mode
+        r = subprocess.run([sys.executable, os.path.join(here, 'helpers', 'pinned_worker.py')], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        out.append(r.stdout.strip().splitlines()[-1])
+    assert out[0].startswith('OK rows=') and out[0] == out[1], out
 
 
 def test_host_rows_are_views_that_outlive_the_device_result(engine):
