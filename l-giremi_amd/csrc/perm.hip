@@ -339,7 +339,7 @@ __device__ __forceinline__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned lo
                 if (us >= 0.07 && v <= vr) break;
                 v = v * alpha / (a * rus * rus + b);
                 const double h = hm - LF[k] - LF[n - k] + ((double)k - (double)m) * lr;
-                if (v <= det_exp(h)) break;
+                if (le_exp(v, h)) break;                        // (the decision of v <= det_exp(h): v > 1e-29 here, see le_exp)
             }
             if (!(++trip & 1u)) o = philox4x32_10(trip >> 1, ci, cj, TAG_PERM2X2, k0, k1);
         }
