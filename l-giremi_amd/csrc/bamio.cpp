@@ -1046,13 +1046,25 @@ static int ref_intervals_impl(lgio_bam* b, int tid, int threads, lgio_intervals*
     if (fd < 0) return fail(LGIO_E_IO, "cannot open %s", b->path.c_str());
     struct Close { int fd; ~Close() { close(fd); } } closer{fd};
     // the reads of a reference are contiguous in a sorted file: from the first record the index points at until the
-    // reference id changes.  Windows of WIN blocks: headers hopped over by the calling thread, blocks inflated by all,
-    // records walked by the calling thread (a record may straddle blocks and windows: `stream` carries the remainder).
+    // reference id changes.  Windows of WIN blocks: headers hopped over by the calling thread, blocks inflated by the worker
+    // threads, records walked by the calling thread (a record may straddle blocks and windows: `stream` carries the
+    // remainder).  Round 4: the walk of a window runs WHILE the workers inflate the next one (two buffer sets) — the walk
+    // was ~40 % of the scan at 16 threads (4 M reads: 1.27 s, the CLI's first stage).
     const size_t WIN = 64 * (size_t)threads;
     uint64_t addr = chunks[0].beg >> 16;
     size_t skip = (size_t)(chunks[0].beg & 0xFFFF);
-    std::vector<BlockRef> refs;
-    std::vector<std::vector<uint8_t>> bufs(WIN);
+    struct Window {
+        std::vector<BlockRef> refs;
+        std::vector<std::vector<uint8_t>> bufs;
+        std::vector<std::thread> pool;
+        std::atomic<size_t> take{0};
+        std::atomic<int> err{0};
+        std::mutex mu;
+        std::string why;
+        bool launched = false;
+    };
+    Window win[2];
+    win[0].bufs.resize(WIN); win[1].bufs.resize(WIN);
     std::vector<uint8_t> stream;
     bool done = false, eof = false;
     // one whole record (without its size word): 0 taken or skipped, 1 = the reference is over, negative error
@@ -1073,39 +1085,51 @@ static int ref_intervals_impl(lgio_bam* b, int tid, int threads, lgio_intervals*
         o->end.push_back(pos + (span > 0 ? span : 1));
         return 0;
     };
-    while (!done && !eof) {
-        refs.clear();
-        while (refs.size() < WIN) {
+    // headers of the next window; 0 ok (possibly empty at the end of the file), negative error
+    auto fill = [&](Window& w) -> int {
+        w.refs.clear();
+        while (!eof && w.refs.size() < WIN) {
             BlockRef br; uint64_t next = 0;
             const int rc = block_ref(fd, addr, br, next);
             if (rc == 1) { eof = true; break; }
             if (rc) return rc;
-            refs.push_back(br);
+            w.refs.push_back(br);
             addr = next;
         }
-        if (refs.empty()) break;
-        std::atomic<size_t> take{0};
-        std::atomic<int> err{0};
-        std::mutex mu;
-        std::string why;
-        auto work = [&] {
+        return LGIO_OK;
+    };
+    auto launch = [&](Window& w, bool with_caller) {
+        w.take = 0; w.err = 0; w.why.clear();
+        Window* const wp = &w;
+        auto work = [wp, fd] {
             std::vector<uint8_t> comp;
-            std::string w;
+            std::string msg;
             for (;;) {
-                const size_t i = take.fetch_add(1);
-                if (i >= refs.size() || err.load()) return;
-                const int rc = inflate_block(fd, refs[i], comp, bufs[i], w);
-                if (rc) { std::lock_guard<std::mutex> g(mu); if (!err.load()) { err = rc; why = w; } return; }
+                const size_t i = wp->take.fetch_add(1);
+                if (i >= wp->refs.size() || wp->err.load()) return;
+                const int rc = inflate_block(fd, wp->refs[i], comp, wp->bufs[i], msg);
+                if (rc) { std::lock_guard<std::mutex> g(wp->mu); if (!wp->err.load()) { wp->err = rc; wp->why = msg; } return; }
             }
         };
-        {
-            std::vector<std::thread> pool;
-            const size_t nt = std::min<size_t>((size_t)threads, refs.size());
-            for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
-            work();
-            for (std::thread& t : pool) t.join();
-        }
-        if (err.load()) return fail(err.load(), "%s", why.c_str());
+        const size_t nt = std::min<size_t>((size_t)threads, w.refs.size());
+        for (size_t t = with_caller ? 1 : 0; t < nt; ++t) w.pool.emplace_back(work);
+        if (with_caller) work();                             // (the first window: nothing to walk yet)
+        w.launched = true;
+    };
+    auto join = [&](Window& w) { for (std::thread& t : w.pool) t.join(); w.pool.clear(); w.launched = false; };
+    struct JoinAll { Window* w; ~JoinAll() { for (int k = 0; k < 2; ++k) { for (std::thread& t : w[k].pool) t.join(); w[k].pool.clear(); } } } join_all{win};   // (error returns)
+    int cur = 0;
+    { const int rc = fill(win[0]); if (rc) return rc; }
+    if (!win[0].refs.empty()) launch(win[0], true);
+    while (!done && !win[cur].refs.empty()) {
+        Window& w = win[cur];
+        join(w);
+        if (w.err.load()) return fail(w.err.load(), "%s", w.why.c_str());
+        Window& nx = win[cur ^ 1];
+        { const int rc = fill(nx); if (rc) return rc; }
+        if (!nx.refs.empty()) launch(nx, threads == 1);       // inflated while this window's records are walked (one thread: before)
+        const std::vector<BlockRef>& refs = w.refs;
+        std::vector<std::vector<uint8_t>>& bufs = w.bufs;
         for (size_t i = 0; i < refs.size() && !done; ++i) {
             b->z.bytes_read += refs[i].head + refs[i].clen + 8;
             if (skip > bufs[i].size()) return fail(LGIO_E_FORMAT, "virtual offset beyond its block");
@@ -1146,6 +1170,7 @@ static int ref_intervals_impl(lgio_bam* b, int tid, int threads, lgio_intervals*
                 d += 4 + (size_t)bs; n -= 4 + (size_t)bs;
             }
         }
+        cur ^= 1;
     }
     if (!done && !stream.empty()) return fail(LGIO_E_FORMAT, "file ends inside a record");
     return finish();
