@@ -99,9 +99,10 @@ struct Pool {
         if (log) fprintf(stderr, "[lgmi pool] hipMalloc %zu bytes (%zu free blocks cached)\n", n, free_.size());
         hipError_t e = hipMalloc(&p, n);
         if (e != hipSuccess) {  // give cached blocks back and retry once
-            trim();
+            (void)hipGetLastError();                         // (the failed call's error is sticky: a later hipGetLastError() after a
+            trim();                                          //  kernel launch would report this out-of-memory as the launch's)
             e = hipMalloc(&p, n);
-            if (e != hipSuccess) return fail(LGMI_E_OOM, "hipMalloc(%zu bytes): %s", n, hipGetErrorString(e));
+            if (e != hipSuccess) { (void)hipGetLastError(); return fail(LGMI_E_OOM, "hipMalloc(%zu bytes): %s", n, hipGetErrorString(e)); }
         }
         live_[p] = n;
         *out = p;
@@ -874,7 +875,8 @@ static PlanCache* plan_for(lgmi_ctx* ctx, const lgmi_dbatch* db, bool het_only, 
     return db->plans.back().get();
 }
 
-static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out, bool defer_perm) {
+static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out, bool defer_perm,
+                           uint64_t cap_hint = 0) {
     if (!ctx || !db || !prm || !out) return fail(LGMI_E_ARG, "NULL argument");
     *out = nullptr;
     HostTrace tr;
@@ -1048,7 +1050,9 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         HIPCHK(wait_stream(st));
         cap_rows = n_rows;
     }
-    const size_t nr = (size_t)std::max<uint64_t>(cap_rows, 1);
+    // (a sequence of shards: every shard's arrays as large as the largest shard's, so that the pool's blocks of the first
+    //  serve all the others — shards are balanced by cost and their row counts grow along the batch)
+    const size_t nr = (size_t)std::max<uint64_t>(std::max(cap_rows, by_bound ? cap_hint : 0), 1);
     if ((rc = pool.alloc((void**)&res->d_i, nr * 4))) return rc;
     if ((rc = pool.alloc((void**)&res->d_j, nr * 4))) return rc;
     if ((rc = pool.alloc((void**)&res->d_mi, nr * 8))) return rc;
@@ -1157,7 +1161,7 @@ static size_t row_bytes_final(bool want_p, bool keep_p, bool want_counts) {
     return 16 + (want_p ? 4 : 0) + (keep_p ? 8 : 0) + (want_counts ? 36 : 0);
 }
 
-static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, const Plan& pl) {
+static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, const Plan& pl, uint64_t* largest = nullptr) {
     const bool want_p = prm->n_shuffles > 0 || prm->exact_2x2;
     const bool keep_p = want_p && !(prm->n_shuffles > 0 && !prm->exact_2x2 && prm->no_row_p);
     const bool want_counts = prm->emit_counts != 0;
@@ -1167,37 +1171,43 @@ static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* 
     const double rows_work = (double)pl.n_examined * (double)row_bytes_working(want_p, keep_p, want_counts);
     const double rows_final = (double)pl.n_examined * (double)row_bytes_final(want_p, keep_p, want_counts);
     int k = 1;
+    double room = budget - fixed - rows_final;
     if (fixed + rows_work > budget) {
         // what is left for a shard's own row arrays once the slot matrix, the operands and the final rows are in;
         // when those three alone exceed the budget (they are floors: the slot matrix keeps its full addressing and the
         // final rows are what the caller asked for) the shards are sized to a quarter of it
-        double room = budget - fixed - rows_final;
         if (room < 0.25 * budget) room = 0.25 * budget;
-        // shards are balanced by cost, not by row count: leave a third of slack on the estimate
-        k = (int)std::ceil(1.35 * rows_work / room);
+        k = (int)std::ceil(1.1 * rows_work / room);          // a first guess: even row counts
     }
-    if (want_p && pl.n_examined >= 0xFFFFFFFFull) {
-        // the permutation kernels carry row numbers in 32 bits: every shard must examine fewer than 2^32 pairs.  Shards are
-        // balanced by COST (with p-values mostly the larger-than-2x2 rows), so their row counts can be far from even: the
-        // shards' plans are built (host only) and the count raised until every one of them fits.
-        k = std::max<int>(k, (int)(pl.n_examined / 0xC0000000ull) + 1);
+    const bool rows32 = want_p && pl.n_examined >= 0xFFFFFFFFull;
+    if (rows32) k = std::max<int>(k, (int)(pl.n_examined / 0xC0000000ull) + 1);
+    if (k > 1) {
+        // Shards are balanced by COST — with p-values mostly the larger-than-2x2 rows, and since round 4 the rows that walk
+        // a column of a large slot matrix — so their row counts can be far from even (the last of eight shards of a dense
+        // chromosome holds a third more rows than the first).  The shards' plans are built (host only) and the count raised
+        // until the LARGEST shard's working rows fit the room, and — the permutation kernels carry row numbers in 32 bits —
+        // every shard examines fewer than 2^32 pairs.
         int ck; uint32_t xg;
         plan_env(&ck, &xg);
+        const double per_row = (double)row_bytes_working(want_p, keep_p, want_counts);
         for (; k < 1024; k += std::max(1, k / 4)) {
-            bool fits = true;
-            for (int r = 0; r < k && fits; ++r) {
+            uint64_t most = 0;
+            for (int r = 0; r < k; ++r) {
                 Plan sp;
                 build_plan(plan_input(db), prm->het_only != 0, (uint32_t)r, (uint32_t)k, ck, xg, prm->n_shuffles, sp);
-                fits = sp.n_examined < 0xFFFFFFF0ull;
+                most = std::max(most, sp.n_examined);
             }
-            if (fits) break;
+            const bool fits_mem = fixed + rows_work <= budget || 1.05 * (double)most * per_row <= room;
+            const bool fits_32 = !want_p || most < 0xFFFFFFF0ull;
+            if (largest) *largest = most;
+            if (fits_mem && fits_32) break;
         }
     }
     return std::min(std::max(k, 1), 1024);
 }
 
 static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, int k, uint64_t bound_rows,
-                            lgmi_dresult** out) {
+                            lgmi_dresult** out, uint64_t largest_shard = 0) {
     const bool want_p = prm->n_shuffles > 0 || prm->exact_2x2;
     const bool p_from_exceed = prm->n_shuffles > 0 && !prm->exact_2x2;
     const bool keep_p = want_p && !(p_from_exceed && prm->no_row_p);
@@ -1231,7 +1241,7 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
         lgmi_params ps = *prm;
         ps.shard_rank = (uint16_t)s; ps.shard_world = (uint16_t)k;
         lgmi_dresult* part = nullptr;
-        if ((rc = run_device_impl(ctx, db, &ps, &part, false))) return rc;
+        if ((rc = run_device_impl(ctx, db, &ps, &part, false, largest_shard))) return rc;
         struct PartGuard { lgmi_dresult* p; ~PartGuard() { lgmi_dresult_free(p); } } pg{part};
         const uint64_t n = part->n_rows;
         if (off + n > bound_rows) return fail(LGMI_E_STATE, "internal: the shards' rows exceed the planned bound");
@@ -1278,8 +1288,9 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if (ctx && db && db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
     if (ctx && db && prm && out && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
         const Plan& pl = plan_for(ctx, db, prm->het_only != 0, 0, 1, prm->n_shuffles, nullptr)->pl;   // (the one the run itself uses)
-        const int k = split_count(ctx, db, prm, pl);
-        if (k > 1) return run_device_split(ctx, db, prm, k, pl.n_examined, out);
+        uint64_t largest = 0;
+        const int k = split_count(ctx, db, prm, pl, &largest);
+        if (k > 1) return run_device_split(ctx, db, prm, k, pl.n_examined, out, largest);
     }
     return run_device_impl(ctx, db, prm, out, false);
 }
@@ -1431,9 +1442,10 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
     if (prm && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
         // more than one launch sequence holds: sequential shards (lgmi_run_device), no overlap of fetch and permutation
         const Plan& pl = plan_for(ctx, db, prm->het_only != 0, 0, 1, prm->n_shuffles, nullptr)->pl;
-        const int k = split_count(ctx, db, prm, pl);
         const uint64_t bound = pl.n_examined;               // (before the shards' plans may evict this one)
-        if (k > 1) { split = true; rc = run_device_split(ctx, db, prm, k, bound, &dr); }
+        uint64_t largest = 0;
+        const int k = split_count(ctx, db, prm, pl, &largest);
+        if (k > 1) { split = true; rc = run_device_split(ctx, db, prm, k, bound, &dr, largest); }
     }
     tr.mark("planned");
     if (!split) rc = run_device_impl(ctx, db, prm, &dr, true);
