@@ -471,7 +471,7 @@ def main():
                                            'rank\'s shard; '
                                            + ('v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands and unit scales, exact in f32 below 2^24 reads; '
                                               if fp4 else 'v_mfma_i32_32x32x32_i8; ')
-                                           + 'weighted-bit operands made from the bit planes in registers (AND / shift-AND per operand dword)'}
+                                           + 'weighted-bit operands made from the bit planes in registers (one AND per operand dword, the y side\'s place value by the MX block scale; shift-AND for the sign bit)'}
                 out['roofline']['share_of_step'] = ms_count / out['stage_ms']['ms_total'] if out['stage_ms']['ms_total'] else None
                 out['hbm_roofline'] = hbm
             else:

@@ -8,11 +8,12 @@
 // Weighted-bit operands, nibble version.  An e2m1 nibble with exactly one of its low three bits set is a power
 // of two — 0b0001 = 0.5 (the subnormal), 0b0010 = 1, 0b0100 = 2 — and 0b1000 is -0.  So for bit i of every
 // nibble of a raw plane dword X (x side) / Y (y side) the operand dwords are
-//     i = 0:  X & 0x11111111 (0.5)        (Y << 2) & 0x44444444 (2)
+//     i = 0:  X & 0x11111111 (0.5)         Y & 0x11111111       (0.5, block scale 2^2)
 //     i = 1:  X & 0x22222222 (1)           Y & 0x22222222       (1)
-//     i = 2:  X & 0x44444444 (2)          (Y >> 2) & 0x11111111 (0.5)
+//     i = 2:  X & 0x44444444 (2)           Y & 0x44444444       (2,   block scale 2^-2)
 //     i = 3: (X >> 3) & 0x11111111 (0.5)  (Y >> 1) & 0x44444444 (2)
-// every product is exactly x * y, and 12 VALU operations turn a raw dword pair into 8 operand dwords (32 reads
+// every product is exactly x * y, and 10 VALU operations (12 before round 4: the y words of passes 0 and 2 were shifted
+// into place instead of scaled) turn a raw dword pair into 8 operand dwords (32 reads
 // on each side).  One operand = 4 dwords = 32 nibbles per lane; lanes 0..31 carry reads 0..127 of a 256-read
 // step and lanes 32..63 reads 128..255, identically on both sides, which is all the sum over k needs.
 // Lane maps and the format / scale codes are checked with exact data by tools/mfma_fp4_probe.hip.
@@ -23,11 +24,14 @@ namespace lgmi {
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-// cbsz = blgp = 4: FP4 e2m1 on both sides; scale bytes 0x7F = 2^0; only the first 4 dwords of an operand are read
-#define LGMI_MFMA4(acc, a, b)                                                                          \
+// cbsz = blgp = 4: FP4 e2m1 on both sides; only the first 4 dwords of an operand are read.  SB = the y side's four block
+// scale bytes (E8M0: 0x7F = 2^0): round 4 lets the SCALE put a pass's product at 1 instead of a shift of the y words —
+// bit i of a nibble is worth 2^(i-1) on either side, so x bit i times y bit i is 2^(2i-2) and the scale 2^(2-2i) makes it 1
+// (i = 0: 0x81 = 2^2, i = 1: 0x7F, i = 2: 0x7D = 2^-2); the sign bit i = 3 still has to be moved on both sides.
+#define LGMI_MFMA4S(acc, a, b, SB)                                                                     \
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{a.x, a.y, a.z, a.w, 0, 0, 0, 0},            \
                                                           v8i{b.x, b.y, b.z, b.w, 0, 0, 0, 0}, acc, 4, 4, 0, \
-                                                          0x7F7F7F7F, 0, 0x7F7F7F7F)
+                                                          0x7F7F7F7F, 0, (SB))
 
 // ---- operand re-layout (once per run, ~2 ms at north-star): the column-major (C, A) entries of every 32-column
 // group in the order the count kernel's waves load them, so that each of its loads is one contiguous kilobyte
@@ -112,15 +116,15 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
     // raw words of one 256-read step: x[c] / y[c] = plane quads (C0, A0, C1, A1) of this lane's 128-read half
     struct Raw { v4i x[4], y[4]; };
 
-#define LGMI_MFMA16(O)                                                                                \
-    LGMI_MFMA4(acc[0][0][0], O.a[0], O.b[0]); LGMI_MFMA4(acc[0][0][1], O.a[1], O.b[0]);                 \
-    LGMI_MFMA4(acc[0][0][2], O.a[0], O.b[1]); LGMI_MFMA4(acc[0][0][3], O.a[1], O.b[1]);                 \
-    LGMI_MFMA4(acc[0][1][0], O.a[0], O.b[2]); LGMI_MFMA4(acc[0][1][1], O.a[1], O.b[2]);                 \
-    LGMI_MFMA4(acc[0][1][2], O.a[0], O.b[3]); LGMI_MFMA4(acc[0][1][3], O.a[1], O.b[3]);                 \
-    LGMI_MFMA4(acc[1][0][0], O.a[2], O.b[0]); LGMI_MFMA4(acc[1][0][1], O.a[3], O.b[0]);                 \
-    LGMI_MFMA4(acc[1][0][2], O.a[2], O.b[1]); LGMI_MFMA4(acc[1][0][3], O.a[3], O.b[1]);                 \
-    LGMI_MFMA4(acc[1][1][0], O.a[2], O.b[2]); LGMI_MFMA4(acc[1][1][1], O.a[3], O.b[2]);                 \
-    LGMI_MFMA4(acc[1][1][2], O.a[2], O.b[3]); LGMI_MFMA4(acc[1][1][3], O.a[3], O.b[3]);
+#define LGMI_MFMA16(O, SB)                                                                            \
+    LGMI_MFMA4S(acc[0][0][0], O.a[0], O.b[0], SB); LGMI_MFMA4S(acc[0][0][1], O.a[1], O.b[0], SB);       \
+    LGMI_MFMA4S(acc[0][0][2], O.a[0], O.b[1], SB); LGMI_MFMA4S(acc[0][0][3], O.a[1], O.b[1], SB);       \
+    LGMI_MFMA4S(acc[0][1][0], O.a[0], O.b[2], SB); LGMI_MFMA4S(acc[0][1][1], O.a[1], O.b[2], SB);       \
+    LGMI_MFMA4S(acc[0][1][2], O.a[0], O.b[3], SB); LGMI_MFMA4S(acc[0][1][3], O.a[1], O.b[3], SB);       \
+    LGMI_MFMA4S(acc[1][0][0], O.a[2], O.b[0], SB); LGMI_MFMA4S(acc[1][0][1], O.a[3], O.b[0], SB);       \
+    LGMI_MFMA4S(acc[1][0][2], O.a[2], O.b[1], SB); LGMI_MFMA4S(acc[1][0][3], O.a[3], O.b[1], SB);       \
+    LGMI_MFMA4S(acc[1][1][0], O.a[2], O.b[2], SB); LGMI_MFMA4S(acc[1][1][1], O.a[3], O.b[2], SB);       \
+    LGMI_MFMA4S(acc[1][1][2], O.a[2], O.b[3], SB); LGMI_MFMA4S(acc[1][1][3], O.a[3], O.b[3], SB);
 #ifndef LGMI_ABL
 #define LGMI_ABL 0      // timing-only ablations (tools/abl_mfma.sh): 1 operands never rebuilt, 2 no loads at all, 4 no loads inside the loop,
                         // 8 loads always hit L1, 16 one load after every fourth MFMA, 32 non-temporal loads, 64 a barrier per trip
@@ -131,9 +135,9 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
 #else
 #define LGMI_OPS(O, R, I)                                                                             \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
-        if ((I) == 0) { O.a[q_] = R.x[q_] & 0x11111111; O.b[q_] = (R.y[q_] << 2) & 0x44444444; }         \
+        if ((I) == 0) { O.a[q_] = R.x[q_] & 0x11111111; O.b[q_] = R.y[q_] & 0x11111111; }                \
         if ((I) == 1) { O.a[q_] = R.x[q_] & 0x22222222; O.b[q_] = R.y[q_] & 0x22222222; }                \
-        if ((I) == 2) { O.a[q_] = R.x[q_] & 0x44444444; O.b[q_] = (R.y[q_] >> 2) & 0x11111111; }         \
+        if ((I) == 2) { O.a[q_] = R.x[q_] & 0x44444444; O.b[q_] = R.y[q_] & 0x44444444; }                \
         if ((I) == 3) { O.a[q_] = (R.x[q_] >> 3) & 0x11111111; O.b[q_] = (R.y[q_] >> 1) & 0x44444444; }  \
     }
 #endif
@@ -177,13 +181,20 @@ __global__ __launch_bounds__(256, 1) void k_count_mfma_fp4(
 #undef LGMI_SLOT_END_L
 #define LGMI_SLOT_END_L(V) LGMI_SLOT_END(V)
 #endif
+// VALU operations the scheduler may place after each MFMA of a slot (the next pass's operands, address arithmetic)
+#ifndef LGMI_V0
+#define LGMI_V0 4
+#define LGMI_V1 5
+#define LGMI_V2 4
+#define LGMI_V3 3
+#endif
 #define LGMI_STEP(CUR, NXT, FAR, KW)                                                                  \
     LGMI_LOADX(FAR, KW)                                                                               \
-    LGMI_OPS(Q, CUR, 1) LGMI_MFMA16(P) LGMI_SLOT_END_L(4)                                               \
+    LGMI_OPS(Q, CUR, 1) LGMI_MFMA16(P, 0x81818181) LGMI_SLOT_END_L(LGMI_V0)                             \
     LGMI_LOADY(FAR, KW)                                                                               \
-    LGMI_OPS(P, CUR, 2) LGMI_MFMA16(Q) LGMI_SLOT_END_L(5)                                               \
-    LGMI_OPS(Q, CUR, 3) LGMI_MFMA16(P) LGMI_SLOT_END(4)                                                 \
-    LGMI_OPS(P, NXT, 0) LGMI_MFMA16(Q) LGMI_SLOT_END(3)
+    LGMI_OPS(P, CUR, 2) LGMI_MFMA16(Q, 0x7F7F7F7F) LGMI_SLOT_END_L(LGMI_V1)                             \
+    LGMI_OPS(Q, CUR, 3) LGMI_MFMA16(P, 0x7D7D7D7D) LGMI_SLOT_END(LGMI_V2)                               \
+    LGMI_OPS(P, NXT, 0) LGMI_MFMA16(Q, 0x7F7F7F7F) LGMI_SLOT_END(LGMI_V3)
 
     // Ring of five raw-word buffers: step s computes on ring[s % 5], prepares bit 0 of ring[(s + 1) % 5] and loads
     // step s + 4 into ring[(s + 4) % 5] — a load has ~3.7 steps (~3.5 us) to land.  With one wave per SIMD nothing else
