@@ -347,6 +347,13 @@ __device__ __forceinline__ uint32_t binom_draw(TabLF LF, uint32_t n, unsigned lo
     return flip ? n - k : k;
 }
 
+// the value of the lane N places down the same 16-lane row (lanes whose source would lie outside the row keep their own)
+template <int N> __device__ __forceinline__ double dpp_row_shr_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x110 + N, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x110 + N, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 // wave-uniform lane index -> v_readlane_b32 (no LDS round trip, unlike __shfl)
 __device__ __forceinline__ uint32_t bcast32(uint32_t v, int L) { return (uint32_t)__builtin_amdgcn_readlane((int)v, L); }
 __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int L) {
@@ -1065,7 +1072,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                     inside22(G, h, (uint32_t)kc, rsobs - G[z] - G[rAo - z], klo, khi);
                     a = klo; b = khi - 1;
                 }
-                int a_p = __shfl_up(a, 1), b_p = __shfl_up(b, 1);
+                int a_p = __builtin_amdgcn_update_dpp(a, a, 0x138, 0xF, 0xF, false),     // wave_shr:1 (lane 0: see below)
+                    b_p = __builtin_amdgcn_update_dpp(b, b, 0x138, 0xF, 0xF, false);
                 if (lane == 0u) { a_p = a_it; b_p = b_it; }
                 const bool first = j == 0u;
                 if (first) { a_p = kc; b_p = kc; }
@@ -1091,15 +1099,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                     beta = beta + adjB;
                     if (b - a <= 0) { rho = 0.0; beta = 0.0; }
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {           // inclusive scan of the maps inside each sub-chunk (Hillis-Steele)
-                    const double pr = __shfl_up(rho, o), pb = __shfl_up(beta, o);
-                    if (sub >= (uint32_t)o) {
-                        const double x = rho * pb;
-                        beta = x + beta;
-                        rho = rho * pr;
-                    }
+                // inclusive scan of the maps inside each sub-chunk (Hillis-Steele).  A sub-chunk is one 16-lane DPP row: the
+                // neighbour's value comes by row_shr (a VALU move) instead of ds_bpermute (an LDS round trip per step)
+#define LGMI_SCAN_STEP(O)                                                                                   \
+                {                                                                                             \
+                    const double pr = dpp_row_shr_f64<O>(rho), pb = dpp_row_shr_f64<O>(beta);                   \
+                    if (sub >= (uint32_t)(O)) {                                                               \
+                        const double x = rho * pb;                                                            \
+                        beta = x + beta;                                                                      \
+                        rho = rho * pr;                                                                       \
+                    }                                                                                         \
                 }
+                LGMI_SCAN_STEP(1) LGMI_SCAN_STEP(2) LGMI_SCAN_STEP(4) LGMI_SCAN_STEP(8)
+#undef LGMI_SCAN_STEP
                 // the mass carried into each sub-chunk: the last chord of the sub-chunk before it (the same row's, or dropped by
                 // rho = 0 when a row starts here)
                 double carry = M_it, M = 0.0;
