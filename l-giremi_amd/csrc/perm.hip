@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     // centre forms with nothing between the bounds) used to sit idle through both phases.  Such rows are finished where they
     // are classified; the others wait in LDS (WREC dwords each) and are processed 64 at a time with every lane busy.
     enum { WREC = 12 };                                     // r, N, K, n, start1, len1, start2, len2, c0 (2), centre, -
-    __shared__ uint32_t s_work[128 * WREC];
+    __shared__ __attribute__((aligned(16))) uint32_t s_work[128 * WREC];
     uint32_t wn = 0u;                                       // rows waiting (wave-uniform)
     __shared__ uint32_t s_pre[65];
     __shared__ unsigned long long s_acc[64];
@@ -395,14 +395,11 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
     // phases B and C for the first `cnt` waiting rows (one lane per row)
     auto process = [&](uint32_t cnt) {
         const bool have = lane < cnt;
-        HG22 h = {1u, 0u, 0u, 0u, 0u, 0.0};
-        uint32_t r = 0u, start1 = 0u, len1 = 0u, start2 = 0u, len2 = 0u;
+        uint32_t r = 0u, len1 = 0u, len2 = 0u;
         int centre = 1;
         if (have) {
             const uint32_t* w = s_work + lane * WREC;
-            r = w[0]; h.N = w[1]; h.K = w[2]; h.n = w[3];
-            start1 = w[4]; len1 = w[5]; start2 = w[6]; len2 = w[7];
-            h.c0 = __longlong_as_double((long long)(((unsigned long long)w[9] << 32) | w[8]));
+            r = w[0]; len1 = w[5]; len2 = w[7];
             centre = (int)w[10];
         }
         // ---- phase B: exact mass of the "as or more extreme" set, or of its complement when that is the short side.
@@ -434,12 +431,15 @@ __global__ __launch_bounds__(64) void k_perm_fast(PermArgs pa)
                 }
             }
             const int rr = (int)lo;
+            // the row's record straight from the list in LDS (three wide reads; ten ds_bpermute before)
+            const uint4 wa = *reinterpret_cast<const uint4*>(s_work + (uint32_t)rr * WREC);
+            const uint4 wb = *reinterpret_cast<const uint4*>(s_work + (uint32_t)rr * WREC + 4);
+            const uint2 wc = *reinterpret_cast<const uint2*>(s_work + (uint32_t)rr * WREC + 8);
             HG22 hb;
-            hb.N = __shfl(h.N, rr); hb.K = __shfl(h.K, rr); hb.n = __shfl(h.n, rr);
+            hb.N = wa.y; hb.K = wa.z; hb.n = wa.w;
             hb.kmin = 0u; hb.kmax = 0u;
-            hb.c0 = __shfl(h.c0, rr);
-            const uint32_t r_start1 = __shfl(start1, rr), r_len1 = __shfl(len1, rr);
-            const uint32_t r_start2 = __shfl(start2, rr), r_len2 = __shfl(len2, rr);
+            hb.c0 = __longlong_as_double((long long)(((unsigned long long)wc.y << 32) | wc.x));
+            const uint32_t r_start1 = wb.x, r_len1 = wb.y, r_start2 = wb.z, r_len2 = wb.w;
             if (active) {
                 uint32_t u = id - s_pre[rr];
                 const uint32_t r_units1 = (r_len1 + UNIT - 1u) / UNIT;
