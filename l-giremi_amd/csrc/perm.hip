@@ -936,6 +936,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
     if (box_max > 4194304ull) box_max = 4194304ull;
     if (pa.exact_2x2) box_max = 1048576ull;                 // the exact-p mode: whatever the walk reaches, with or without shuffles
     __shared__ unsigned long long s_acc[64];                // the rows' inside masses (2^-62, integer sums)
+    __shared__ __attribute__((aligned(16))) uint32_t s_row[64 * 16];   // the round's rows: what a chord needs of its row
     unsigned int* const next_row = pa.gen_count + 5;
     uint32_t q_next = 0u;
     if (lane == 0) q_next = atomicAdd(next_row, 64u);
@@ -1029,10 +1030,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 const uint32_t v = __shfl_up(incl, o);
                 if (lane >= (uint32_t)o) incl += v;
             }
+            const uint32_t my_pre = incl - my_sc;            // sub-chunks before this lane's row
             __syncthreads();                                 // (one wave per workgroup) the previous round's reads are over
             s_acc[lane] = 0ull;
+            {   // the row's figures where every chord's lane can read them (four wide LDS reads a trip; fifteen ds_bpermute before)
+                uint4* const q = reinterpret_cast<uint4*>(s_row + lane * 16u);
+                const unsigned long long sb = (unsigned long long)sobs, cb = (unsigned long long)__double_as_longlong(cJ), nb = (unsigned long long)__double_as_longlong(rN);
+                q[0] = make_uint4(Ao, Ap, Aq, B0);
+                q[1] = make_uint4(nz, (uint32_t)zlo, my_pre, 0u);
+                q[2] = make_uint4((uint32_t)sb, (uint32_t)(sb >> 32), (uint32_t)cb, (uint32_t)(cb >> 32));
+                q[3] = make_uint4((uint32_t)nb, (uint32_t)(nb >> 32), 0u, 0u);
+            }
             __syncthreads();
-            const uint32_t my_pre = incl - my_sc;            // sub-chunks before this lane's row
             const uint32_t TS = bcast32(incl, 63);           // wave-uniform
             const uint32_t grp = lane >> 4, sub = lane & 15u;
             double M_it = 0.0;                               // carried from lane 63 of the previous trip
@@ -1050,11 +1059,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                     if (grp == g) rs_u = slot;
                 }
                 const int rs = (int)rs_u;
-                pre_rs = __shfl(my_pre, rs);
-                const uint32_t rAo = __shfl(Ao, rs), rAp = __shfl(Ap, rs), rAq = __shfl(Aq, rs), rB0 = __shfl(B0, rs), rnz = __shfl(nz, rs);
-                const int rzlo = __shfl(zlo, rs);
-                const long long rsobs = __shfl(sobs, rs);
-                const double rcJ = __shfl(cJ, rs), rrN = __shfl(rN, rs);
+                const uint4* const q = reinterpret_cast<const uint4*>(s_row + rs_u * 16u);
+                const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                pre_rs = q1.z;
+                const uint32_t rAo = q0.x, rAp = q0.y, rAq = q0.z, rB0 = q0.w, rnz = q1.x;
+                const int rzlo = (int)q1.y;
+                const long long rsobs = (long long)(((unsigned long long)q2.y << 32) | q2.x);
+                const double rcJ = __longlong_as_double((long long)(((unsigned long long)q2.w << 32) | q2.z));
+                const double rrN = __longlong_as_double((long long)(((unsigned long long)q3.y << 32) | q3.x));
                 const uint32_t j = valid ? 16u * (sid - pre_rs) + sub : 0u;
                 const bool active = valid && j < rnz;
                 const uint32_t Np = rAp + rAq, K = rAp;
