@@ -921,7 +921,9 @@ __device__ __forceinline__ void walk_sum(TabLF LF, const HG22& h, int lo, int hi
 }
 
 #ifndef LGMI_SIX_WPS
-#define LGMI_SIX_WPS 5     // waves per SIMD the register budget is set for: 4 (108 VGPRs) 46.1 ms, 5 (96 + 10 spilled) 41.7, 6 (80 + 38) 44.2
+#define LGMI_SIX_WPS 7     // waves per SIMD the register budget is set for.  With the row figures and the scans still going through
+                           // ds_bpermute: 4 (108 VGPRs) 46.1 ms, 5 (96 + 10 spilled) 41.7, 6 (80 + 38) 44.2.  With DPP scans and the row
+                           // figures read from LDS (5: 96, none spilled, 41.2 ms): 6 (80 + 10) 39.0, 7 (72 + 18) 37.8, 8 (64 + 31) 44.2
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS, LGMI_SIX_WPS))) void k_perm_six(PermArgs pa)
 {
