@@ -923,7 +923,8 @@ __device__ __forceinline__ void walk_sum(TabLF LF, const HG22& h, int lo, int hi
 #ifndef LGMI_SIX_WPS
 #define LGMI_SIX_WPS 7     // waves per SIMD the register budget is set for.  With the row figures and the scans still going through
                            // ds_bpermute: 4 (108 VGPRs) 46.1 ms, 5 (96 + 10 spilled) 41.7, 6 (80 + 38) 44.2.  With DPP scans and the row
-                           // figures read from LDS (5: 96, none spilled, 41.2 ms): 6 (80 + 10) 39.0, 7 (72 + 18) 37.8, 8 (64 + 31) 44.2
+                           // figures read from LDS (5: 96, none spilled, 41.2 ms): 6 (80 + 10) 39.0, 7 (72 + 18) 37.8, 8 (64 + 31) 44.2; with the row's own
+                           // state parked in LDS across the trips: 7 (72 + 10) 37.7, 8 (64 + 20) 38.1
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS, LGMI_SIX_WPS))) void k_perm_six(PermArgs pa)
 {
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
         int zlo = 0;
         long long sobs = 0;
         double cJ = 0.0, rN = 0.0;
-        unsigned long long thr = 0ull, ins_x = 0ull;         // ins_x: the inside mass (2^-62), for the exact-p mode
+        unsigned long long ins_x = 0ull;                     // rows decided here: their inside mass (2^-62)
         if (r != 0xFFFFFFFFu) {
             uint32_t T[9];
 #pragma unroll
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 b += (double)N;
                 b += det_log(((double)Ao + 1.0) * ((double)Ap + 1.0));
                 b -= (double)sobs * 3.725290298461914e-09;
-                if (b < -23.1) { st = 3; thr = 0ull; ins_x = 4611686018427387904ull; }
+                if (b < -23.1) { st = 3; ins_x = 4611686018427387904ull; }          // (thr = 0)
                 else {
                     HG22 hc;
                     hg22_set(hc, N, Ao, B0, 0.0);
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                     const uint32_t kcc = kc22(hc);
                     int zhi;
                     inside22(G, hc, kcc, sc, zlo, zhi);
-                    if (zhi - zlo - 1 <= 0) { st = 3; thr = 4294967296ull; ins_x = 0ull; }
+                    if (zhi - zlo - 1 <= 0) { st = 3; ins_x = 0ull; }               // (thr = 2^32)
                     else {
                         int zc = (int)kcc;
                         if (zc <= zlo) zc = zlo + 1;
@@ -1034,14 +1035,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
             }
             const uint32_t my_pre = incl - my_sc;            // sub-chunks before this lane's row
             __syncthreads();                                 // (one wave per workgroup) the previous round's reads are over
-            s_acc[lane] = 0ull;
+            s_acc[lane] = st == 3 ? ins_x : 0ull;            // (rows decided in phase S: their inside mass as it is; nothing is added)
             {   // the row's figures where every chord's lane can read them (four wide LDS reads a trip; fifteen ds_bpermute before)
                 uint4* const q = reinterpret_cast<uint4*>(s_row + lane * 16u);
                 const unsigned long long sb = (unsigned long long)sobs, cb = (unsigned long long)__double_as_longlong(cJ), nb = (unsigned long long)__double_as_longlong(rN);
                 q[0] = make_uint4(Ao, Ap, Aq, B0);
-                q[1] = make_uint4(nz, (uint32_t)zlo, my_pre, 0u);
+                q[1] = make_uint4(nz, (uint32_t)zlo, my_pre, r);             // (.w and q[3].z: this lane's own row and state, read back
+
                 q[2] = make_uint4((uint32_t)sb, (uint32_t)(sb >> 32), (uint32_t)cb, (uint32_t)(cb >> 32));
-                q[3] = make_uint4((uint32_t)nb, (uint32_t)(nb >> 32), 0u, 0u);
+                q[3] = make_uint4((uint32_t)nb, (uint32_t)(nb >> 32), (uint32_t)st, 0u);   //  in phase D — six registers fewer across the trips)
             }
             __syncthreads();
             const uint32_t TS = bcast32(incl, 63);           // wave-uniform
@@ -1143,28 +1145,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                     atomicAdd(&s_acc[rs], M >= 1.0 ? 4611686018427387904ull : (unsigned long long)(M * 4611686018427387904.0));
             }
             __syncthreads();
-            if (st == 2) {
-                const unsigned long long ins = s_acc[lane];
-                thr = ins <= 4611686018427387904ull ? (4611686018427387904ull - ins) >> 30 : 0ull;
-                ins_x = ins;
-                st = 3;
-            }
         }
-        // ---- phase D
-        if (st == 3) {
+        // ---- phase D: thr = (2^62 - inside) >> 30 for every six-cell row (inside = 2^62 after the zero test: 0; inside = 0 for
+        //      an empty chord range: 2^32)
+        const uint32_t r_d = s_row[lane * 16u + 7u];
+        const bool fin = s_row[lane * 16u + 14u] >= 2u;          // state 2 (walked) or 3 (decided in phase S)
+        if (fin) {
+            const unsigned long long ins = s_acc[lane];
             if (pa.exact_2x2) {                              // the exact p: one minus the inside mass (six_thr's p_out in the oracle)
-                double p = 1.0 - (double)ins_x * 2.168404344971009e-19;
+                double p = 1.0 - (double)ins * 2.168404344971009e-19;
                 if (p < 0.0) p = 0.0;
-                out_exceed[r] = LGMI_EXCEED_EXACT;
-                out_p[r] = p;
+                out_exceed[r_d] = LGMI_EXCEED_EXACT;
+                out_p[r_d] = p;
             } else {
-                const uint32_t exceed = binom_draw(LF, n_shuffles, thr, row_i[r] + pa.site_base, row_j[r] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
-                out_exceed[r] = exceed;
-                if (out_p) out_p[r] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
+                const unsigned long long thr = ins <= 4611686018427387904ull ? (4611686018427387904ull - ins) >> 30 : 0ull;
+                const uint32_t exceed = binom_draw(LF, n_shuffles, thr, row_i[r_d] + pa.site_base, row_j[r_d] + pa.site_base, (uint32_t)seed, (uint32_t)(seed >> 32));
+                out_exceed[r_d] = exceed;
+                if (out_p) out_p[r_d] = (1.0 + (double)exceed) / ((double)n_shuffles + 1.0);
             }
-            if (!ls.third) ls.in[q] = 0xFFFFFFFFu;          // no third list: k_perm_general skips the row
+            if (!ls.third) ls.in[q0 + lane] = 0xFFFFFFFFu;  // no third list: k_perm_general skips the row
         }
-        const uint32_t done = (uint32_t)__popcll(__ballot(st == 3));        // (statistics)
+        const uint32_t done = (uint32_t)__popcll(__ballot(fin));           // (statistics)
         if (lane == 0 && done) atomicAdd(pa.gen_count + 6, done);
     }
 }
