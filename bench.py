@@ -173,6 +173,45 @@ def cpu_baseline(eng, wl, min_common, n_shuffles, seed):
                                                                                   len(out['row_i']), dt)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (no RANK / WORLD_SIZE in the environment): start the N ranks here, one
+    fresh child process per GPU with RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT set — what
+    `python -m torch.distributed.run --nproc-per-node N` exports.  Called before this process has loaded liblgmi or made
+    any GPU call, and it never makes one: children are started, never exec'ed over a process that has initialised the GPU.
+    Rank 0 inherits stdout and prints the one JSON line; the exit code is 0 only if every rank's is."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                # a free port for rank 0's rendezvous listener
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # RCCL across processes needs dmabuf IPC on this driver
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [None] * n
+    deadline = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if deadline is None and any(c not in (None, 0) for c in codes):
+            deadline = time.time() + 30.0                      # a rank failed: the others get half a minute to notice (watchdogs, closed sockets)
+        if deadline is not None and time.time() > deadline:
+            for r, p in enumerate(procs):                      # exactly the children started above, by pid
+                if codes[r] is None:
+                    p.send_signal(signal.SIGKILL)
+            deadline = time.time() + 1e9
+        time.sleep(0.05)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        print('[bench] rank exit codes: %s' % codes, file=sys.stderr)
+    return 0 if not bad else (bad[0] if bad[0] > 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -197,8 +236,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
+            # no launcher: this process becomes one — it starts the N ranks as fresh children and never touches the GPU
+            sys.exit(spawn_ranks(args.gpus))
         args.gpus = world
 
     # stdout carries ONE JSON line.  Libraries loaded below write banners to file descriptor 1 (RCCL prints its version
@@ -482,14 +522,14 @@ def main():
                 # prep + kernels + fetch), through lgmi_run.  Never `value`.
                 pb = db.download()
                 t1 = time.perf_counter()
-                eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+                eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, compact=True)
                 dt_first = time.perf_counter() - t1                # pays the pinning of the result buffers (cached after)
                 # steady state: the median of four more calls (the second call still pays first-use costs of its own — the
                 # runtime's registration of the caller's pages for the DMA — 28.8 ms against 20.4 from the third on, footprint batch)
                 later = []
                 for _ in range(4 if info['ms_total'] < 50.0 else 2):
                     t1 = time.perf_counter()
-                    hi = eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True)
+                    hi = eng.run_raw(pb, min_common=args.min_common, n_shuffles=n_shuffles, seed=seed, het_only=True, compact=True)
                     later.append(time.perf_counter() - t1)
                 dt = sorted(later)[len(later) // 2] if len(later) % 2 else sum(sorted(later)[len(later) // 2 - 1:len(later) // 2 + 1]) / 2.0
                 out['host_to_host'] = {'ms': 1e3 * dt, 'ms_min': 1e3 * min(later), 'ms_first_call': 1e3 * dt_first,
@@ -498,11 +538,16 @@ def main():
                                        'h2d_bytes': int(pb.planes.nbytes + 25 * len(pb.site_pos)),
                                        'd2h_bytes': int(hi['bytes_out'] + 12 * len(pb.site_pos)),
                                        'kernels_ms': hi['ms_total'],
+                                       'row_form': 'compact (include/lgmi.h ABI 6): per-site row offsets instead of row_i, no partner for a site '
+                                                   'whose every candidate pair was emitted, 16-bit permutation counts',
                                        'note': 'one lgmi_run call from pageable host memory: validation + H2D + layout prep '
-                                               '+ kernels + D2H of (i, j, mi, p, exceed) per row into pinned buffers the '
-                                               'context caches (the first call pins them); ms = median of the calls after the first.  The host side '
+                                               '+ kernels + D2H of the compact rows (mi, 16-bit exceed, listed partners, per-site offsets) into pinned buffers the '
+                                               'context caches (the first call pins them), the permutation counts following the kernels range by range; '
+                                               'ms = median of the calls after the first.  The host side '
                                                '(planner threads, page pinning) shares the box\'s CPUs with seven other tenants under a 16-CPU quota: '
                                                'the same call measured 20 - 60 ms on one box within a minute'}
+                # SURVEY 8d's wall time as a rate, next to `value` (which stays the resident-to-resident figure)
+                out['value_host_to_host'] = hi['n_examined'] / dt
                 del pb
             if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
                 out['cpu_baseline'] = cpu_baseline(eng, wl, args.min_common, n_shuffles, seed)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LGMI_ABI_VERSION 5
+#define LGMI_ABI_VERSION 6
 
 /* error codes */
 #define LGMI_OK        0
@@ -109,7 +109,14 @@ typedef struct lgmi_params {
                               tables with few candidate tables (enumeration) and 3 x 2 / 2 x 3 tables whose region
                               {MI < observed} has at most 2^20 chords (perimeter walk).  The other
                               larger tables keep the n_shuffles estimate (row_p NaN, row_exceed LGMI_EXCEED_EXACT
-                              when n_shuffles == 0) */
+                              when n_shuffles == 0).
+                              ACCURACY of an "exact" p: masses are summed in 2^-62 fixed point from a log-factorial
+                              table, |dp| <= 1e-9 up to 2e5 reads (5e-8 at 3e6).  A tail that is summed directly (2 x 2
+                              tail form, enumeration) keeps that as a RELATIVE figure down to ~1e-18; the 2 x 2 centre form
+                              and the 3 x 2 / 2 x 3 walk return 1 - (mass inside), an ABSOLUTE 1e-9: read a p below ~1e-8
+                              from them as "< 1e-8".  A 3 x 2 / 2 x 3 row whose whole tail is bounded below 2^-33 before any
+                              sum is made returns that BOUND (an upper bound of its p, < 9.3e-11, at least 2.2e-308) — an
+                              exact p is never 0.0: the observed table is in its own tail */
     uint8_t  no_row_p;     /* 1: when every row_p is a function of its row_exceed — Monte-Carlo estimates,
                               p = (1 + row_exceed) / (n_shuffles + 1), i.e. n_shuffles > 0 without exact_2x2 — the
                               p array is not made at all: lgmi_result.row_p is NULL, row_p_derived is 1 and the
@@ -127,7 +134,12 @@ typedef struct lgmi_params {
      * batches (footprints dealt to ranks, lgmi.cli --gpus) passes each rank's site base — the same number it passes to
      * lgmi_comm_gather — and gets, pair for pair, the draws of the single batch that holds all the footprints.  0 else. */
     uint32_t stream_site_base;
-    uint32_t reserved1;    /* must be 0 */
+    uint8_t  compact_rows; /* ABI 6.  1: lgmi_run() returns the rows in the COMPACT form described at lgmi_result (row_i and
+                              row_j are not shipped: 10 instead of 20 bytes per row of a dense block cross PCIe, and the
+                              permutation counts travel in pieces while the permutation stage is still running).  Ignored by
+                              lgmi_run_device(): a resident result holds both forms, lgmi_dresult_fetch() /
+                              lgmi_dresult_fetch_compact() choose */
+    uint8_t  reserved1[3]; /* must be 0 */
 } lgmi_params;
 #define LGMI_EXCEED_EXACT 0xFFFFFFFFu
 
@@ -154,6 +166,24 @@ typedef struct lgmi_result {
     uint32_t n_shuffles;          /* of the run that made the rows */
     uint32_t row_p_derived;       /* 1: row_p is NULL because lgmi_params.no_row_p asked for that:
                                      p[r] = (1 + row_exceed[r]) / (n_shuffles + 1) */
+    /* ---- ABI 6: the COMPACT row form (lgmi_params.compact_rows with lgmi_run(), or lgmi_dresult_fetch_compact()).
+     * Rows are in reference order (mutual_information.py:10-12, :42-45): all rows of first site s are consecutive, so
+     * row_i is a run-length code — rows [row_begin[s], row_begin[s + 1]) have row_i == s — and the partners of a site
+     * whose every candidate pair was emitted are the candidates themselves, in order:
+     *     candidates of s = the later sites of its block: all of them when het_only == 0 or s is a het_snp site, else the
+     *     later het_snp sites (mismatch.py:392-396).
+     * compact == 1: row_i == row_j == NULL;
+     *     site_row_full[s] == 1: the k-th row of s has row_j = the k-th candidate of s (nothing is stored);
+     *     site_row_full[s] == 0: its row_j are listed, in row order, in row_j_listed (sites in increasing s);
+     *     row_exceed16 (row_exceed == NULL) when every count fits 16 bits: n_shuffles <= 65535 and no exact p.
+     * lgmi_result_expand_rows() writes the plain row_i / row_j arrays from these. */
+    uint32_t compact;
+    uint32_t reserved3;               /* 0 */
+    const uint64_t* row_begin;        /* [n_sites + 1] */
+    const uint8_t*  site_row_full;    /* [n_sites] */
+    const uint32_t* row_j_listed;     /* [n_row_j_listed] */
+    uint64_t        n_row_j_listed;
+    const uint16_t* row_exceed16;     /* [n_rows] or NULL */
 } lgmi_result;
 
 /* figures of one run: work done and HIP-event time of each stage (ms), taken
@@ -249,6 +279,14 @@ int  lgmi_dresult_info(const lgmi_dresult* dr, lgmi_run_info* out);
 int  lgmi_dresult_device_ptrs(const lgmi_dresult* dr, lgmi_result* out_device_view);
 /* HBM -> host; the host arrays live until lgmi_result_free(out) */
 int  lgmi_dresult_fetch(lgmi_dresult* dr, lgmi_result* out);
+/* the same in the compact row form (lgmi_result.compact == 1): what crosses PCIe is row_mi, the 16- or 32-bit permutation
+ * counts, the listed partners of the sites that are not full, and three per-site arrays.  Not for results gathered from
+ * ranks that ran different batches (LGMI_E_STATE): the root does not hold the other ranks' site tables */
+int  lgmi_dresult_fetch_compact(lgmi_dresult* dr, lgmi_result* out);
+/* compact form -> the plain arrays: row_i_out / row_j_out [n_rows] (either may be NULL), written on the host by the
+ * library's thread team from row_begin, site_row_full, row_j_listed and the site table the result kept.  A result that
+ * is not compact is copied.  (The reference's rows carry both positions: mutual_information.py:42-45.) */
+int  lgmi_result_expand_rows(const lgmi_result* res, uint32_t* row_i_out, uint32_t* row_j_out);
 void lgmi_dresult_free(lgmi_dresult* dr);
 
 /* upload + run + fetch in one call (what the Python drop-ins use) */

@@ -194,7 +194,7 @@ struct lgmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    unsigned long long* h_scal = nullptr;   // 4 KB of pinned words: [0, 8) the scalars a run reads back (a pageable destination
+    unsigned long long* h_scal = nullptr;   // 8 KB of pinned words: [0, 8) the scalars a run reads back (a pageable destination
                                             // makes every small copy a staged, blocking one), [8, 512) comm.cpp's small exchanges
     Pool pool;
     long long* d_G = nullptr;   // round(n ln n * 2^28): permutation statistic (perm.hip)
@@ -206,6 +206,11 @@ struct lgmi_ctx {
     int rank = 0, world = 1;
     size_t mem_total = 0;       // device memory, for the "allocate rows by their upper bound" decision
     std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
+    std::vector<hipEvent_t> more_ev;       // events of chunked stages (permute_impl, lgmi_run), made on first use
+    hipEvent_t event(size_t k) {           // NULL when the runtime refuses one
+        while (more_ev.size() <= k) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; } more_ev.push_back(e); }
+        return more_ev[k];
+    }
 };
 
 // A plan is a function of the resident batch and a few parameters, not of the run: it is kept with the batch, host
@@ -229,9 +234,17 @@ struct PlanCache {
     }
 };
 
+// what the compact row form needs of a batch to name a row's sites (include/lgmi.h: candidates of a site): shared by
+// the resident batch, its results and the host results fetched from them, so any of them may be freed first
+struct SiteTable {
+    std::vector<uint64_t> block_site_begin;
+    std::vector<uint8_t> type;
+};
+
 struct lgmi_dbatch {
     lgmi_ctx* ctx = nullptr;
     DevBatch d;
+    std::shared_ptr<const SiteTable> table;
     mutable std::vector<std::unique_ptr<PlanCache>> plans;   // most recently used plans of this batch (at most PLAN_CACHE_N)
     mutable uint64_t plan_stamp = 0;
     // host copies of the site metadata (planning happens on the host)
@@ -267,10 +280,21 @@ struct lgmi_dresult {
     uint64_t* d_nrows = nullptr;           // the row count on the device, for the permutation kernels' grids
     uint64_t cap_rows = 0;
     lgmi_params prm = {};
+    // the compact row form (ABI 6): per-site integers that add up over shards, and what a compact fetch derives from them
+    std::shared_ptr<const SiteTable> table;     // NULL: gathered from ranks that ran different batches
+    bool het_only = false;
+    uint32_t* d_nfirst = nullptr;          // [n_sites] rows whose FIRST site is s
+    uint32_t* d_ncand = nullptr;           // [n_sites] pairs s could have emitted as first site
+    uint8_t* d_full = nullptr;             // [n_sites]   (from here: made by compact_prepare)
+    uint64_t* d_row_begin = nullptr;       // [n_sites + 1]
+    uint32_t* d_jlisted = nullptr; uint64_t n_jlisted = 0;
+    uint16_t* d_exceed16 = nullptr;
+    bool compact_ready = false;
 };
 
 struct HostResult : ResultOwner {  // owner_ of a host lgmi_result: pinned buffers that go back to the context's cache
     std::shared_ptr<PinnedPool> pool;
+    std::shared_ptr<const SiteTable> table; bool het_only = false;     // compact form: lgmi_result_expand_rows reads these
     std::vector<std::pair<void*, size_t>> bufs;
     template <class T> T* take(size_t count) {
         size_t got = 0;
@@ -325,7 +349,7 @@ extern "C" int lgmi_ctx_create(int device_id, lgmi_ctx** out) {
     c->device = device_id;
     HIPCHK(hipStreamCreate(&c->stream));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
-    HIPCHK(hipHostMalloc((void**)&c->h_scal, 4096, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_scal, 8192, hipHostMallocDefault));   // words [512, 1024): the chunked permutation stage
     size_t free_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &c->mem_total));
     *out = c;
@@ -343,6 +367,7 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     if (ctx->d_LF) (void)hipFree(ctx->d_LF);
     ctx->pool.destroy();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->more_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     if (ctx->comm_event) (void)hipEventDestroy(ctx->comm_event);
@@ -519,6 +544,7 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     db->pos.assign(b->site_pos, b->site_pos + ns);
     db->type.assign(b->site_type, b->site_type + ns);
     for (uint64_t k = 0; k < b->n_blocks; ++k) db->max_reads = std::max(db->max_reads, b->block_n_reads[k]);
+    { auto t = std::make_shared<SiteTable>(); t->block_site_begin = db->block_site_begin; t->type = db->type; db->table = t; }
     tr.mark("host_copies");
 
     hipStream_t st = ctx->stream;
@@ -632,6 +658,7 @@ extern "C" int lgmi_synth_dense(lgmi_ctx* ctx, const lgmi_synth_spec* sp, lgmi_d
             db->tri[g] = ss.tri ? 1 : 0;
         }
     }
+    { auto t = std::make_shared<SiteTable>(); t->block_site_begin = db->block_site_begin; t->type = db->type; db->table = t; }
     db->cols.resize(ns);
     for (uint32_t s = 0; s < ns; ++s) db->cols[s] = Col{(uint64_t)s * W, 0u, W};
     for (uint32_t s = 0; s < ns; ++s) {
@@ -837,6 +864,8 @@ extern "C" void lgmi_dresult_free(lgmi_dresult* r) {
     p.release(r->d_i); p.release(r->d_j); p.release(r->d_mi); p.release(r->d_p);
     p.release(r->d_exceed); p.release(r->d_counts); p.release(r->d_rec); p.release(r->d_mean); p.release(r->d_npairs);
     p.release(r->d_sum); p.release(r->d_nrows);
+    p.release(r->d_nfirst); p.release(r->d_ncand); p.release(r->d_full); p.release(r->d_row_begin); p.release(r->d_jlisted);
+    p.release(r->d_exceed16);
     delete r;
 }
 
@@ -882,7 +911,8 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HostTrace tr;
     if (db->ctx != ctx) return fail(LGMI_E_ARG, "batch belongs to another context");
     if (prm->no_row_p > 1) return fail(LGMI_E_ARG, "lgmi_params.no_row_p must be 0 or 1");
-    if (prm->reserved1) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
+    if (prm->reserved1[0] || prm->reserved1[1] || prm->reserved1[2]) return fail(LGMI_E_ARG, "reserved params bytes must be 0");
+    if (prm->compact_rows > 1) return fail(LGMI_E_ARG, "lgmi_params.compact_rows must be 0 or 1");
     if ((uint64_t)prm->stream_site_base + db->d.n_sites >= 0xFFFFFFF0ull) return fail(LGMI_E_ARG, "stream_site_base + sites overflows 32 bits");
     if (prm->exact_2x2 > 1) return fail(LGMI_E_ARG, "exact_2x2 must be 0 or 1");
     if (prm->n_shuffles > (1u << 24)) return fail(LGMI_E_ARG, "n_shuffles must be <= 2^24");
@@ -924,6 +954,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     res->sharded = sh_world > 1;
     res->n_shuffles = prm->n_shuffles;
     res->p_from_exceed = prm->n_shuffles > 0 && !prm->exact_2x2;
+    res->table = db->table; res->het_only = prm->het_only != 0;
     const bool keep_p = want_p && !(res->p_from_exceed && prm->no_row_p);   // row_p as an array of its own
     // scratch (returned to the pool at the end of the call) and the result
     std::vector<void*> scratch;
@@ -966,6 +997,8 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     if ((rc = salloc((void**)&d_wordpairs, 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_mean, (size_t)ns * 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_npairs, (size_t)ns * 4))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_nfirst, std::max<size_t>(ns, 1) * 4))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_ncand, std::max<size_t>(ns, 1) * 4))) return rc;
     unsigned long long* d_sum = res->d_sum;
 
     // The plan goes up through one pinned staging buffer (cached by the context).  Straight from the pageable
@@ -1004,6 +1037,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     pcache->on_device = true;
     tr.mark("uploaded");
     if (ns) HIPCHK(hipMemsetAsync(d_sum, 0, (size_t)ns * 8, st));
+    if (ns) HIPCHK(hipMemsetAsync(res->d_nfirst, 0, (size_t)ns * 4, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ns * 4 + 64, st));
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
 
@@ -1024,7 +1058,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
 
     EmitArgs ea{};
     ea.n_sites = ns; ea.min_common = prm->min_common; ea.het_only = prm->het_only != 0;
-    ea.plans = d_plans; ea.smap = d_smap; ea.xlist = d_xlist; ea.cols = db->d.d_cols;
+    ea.plans = d_plans; ea.smap = d_smap; ea.xsites = d_ylist; ea.cols = db->d.d_cols;
     ea.type = db->d.d_type; ea.tri = db->d.d_tri;
     ea.slots = d_slots;
     ea.n_items = (uint32_t)n_items; ea.items = d_items;
@@ -1036,6 +1070,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     ea.site_sum = d_sum; ea.site_cnt = d_cnt; ea.err_flag = d_err; ea.unit_words = d_unitwords;
     launch_emit_count(st, ea);
     launch_scan(st, d_rowcnt, d_rowstart, (uint32_t)n_items, d_scantmp);
+    launch_site_rows(st, (uint32_t)n_items, d_items, d_rowcnt, ns, d_smap, d_plans, res->d_nfirst, res->d_ncand);
     launch_sum_u64(st, d_unitwords, (uint32_t)pl.units.size(), d_wordpairs);
     HIPCHK(hipGetLastError());
     // Row arrays: the number of rows is only known on the device here.  When the upper bound (every examined pair
@@ -1219,6 +1254,7 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
     lgmi_dresult* res = new lgmi_dresult();
     res->ctx = ctx; res->n_sites = ns; res->has_p = want_p; res->has_counts = want_counts;
     res->n_shuffles = prm->n_shuffles; res->p_from_exceed = p_from_exceed;
+    res->table = db->table; res->het_only = prm->het_only != 0;
     struct Guard { lgmi_dresult* r; ~Guard() { if (r) lgmi_dresult_free(r); } } guard{res};
     int rc;
     const size_t nr = (size_t)std::max<uint64_t>(bound_rows, 1);
@@ -1231,9 +1267,12 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
     if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_npairs, std::max<size_t>(ns, 1) * 4))) return rc;
     if ((rc = pool.alloc((void**)&res->d_mean, std::max<size_t>(ns, 1) * 8))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_nfirst, std::max<size_t>(ns, 1) * 4))) return rc;
+    if ((rc = pool.alloc((void**)&res->d_ncand, std::max<size_t>(ns, 1) * 4))) return rc;
     if (ns) {
         HIPCHK(hipMemsetAsync(res->d_sum, 0, (size_t)ns * 8, st));
         HIPCHK(hipMemsetAsync(res->d_npairs, 0, (size_t)ns * 4, st));
+        HIPCHK(hipMemsetAsync(res->d_nfirst, 0, (size_t)ns * 4, st));
     }
     lgmi_run_info tot = {};
     uint64_t off = 0;
@@ -1255,6 +1294,8 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
         if (want_p) HIPCHK(d2d(res->d_exceed + off, part->d_exceed, n * 4));
         if (keep_p) HIPCHK(d2d(res->d_p + off, part->d_p, n * 8));
         launch_sites_add(st, ns, res->d_sum, part->d_sum, res->d_npairs, part->d_npairs);
+        launch_add_u32(st, ns, res->d_nfirst, part->d_nfirst);                // (rows by first site: integers, like the pair counts)
+        if (s == 0 && ns) HIPCHK(hipMemcpyAsync(res->d_ncand, part->d_ncand, (size_t)ns * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipGetLastError());
         HIPCHK(wait_stream(st));                       // the part's arrays go back to the pool next
         const lgmi_run_info& pi = part->info;
@@ -1300,53 +1341,100 @@ extern "C" int lgmi_run_device_rows(lgmi_ctx* ctx, const lgmi_dbatch* db, const 
     return run_device_impl(ctx, db, prm, out, true);
 }
 
-extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
-    if (!ctx || !res) return fail(LGMI_E_ARG, "NULL argument");
-    if (res->ctx != ctx) return fail(LGMI_E_ARG, "result belongs to another context");
-    if (!res->perm_pending) return LGMI_OK;              // nothing was deferred (no p requested, or already done)
+// The permutation stage of a result whose rows are final, optionally in `n_chunks` contiguous row ranges: the kernels key
+// their Philox counters by the PAIR (row_i, row_j), never by a row number or the launch geometry, so a range of rows gives
+// the same counts whether it is run alone or inside the whole.  After each range `after_chunk(first row, rows)` is called
+// with the range's kernels queued on the main stream (lgmi_run ships the range's counts to the host while the next range
+// is computed).  One range = the plain stage.
+template <class F>
+static int permute_impl(lgmi_ctx* ctx, lgmi_dresult* res, uint32_t n_chunks, F after_chunk) {
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     Pool& pool = ctx->pool;
     int rc = LGMI_OK;
-    uint32_t* d_genlist = nullptr; unsigned int* d_gencount = nullptr;
-    struct Guard { Pool& p; uint32_t** a; unsigned int** b; ~Guard() { p.release(*a); p.release(*b); } } guard{pool, &d_genlist, &d_gencount};
+    uint32_t* d_genlist = nullptr; unsigned int* d_gencount = nullptr; uint64_t* d_chunk_rows = nullptr;
+    struct Guard { Pool& p; uint32_t** a; unsigned int** b; uint64_t** c; ~Guard() { p.release(*a); p.release(*b); p.release(*c); } } guard{pool, &d_genlist, &d_gencount, &d_chunk_rows};
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     HIPCHK(hipEventRecord(ctx->ev[6], st));
-    unsigned int n_general = 0;
+    uint64_t n_general = 0, n_six = 0;
+    // a chunked stage needs the row count on the host (it has it: the rows were waited for) and at least a few thousand rows
+    const uint64_t n_rows = res->n_rows;
+    if (n_chunks < 1 || n_rows < 65536ull * n_chunks) n_chunks = 1;
+    if (n_chunks > 32) n_chunks = 32;
+    const bool chunked = n_chunks > 1;
+    float ms_fast = 0.f, ms_exact = 0.f;
+    enum { HS_ROWS = 512, HS_GEN = 576 };                    // pinned words: the chunks' row counts (up), their queue counters (down)
+    if (chunked) for (uint32_t k = 0; k < 3 * n_chunks; ++k) if (!ctx->event(k)) return fail(LGMI_E_HIP, "hipEventCreate failed");
     if (res->cap_rows) {
-        if ((rc = pool.alloc((void**)&d_genlist, (size_t)res->cap_rows * 4))) return rc;
-        if ((rc = pool.alloc((void**)&d_gencount, 64))) return rc;      // [0] queued rows, [1] k_perm_general's next row, [2] rows k_perm_enum leaves to it, [3] some row is enumerable
-        HIPCHK(hipMemsetAsync(d_gencount, 0, 64, st));
-        PermArgs pa{};
-        pa.n_rows_dev = res->d_nrows; pa.max_rows = res->cap_rows;
-        pa.row_i = res->d_i; pa.row_j = res->d_j; pa.counts = res->d_counts; pa.rec = res->d_rec; pa.G = ctx->d_G; pa.LF = ctx->d_LF;
-        pa.n_shuffles = res->prm.n_shuffles; pa.seed = res->prm.seed; pa.exact_2x2 = res->prm.exact_2x2; pa.site_base = res->prm.stream_site_base;
-        pa.out_p = res->d_p; pa.out_exceed = res->d_exceed; pa.gen_list = d_genlist; pa.gen_count = d_gencount;
-        launch_perm_fast(st, pa);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->ev[6], st));
-        launch_perm_general(st, pa, ctx->ev[7]);
-        HIPCHK(hipGetLastError());
-        ctx->h_scal[1] = 0; ctx->h_scal[4] = 0;
-        HIPCHK(hipMemcpyAsync(&ctx->h_scal[1], d_gencount, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&ctx->h_scal[4], d_gencount + 6, 4, hipMemcpyDeviceToHost, st));
+        const uint64_t chunk_cap = chunked ? ((n_rows + n_chunks - 1) / n_chunks + 1) & ~1ull : res->cap_rows;   // even: the 16-bit narrowing stays aligned
+        if ((rc = pool.alloc((void**)&d_genlist, (size_t)chunk_cap * 4))) return rc;
+        if ((rc = pool.alloc((void**)&d_gencount, 64 * (size_t)n_chunks))) return rc;      // per chunk: [0] queued rows, [1] k_perm_general's next row, [2] rows k_perm_enum leaves to it, [3] some row is enumerable, ...
+        HIPCHK(hipMemsetAsync(d_gencount, 0, 64 * (size_t)n_chunks, st));
+        unsigned long long* const hs = ctx->h_scal;
+        if (chunked) {
+            if ((rc = pool.alloc((void**)&d_chunk_rows, 8 * (size_t)n_chunks))) return rc;
+            for (uint32_t c = 0; c < n_chunks; ++c) hs[HS_ROWS + c] = std::min<uint64_t>(chunk_cap, n_rows - std::min<uint64_t>(n_rows, c * chunk_cap));
+            HIPCHK(hipMemcpyAsync(d_chunk_rows, &hs[HS_ROWS], 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+        }
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint64_t r0 = chunked ? std::min<uint64_t>(n_rows, c * chunk_cap) : 0, nr = chunked ? (uint64_t)hs[HS_ROWS + c] : res->cap_rows;
+            PermArgs pa{};
+            pa.n_rows_dev = chunked ? d_chunk_rows + c : res->d_nrows; pa.max_rows = nr;
+            pa.row_i = res->d_i + r0; pa.row_j = res->d_j + r0; pa.counts = res->d_counts ? res->d_counts + 9 * r0 : nullptr; pa.rec = res->d_rec + r0;
+            pa.G = ctx->d_G; pa.LF = ctx->d_LF;
+            pa.n_shuffles = res->prm.n_shuffles; pa.seed = res->prm.seed; pa.exact_2x2 = res->prm.exact_2x2; pa.site_base = res->prm.stream_site_base;
+            pa.out_p = res->d_p ? res->d_p + r0 : nullptr; pa.out_exceed = res->d_exceed + r0; pa.gen_list = d_genlist; pa.gen_count = d_gencount + 16 * c;
+            hipEvent_t e_fast = chunked ? ctx->event(3 * c) : ctx->ev[6], e_exact = chunked ? ctx->event(3 * c + 1) : ctx->ev[7];
+            launch_perm_fast(st, pa);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(e_fast, st));
+            launch_perm_general(st, pa, e_exact);                // (records e_exact itself, also when it has nothing to do)
+            HIPCHK(hipGetLastError());
+            if (chunked) {
+                HIPCHK(hipEventRecord(ctx->event(3 * c + 2), st));
+                if ((rc = after_chunk(r0, nr))) return rc;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(&hs[HS_GEN], d_gencount, 64 * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
+    if (!(chunked && res->cap_rows) && (rc = after_chunk(0, n_rows))) return rc;
     HIPCHK(wait_stream(st));
-    if (res->cap_rows) n_general = (unsigned int)ctx->h_scal[1];
+    if (res->cap_rows) {
+        const unsigned int* gc = reinterpret_cast<const unsigned int*>(&ctx->h_scal[HS_GEN]);
+        for (uint32_t c = 0; c < n_chunks; ++c) { n_general += gc[16 * c]; n_six += gc[16 * c + 6]; }
+        if (chunked)
+            for (uint32_t c = 0; c < n_chunks; ++c) {        // stage times of a chunked run: the chunks' sums
+                float a = 0.f, b = 0.f;
+                HIPCHK(hipEventElapsedTime(&a, c == 0 ? ctx->ev[3] : ctx->event(3 * c - 1), ctx->event(3 * c)));
+                HIPCHK(hipEventElapsedTime(&b, ctx->event(3 * c), ctx->event(3 * c + 1)));
+                ms_fast += a; ms_exact += b;
+            }
+    }
     lgmi_run_info& inf = res->info;
     inf.n_general_rows = n_general;
-    inf.n_six_rows = res->cap_rows ? (uint32_t)ctx->h_scal[4] : 0u;
+    inf.n_six_rows = (uint32_t)n_six;
     HIPCHK(hipEventElapsedTime(&inf.ms_perm, ctx->ev[3], ctx->ev[4]));
-    HIPCHK(hipEventElapsedTime(&inf.ms_perm_fast, ctx->ev[3], ctx->ev[6]));
-    HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));
-    inf.ms_perm_exact = 0.f;
-    if (res->cap_rows) HIPCHK(hipEventElapsedTime(&inf.ms_perm_exact, ctx->ev[6], ctx->ev[7]));
+    if (chunked) {
+        inf.ms_perm_fast = ms_fast; inf.ms_perm_exact = ms_exact; inf.ms_perm_general = inf.ms_perm - ms_fast;
+    } else {
+        HIPCHK(hipEventElapsedTime(&inf.ms_perm_fast, ctx->ev[3], ctx->ev[6]));
+        HIPCHK(hipEventElapsedTime(&inf.ms_perm_general, ctx->ev[6], ctx->ev[4]));
+        inf.ms_perm_exact = 0.f;
+        if (res->cap_rows) HIPCHK(hipEventElapsedTime(&inf.ms_perm_exact, ctx->ev[6], ctx->ev[7]));
+    }
     inf.ms_total += inf.ms_perm;
     res->perm_pending = false;
     if (!res->has_counts && res->d_counts) { pool.release(res->d_counts); res->d_counts = nullptr; }
     if (res->d_rec) { pool.release(res->d_rec); res->d_rec = nullptr; }
     return LGMI_OK;
+}
+
+extern "C" int lgmi_dresult_permute(lgmi_ctx* ctx, lgmi_dresult* res) {
+    if (!ctx || !res) return fail(LGMI_E_ARG, "NULL argument");
+    if (res->ctx != ctx) return fail(LGMI_E_ARG, "result belongs to another context");
+    if (!res->perm_pending) return LGMI_OK;              // nothing was deferred (no p requested, or already done)
+    return permute_impl(ctx, res, 1u, [](uint64_t, uint64_t) { return LGMI_OK; });
 }
 
 extern "C" int lgmi_dresult_info(const lgmi_dresult* r, lgmi_run_info* out) {
@@ -1374,60 +1462,194 @@ extern "C" void lgmi_result_free(lgmi_result* res) {
     memset(res, 0, sizeof *res);
 }
 
+// ---- the compact row form on the device: full flags, row_begin, the listed partners (include/lgmi.h, lgmi_result).
+// Made on the main stream from the per-site integers every run leaves behind (d_nfirst, d_ncand); one 8-byte read-back
+// sizes the list.  Idempotent.
+static int compact_prepare(lgmi_dresult* r) {
+    if (r->compact_ready) return LGMI_OK;
+    if (!r->table || !r->d_nfirst || !r->d_ncand)
+        return fail(LGMI_E_STATE, "this result has no compact form (gathered from ranks that ran different batches)");
+    lgmi_ctx* ctx = r->ctx;
+    hipStream_t st = ctx->stream;
+    Pool& pool = ctx->pool;
+    const uint32_t ns = (uint32_t)r->n_sites;
+    int rc;
+    uint32_t* d_listed = nullptr; uint64_t* d_list_begin = nullptr; uint64_t* d_scantmp = nullptr;
+    struct Guard { Pool& p; hipStream_t st; uint32_t** a; uint64_t** b; uint64_t** c;
+                   ~Guard() { (void)hipStreamSynchronize(st); p.release(*a); p.release(*b); p.release(*c); } } guard{pool, st, &d_listed, &d_list_begin, &d_scantmp};
+    if ((rc = pool.alloc((void**)&r->d_full, std::max<size_t>(ns, 1)))) return rc;
+    if ((rc = pool.alloc((void**)&r->d_row_begin, ((size_t)ns + 1) * 8))) return rc;
+    if ((rc = pool.alloc((void**)&d_listed, std::max<size_t>(ns, 1) * 4))) return rc;
+    if ((rc = pool.alloc((void**)&d_list_begin, ((size_t)ns + 1) * 8))) return rc;
+    if ((rc = pool.alloc((void**)&d_scantmp, scan_tmp_words(ns) * 8))) return rc;
+    launch_compact_sites(st, ns, r->d_nfirst, r->d_ncand, r->d_full, d_listed, r->d_row_begin, d_list_begin, d_scantmp);
+    HIPCHK(hipGetLastError());
+    unsigned long long* hs = ctx->h_scal;
+    hs[5] = hs[6] = 0;
+    HIPCHK(hipMemcpyAsync(&hs[5], d_list_begin + ns, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&hs[6], r->d_row_begin + ns, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(wait_stream(st));
+    if (hs[6] != r->n_rows) return fail(LGMI_E_STATE, "internal: per-site row counts add up to %llu, the result has %llu rows",
+                                        (unsigned long long)hs[6], (unsigned long long)r->n_rows);
+    r->n_jlisted = hs[5];
+    if (r->n_jlisted) {
+        if ((rc = pool.alloc((void**)&r->d_jlisted, (size_t)r->n_jlisted * 4))) return rc;
+        launch_list_partners(st, ns, r->d_full, r->d_row_begin, d_list_begin, r->d_j, r->d_jlisted);
+        HIPCHK(hipGetLastError());
+    }
+    r->compact_ready = true;
+    return LGMI_OK;
+}
+// permutation counts in 16 bits: every count is at most n_shuffles
+static bool exceed_fits16(const lgmi_dresult* r) { return r->has_p && r->p_from_exceed && r->n_shuffles <= 65535u; }
+
 // HBM -> pinned host buffers in two parts, so that lgmi_run can bring the rows over while the permutation stage still
-// runs: part 1 = everything that is final after the emit stage, part 2 = row_p / row_exceed
-static int fetch_part(lgmi_dresult* r, HostResult* h, lgmi_result* out, hipStream_t st, int part) {
+// runs: part 1 = everything that is final after the emit stage, part 2 = row_p / row_exceed of the rows [r0, r0 + nr)
+// (part 2 is called once per chunk of a chunked permutation stage; its host arrays are taken on the first call)
+static int fetch_part(lgmi_dresult* r, HostResult* h, lgmi_result* out, hipStream_t st, int part, bool compact,
+                      uint64_t r0 = 0, uint64_t nr = ~0ull) {
     const size_t n = (size_t)r->n_rows, ns = (size_t)r->n_sites;
     auto d2h = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
     };
     if (part == 1) {
-        uint32_t* hi = h->take<uint32_t>(n); uint32_t* hj = h->take<uint32_t>(n); double* hmi = h->take<double>(n);
+        double* hmi = h->take<double>(n);
         double* hmean = h->take<double>(ns); uint32_t* hnp = h->take<uint32_t>(ns);
         uint32_t* hc = r->has_counts ? h->take<uint32_t>(n * 9) : nullptr;
-        if (!hi || !hj || !hmi || !hmean || !hnp || (r->has_counts && !hc)) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
-        HIPCHK(d2h(hi, r->d_i, n * 4));
-        HIPCHK(d2h(hj, r->d_j, n * 4));
+        if (!hmi || !hmean || !hnp || (r->has_counts && !hc)) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
+        if (compact) {
+            uint64_t* hb = h->take<uint64_t>(ns + 1); uint8_t* hf = h->take<uint8_t>(ns);
+            uint32_t* hl = r->n_jlisted ? h->take<uint32_t>((size_t)r->n_jlisted) : nullptr;
+            if (!hb || !hf || (r->n_jlisted && !hl)) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
+            HIPCHK(d2h(hb, r->d_row_begin, (ns + 1) * 8));
+            HIPCHK(d2h(hf, r->d_full, ns));
+            if (hl) HIPCHK(d2h(hl, r->d_jlisted, (size_t)r->n_jlisted * 4));
+            out->compact = 1; out->row_begin = hb; out->site_row_full = hf; out->row_j_listed = hl; out->n_row_j_listed = r->n_jlisted;
+            h->table = r->table; h->het_only = r->het_only;
+        } else {
+            uint32_t* hi = h->take<uint32_t>(n); uint32_t* hj = h->take<uint32_t>(n);
+            if (!hi || !hj) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
+            HIPCHK(d2h(hi, r->d_i, n * 4));
+            HIPCHK(d2h(hj, r->d_j, n * 4));
+            out->row_i = hi; out->row_j = hj;
+        }
         HIPCHK(d2h(hmi, r->d_mi, n * 8));
         HIPCHK(d2h(hmean, r->d_mean, ns * 8));
         HIPCHK(d2h(hnp, r->d_npairs, ns * 4));
         if (r->has_counts) HIPCHK(d2h(hc, r->d_counts, n * 36));
         out->n_rows = n; out->n_sites = ns;
-        out->row_i = hi; out->row_j = hj; out->row_mi = hmi; out->row_counts = hc;
+        out->row_mi = hmi; out->row_counts = hc;
         out->site_mean_mi = hmean; out->site_n_pairs = hnp;
     } else if (r->has_p) {
         // row_p travels only when it exists as an array (lgmi_params.no_row_p: it is (1 + exceed) / (n_shuffles + 1),
         // 8 of the 28 bytes a row used to cost on the way to the host)
-        double* hp = r->d_p ? h->take<double>(n) : nullptr; uint32_t* hex = h->take<uint32_t>(n);
-        if ((r->d_p && !hp) || !hex) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
-        if (r->d_p) HIPCHK(d2h(hp, r->d_p, n * 8));
-        HIPCHK(d2h(hex, r->d_exceed, n * 4));
-        out->row_p = hp; out->row_exceed = hex;
-        out->n_shuffles = r->n_shuffles; out->row_p_derived = r->d_p ? 0u : 1u;
+        const bool narrow = compact && exceed_fits16(r);
+        if (!out->row_exceed && !out->row_exceed16) {
+            double* hp = r->d_p ? h->take<double>(n) : nullptr;
+            uint32_t* hex = narrow ? nullptr : h->take<uint32_t>(n);
+            uint16_t* hex16 = narrow ? h->take<uint16_t>(n) : nullptr;
+            if ((r->d_p && !hp) || (!hex && !hex16)) return fail(LGMI_E_OOM, "pinned host memory for %zu result rows", n);
+            out->row_p = hp; out->row_exceed = hex; out->row_exceed16 = hex16;
+            out->n_shuffles = r->n_shuffles; out->row_p_derived = r->d_p ? 0u : 1u;
+        }
+        if (r0 > n) r0 = n;
+        if (nr > n - r0) nr = n - r0;
+        if (r->d_p) HIPCHK(d2h(const_cast<double*>(out->row_p) + r0, r->d_p + r0, nr * 8));
+        if (narrow) HIPCHK(d2h(const_cast<uint16_t*>(out->row_exceed16) + r0, r->d_exceed16 + r0, nr * 2));
+        else HIPCHK(d2h(const_cast<uint32_t*>(out->row_exceed) + r0, r->d_exceed + r0, nr * 4));
     }
     return LGMI_OK;
 }
 
-extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out) {
+static int fetch_impl(lgmi_dresult* r, lgmi_result* out, bool compact) {
     if (!r || !out) return fail(LGMI_E_ARG, "NULL argument");
     memset(out, 0, sizeof *out);
     if (r->perm_pending) return fail(LGMI_E_STATE, "the permutation stage of this result has not run (lgmi_dresult_permute)");
     HIPCHK(hipSetDevice(r->ctx->device));
+    hipStream_t st = r->ctx->stream;
+    int rc;
+    if (compact) {
+        if ((rc = compact_prepare(r))) return rc;
+        if (exceed_fits16(r) && !r->d_exceed16 && r->n_rows) {
+            if ((rc = r->ctx->pool.alloc((void**)&r->d_exceed16, (size_t)r->n_rows * 2 + 4))) return rc;
+            launch_narrow_u16(st, r->n_rows, r->d_exceed, r->d_exceed16);
+            HIPCHK(hipGetLastError());
+        }
+    }
     HostResult* h = new HostResult();
     h->pool = r->ctx->pinned;
     struct Guard { HostResult* p; ~Guard() { delete p; } } guard{h};
-    hipStream_t st = r->ctx->stream;
-    int rc = fetch_part(r, h, out, st, 1);
-    if (!rc) rc = fetch_part(r, h, out, st, 2);
-    if (rc) { memset(out, 0, sizeof *out); return rc; }
+    rc = fetch_part(r, h, out, st, 1, compact);
+    if (!rc) rc = fetch_part(r, h, out, st, 2, compact);
+    if (rc) { (void)hipStreamSynchronize(st); memset(out, 0, sizeof *out); return rc; }
     HIPCHK(wait_stream(st));
     out->owner_ = static_cast<ResultOwner*>(h);
     guard.p = nullptr;
     return LGMI_OK;
 }
+extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out) { return fetch_impl(r, out, false); }
+extern "C" int lgmi_dresult_fetch_compact(lgmi_dresult* r, lgmi_result* out) { return fetch_impl(r, out, true); }
+
+// compact form -> plain row_i / row_j on the host (include/lgmi.h).  Threads take site ranges of equal row counts.
+extern "C" int lgmi_result_expand_rows(const lgmi_result* res, uint32_t* row_i, uint32_t* row_j) {
+    if (!res) return fail(LGMI_E_ARG, "res is NULL");
+    const uint64_t n = res->n_rows, ns = res->n_sites;
+    if (!res->compact) {
+        if ((row_i && !res->row_i) || (row_j && !res->row_j)) return fail(LGMI_E_STATE, "the result holds no row_i / row_j");
+        if (row_i && n) memcpy(row_i, res->row_i, n * 4);
+        if (row_j && n) memcpy(row_j, res->row_j, n * 4);
+        return LGMI_OK;
+    }
+    const HostResult* h = dynamic_cast<const HostResult*>(static_cast<const ResultOwner*>(res->owner_));
+    if (!h || !h->table || !res->row_begin || !res->site_row_full) return fail(LGMI_E_STATE, "not a compact result of this library");
+    const SiteTable& tb = *h->table;
+    if (tb.type.size() != ns) return fail(LGMI_E_STATE, "internal: site table of %zu sites, result of %llu", tb.type.size(), (unsigned long long)ns);
+    const bool het_only = h->het_only;
+    const uint64_t nb = tb.block_site_begin.size() - 1;
+    const uint64_t* const rb = res->row_begin;
+    // offsets of the listed partners: a prefix over the sites that are not full
+    PodVec<uint64_t> lb;
+    lb.resize(ns + 1);
+    { uint64_t o = 0; for (uint64_t s = 0; s < ns; ++s) { lb[s] = o; if (!res->site_row_full[s]) o += rb[s + 1] - rb[s]; } lb[ns] = o; }
+    if (lb[ns] != res->n_row_j_listed) return fail(LGMI_E_STATE, "internal: %llu listed partners, the flags ask for %llu",
+                                                   (unsigned long long)res->n_row_j_listed, (unsigned long long)lb[ns]);
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(plan_threads(1u << 20), n >> 20));
+    Team team(T);
+    team.run([&](unsigned t) {
+        // a thread writes the sites whose first row falls into its share of the rows (it walks every block's site list — a
+        // site's implicit partners are the later sites of its block — and skips the blocks outside its share)
+        const uint64_t r_lo = n * t / T, r_hi = n * (t + 1) / T;
+        std::vector<uint32_t> xs;
+        for (uint64_t b = 0; b < nb; ++b) {
+            const uint64_t sb = tb.block_site_begin[b], se = tb.block_site_begin[b + 1];
+            if (rb[se] <= r_lo || rb[sb] >= r_hi) continue;
+            bool have_xs = false;
+            uint32_t xnext = 0;                                   // x sites of the block at or before s
+            for (uint64_t s = sb; s < se; ++s) {
+                const bool is_x = !het_only || tb.type[s] == LGMI_TYPE_HET_SNP;
+                if (is_x) ++xnext;
+                const uint64_t r0 = rb[s], cnt = rb[s + 1] - r0;
+                if (!cnt || r0 < r_lo || r0 >= r_hi) continue;   // (a site's rows belong to the thread its first row falls to)
+                if (row_i) std::fill(row_i + r0, row_i + r0 + cnt, (uint32_t)s);
+                if (!row_j) continue;
+                if (!res->site_row_full[s]) { memcpy(row_j + r0, res->row_j_listed + lb[s], cnt * 4); continue; }
+                if (is_x) { for (uint64_t k = 0; k < cnt; ++k) row_j[r0 + k] = (uint32_t)(s + 1 + k); continue; }
+                if (!have_xs) {                                   // the block's x sites, once per thread that needs them
+                    xs.clear();
+                    for (uint64_t q = sb; q < se; ++q) if (tb.type[q] == LGMI_TYPE_HET_SNP) xs.push_back((uint32_t)q);
+                    have_xs = true;
+                }
+                memcpy(row_j + r0, xs.data() + xnext, cnt * 4);
+            }
+        }
+    });
+    return LGMI_OK;
+}
 
 // upload + run + fetch in one call.  With permutation p-values the run is split: the rows start their way to the host
-// (communication stream) while the permutation stage runs on the main stream.
+// (communication stream) while the permutation stage runs on the main stream — and the stage itself runs in a few row
+// ranges (LGMI_PERM_CHUNKS, default 4 from 32 M rows on), each range's counts following the rows as soon as its kernels
+// are done, so that what is left to copy when the last kernel ends is one range's counts.
 extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_params* prm, lgmi_result* out,
                         lgmi_run_info* info) {
     if (!out) return fail(LGMI_E_ARG, "out is NULL");
@@ -1451,19 +1673,52 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
     if (!split) rc = run_device_impl(ctx, db, prm, &dr, true);
     tr.mark("rows");
     if (!rc) {
+        const bool compact = prm->compact_rows != 0;
+        if (compact) rc = compact_prepare(dr);
+        tr.mark("compact");
         HostResult* h = new HostResult();
         h->pool = ctx->pinned;
-        hipStream_t cs = ctx_comm_stream(ctx);
-        rc = fetch_part(dr, h, out, cs, 1);                 // in flight under the permutation stage
+        hipStream_t cs = ctx_comm_stream(ctx), ms = ctx->stream;
+        hipEvent_t ce = ctx_comm_event(ctx);
+        if (!rc && cs != ms) {                                   // the communication stream behind what made the rows (and the compact form)
+            if (!ce) rc = fail(LGMI_E_HIP, "no event for the communication stream");
+            else if (hipEventRecord(ce, ms) != hipSuccess || hipStreamWaitEvent(cs, ce, 0) != hipSuccess) rc = fail(LGMI_E_HIP, "stream ordering failed in lgmi_run");
+        }
+        if (!rc) rc = fetch_part(dr, h, out, cs, 1, compact);   // in flight under the permutation stage
         tr.mark("fetch1_posted");
-        if (!rc) rc = lgmi_dresult_permute(ctx, dr);
+        if (!rc && dr->perm_pending) {
+            const bool narrow = compact && exceed_fits16(dr);
+            if (narrow && dr->n_rows) rc = ctx->pool.alloc((void**)&dr->d_exceed16, (size_t)dr->n_rows * 2 + 4);
+            uint32_t n_chunks = dr->n_rows >= (32ull << 20) ? 4u : 1u;
+            if (const char* e = getenv("LGMI_PERM_CHUNKS")) n_chunks = (uint32_t)std::max(1, atoi(e));
+            uint32_t k_ev = 0;
+            if (!rc) rc = permute_impl(ctx, dr, n_chunks, [&](uint64_t r0, uint64_t nr) -> int {
+                // the range's counts: narrowed behind its kernels, then on their way while the next range is computed
+                if (narrow) { launch_narrow_u16(ms, nr, dr->d_exceed + r0, dr->d_exceed16 + r0); HIPCHK(hipGetLastError()); }
+                if (cs != ms) {
+                    hipEvent_t e = ctx->event(96 + k_ev++);
+                    if (!e) return fail(LGMI_E_HIP, "hipEventCreate failed");
+                    HIPCHK(hipEventRecord(e, ms));
+                    HIPCHK(hipStreamWaitEvent(cs, e, 0));
+                }
+                return fetch_part(dr, h, out, cs, 2, compact, r0, nr);
+            });
+        } else if (!rc) {
+            // no deferred stage (no p-values, or a run cut into sequential shards whose shards ran theirs): one copy
+            if (compact && exceed_fits16(dr) && dr->n_rows) {
+                rc = ctx->pool.alloc((void**)&dr->d_exceed16, (size_t)dr->n_rows * 2 + 4);
+                if (!rc) { launch_narrow_u16(cs, dr->n_rows, dr->d_exceed, dr->d_exceed16); if (hipGetLastError() != hipSuccess) rc = fail(LGMI_E_HIP, "narrowing kernel"); }
+            }
+            if (!rc) rc = fetch_part(dr, h, out, cs, 2, compact);
+        }
         tr.mark("permuted");
-        if (!rc) rc = fetch_part(dr, h, out, cs, 2);
-        tr.mark("fetch2_posted");
         if (!rc && hipStreamSynchronize(cs) != hipSuccess) rc = fail(LGMI_E_HIP, "hipStreamSynchronize failed in lgmi_run");
-        if (rc) { (void)hipStreamSynchronize(cs); delete h; memset(out, 0, sizeof *out); }
+        if (rc) { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ms); delete h; memset(out, 0, sizeof *out); }
         else {
             out->owner_ = static_cast<ResultOwner*>(h);
+            dr->info.bytes_out = dr->n_rows * (8ull + (dr->has_counts ? 36ull : 0ull) + (dr->d_p ? 8ull : 0ull) +
+                                               (dr->has_p ? (out->row_exceed16 ? 2ull : 4ull) : 0ull) + (compact ? 0ull : 8ull)) +
+                                 (compact ? 4ull * dr->n_jlisted + 9ull * dr->n_sites : 0ull);
             if (info) *info = dr->info;
         }
     }

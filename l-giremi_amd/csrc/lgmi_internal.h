@@ -27,10 +27,10 @@ struct BlockPlan {
     uint64_t slot_base;  // first slot of the block's nx x ny_pad slot matrix
     uint32_t xl_off;     // offset of the block's x list in xlist[]
     uint32_t yl_off;     // offset of the block's y list in ylist[]
-    uint32_t nx;         // rows: x sites then pseudo rows of tri x sites
+    uint32_t nx;         // rows: x sites in position order, a tri x site's pseudo row right behind its own
     uint32_t ny;         // cols: non-x sites, x sites, pseudo cols of tri sites
     uint32_t ny_pad;     // row stride of the slot matrix (multiple of 4)
-    uint32_t nxs;        // number of real x sites (prefix of the x list)
+    uint32_t nxs;        // number of real x sites (x ranks 0 .. nxs - 1)
     uint32_t site_begin; // first global site of the block
     uint32_t site_end;
     // matrix-core blocks (FP4 kernel): the operands re-laid in the order the waves load them (k_gather_ops):
@@ -119,7 +119,7 @@ struct EmitArgs {
     int het_only;
     const BlockPlan* plans;
     const SiteMap* smap;
-    const uint32_t* xlist;
+    const uint32_t* xsites;   // the y list (its x part, [yl_off + n_sites_of_block - nxs, + nxs), lists the x sites by rank)
     const Col* cols;
     const uint8_t* type;
     const uint8_t* tri;
@@ -155,6 +155,15 @@ void launch_sites_add(hipStream_t st, uint32_t n_sites, unsigned long long* sum,
                       uint32_t* cnt, const uint32_t* cnt_part);
 void launch_rows_mean(hipStream_t st, uint64_t n_rows, const uint32_t* ri, const uint32_t* rj,
                       const double* mi, unsigned long long* sum, uint32_t* cnt);
+// the compact row form (ABI 6): per-site row counts by first site / candidate counts, full flags + offsets, listed partners
+void launch_site_rows(hipStream_t st, uint32_t n_items, const uint2* items, const uint32_t* row_cnt, uint32_t n_sites,
+                      const SiteMap* smap, const BlockPlan* plans, uint32_t* n_first, uint32_t* n_cand);
+void launch_compact_sites(hipStream_t st, uint32_t n_sites, const uint32_t* n_first, const uint32_t* n_cand, uint8_t* full,
+                          uint32_t* listed_tmp, uint64_t* row_begin, uint64_t* list_begin, uint64_t* scan_tmp);
+void launch_list_partners(hipStream_t st, uint32_t n_sites, const uint8_t* full, const uint64_t* row_begin, const uint64_t* list_begin,
+                          const uint32_t* row_j, uint32_t* out);
+void launch_narrow_u16(hipStream_t st, uint64_t n, const uint32_t* in, uint16_t* out);
+void launch_add_u32(hipStream_t st, uint32_t n, uint32_t* acc, const uint32_t* part);
 
 // perm.hip
 struct PermArgs {

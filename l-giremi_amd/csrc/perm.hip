@@ -986,7 +986,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
                 b += (double)N;
                 b += det_log(((double)Ao + 1.0) * ((double)Ap + 1.0));
                 b -= (double)sobs * 3.725290298461914e-09;
-                if (b < -23.1) { st = 3; ins_x = 4611686018427387904ull; }          // (thr = 0)
+                if (b < -23.1) {                                                     // (thr = 0)
+                    st = 3; ins_x = 4611686018427387904ull;
+                    if (pa.exact_2x2) {
+                        // the exact p of such a row is the bound itself (an upper bound of the tail mass, never 0.0; six_thr in
+                        // the specification): carried to phase D as the double's bits under bit 63, which no mass ever sets
+                        const double pb = det_exp(b);
+                        ins_x = (unsigned long long)__double_as_longlong(pb > 2.2250738585072014e-308 ? pb : 2.2250738585072014e-308) | (1ull << 63);
+                    }
+                }
                 else {
                     HG22 hc;
                     hg22_set(hc, N, Ao, B0, 0.0);
@@ -1155,6 +1163,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGMI_SIX_WPS
             if (pa.exact_2x2) {                              // the exact p: one minus the inside mass (six_thr's p_out in the oracle)
                 double p = 1.0 - (double)ins * 2.168404344971009e-19;
                 if (p < 0.0) p = 0.0;
+                if (ins >> 63) p = __longlong_as_double((long long)(ins & ~(1ull << 63)));   // the zero test's bound (phase S)
                 out_exceed[r_d] = LGMI_EXCEED_EXACT;
                 out_p[r_d] = p;
             } else {

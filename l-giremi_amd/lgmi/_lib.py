@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LGMI_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'liblgmi.so'))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK, E_ARG, E_OOM, E_HIP, E_RCCL, E_NODEV, E_STATE, E_DOMAIN = 0, -1, -2, -3, -4, -5, -6, -7
 TYPE_MISMATCH, TYPE_SNP, TYPE_HET_SNP = 0, 1, 2
 UNIQUE_ID_BYTES = 128
@@ -18,6 +18,7 @@ EXCEED_EXACT = 0xFFFFFFFF
 NONE = 0xFFFFFFFF
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+u16p = C.POINTER(C.c_uint16)
 i64p, f64p = C.POINTER(C.c_int64), C.POINTER(C.c_double)
 
 
@@ -32,14 +33,17 @@ class Params(C.Structure):
     _fields_ = [('min_common', C.c_uint32), ('n_shuffles', C.c_uint32), ('seed', C.c_uint64),
                 ('het_only', C.c_uint8), ('emit_counts', C.c_uint8), ('exact_2x2', C.c_uint8),
                 ('no_row_p', C.c_uint8), ('shard_rank', C.c_uint16), ('shard_world', C.c_uint16),
-                ('stream_site_base', C.c_uint32), ('reserved1', C.c_uint32)]
+                ('stream_site_base', C.c_uint32), ('compact_rows', C.c_uint8), ('reserved1', C.c_uint8 * 3)]
 
 
 class Result(C.Structure):
     _fields_ = [('n_rows', C.c_uint64), ('n_sites', C.c_uint64), ('row_i', u32p), ('row_j', u32p),
                 ('row_mi', f64p), ('row_p', f64p), ('row_exceed', u32p), ('row_counts', u32p),
                 ('site_mean_mi', f64p), ('site_n_pairs', u32p), ('owner_', C.c_void_p),
-                ('n_shuffles', C.c_uint32), ('row_p_derived', C.c_uint32)]
+                ('n_shuffles', C.c_uint32), ('row_p_derived', C.c_uint32),
+                # ABI 6: the compact row form (include/lgmi.h)
+                ('compact', C.c_uint32), ('reserved3', C.c_uint32), ('row_begin', u64p), ('site_row_full', u8p),
+                ('row_j_listed', u32p), ('n_row_j_listed', C.c_uint64), ('row_exceed16', u16p)]
 
 
 class RunInfo(C.Structure):
@@ -108,6 +112,8 @@ SYMBOLS = {
     'lgmi_dresult_info': (C.c_int, [VP, C.POINTER(RunInfo)]),
     'lgmi_dresult_device_ptrs': (C.c_int, [VP, C.POINTER(Result)]),
     'lgmi_dresult_fetch': (C.c_int, [VP, C.POINTER(Result)]),
+    'lgmi_dresult_fetch_compact': (C.c_int, [VP, C.POINTER(Result)]),
+    'lgmi_result_expand_rows': (C.c_int, [C.POINTER(Result), u32p, u32p]),
     'lgmi_dresult_free': (None, [VP]),
     'lgmi_run': (C.c_int, [VP, C.POINTER(Batch), C.POINTER(Params), C.POINTER(Result), C.POINTER(RunInfo)]),
     'lgmi_result_free': (None, [C.POINTER(Result)]),

@@ -9,6 +9,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
+from ._lib import check
 from .pack import PackedBatch
 
 
@@ -17,15 +18,49 @@ class MIResult:
 
     ``row_p``: the permutation p of every row, or None without p-values.  The library is asked not to make the array
     when it is a function of ``row_exceed`` (Monte-Carlo estimates: ``(1 + row_exceed) / (n_shuffles + 1)``,
-    lgmi_params.no_row_p) — 8 of 28 bytes per row that need not cross PCIe; it is derived here on first use."""
+    lgmi_params.no_row_p) — 8 of 28 bytes per row that need not cross PCIe; it is derived here on first use.
+
+    ``row_i`` / ``row_j`` / ``row_exceed``: with the compact row form (include/lgmi.h, ABI 6: what ``Engine.run`` asks
+    for) the library ships per-site row offsets instead of ``row_i``, no partner at all for a site whose every candidate
+    pair was emitted, and 16-bit counts; the plain arrays are made on first use (``lgmi_result_expand_rows``), the way
+    ``row_p`` is.  ``row_begin`` / ``site_row_full`` / ``row_j_listed`` are the compact arrays themselves (None otherwise)."""
 
     def __init__(self, row_i, row_j, row_mi, row_p, row_exceed, row_counts, site_mean_mi, site_n_pairs, info,
-                 n_shuffles=0, p_derived=False):
-        self.row_i, self.row_j, self.row_mi = row_i, row_j, row_mi
-        self._row_p, self.row_exceed = row_p, row_exceed
+                 n_shuffles=0, p_derived=False, compact=None):
+        self._row_i, self._row_j, self.row_mi = row_i, row_j, row_mi
+        self._row_p, self._row_exceed = row_p, row_exceed
         self.row_counts = row_counts             # (n_rows, 3, 3): [class at i][class at j]
         self.site_mean_mi, self.site_n_pairs, self.info = site_mean_mi, site_n_pairs, info
         self.n_shuffles, self._p_derived = int(n_shuffles), bool(p_derived)
+        # compact: dict(row_begin, site_row_full, row_j_listed, row_exceed16, expand) or None
+        self._compact = compact
+        self.row_begin = compact['row_begin'] if compact else None
+        self.site_row_full = compact['site_row_full'] if compact else None
+        self.row_j_listed = compact['row_j_listed'] if compact else None
+
+    @property
+    def compact(self):
+        return self._compact is not None
+
+    def _expand(self):
+        if self._row_i is None and self._compact is not None:
+            self._row_i, self._row_j = self._compact['expand']()
+
+    @property
+    def row_i(self):
+        self._expand()
+        return self._row_i
+
+    @property
+    def row_j(self):
+        self._expand()
+        return self._row_j
+
+    @property
+    def row_exceed(self):
+        if self._row_exceed is None and self._compact is not None and self._compact.get('row_exceed16') is not None:
+            self._row_exceed = self._compact['row_exceed16'].astype(np.uint32)
+        return self._row_exceed
 
     @property
     def row_p(self):
@@ -35,7 +70,7 @@ class MIResult:
 
     @property
     def n_rows(self):
-        return len(self.row_i)
+        return len(self.row_mi)
 
 
 class _HostRows:
@@ -52,44 +87,61 @@ class _HostRows:
 
 
 def _copy_result(res: _lib.Result, info: dict, owner: _HostRows = None) -> MIResult:
-    """owner given: the arrays are VIEWS of the library's host buffers (no copy: the rows of a batch of footprints are
-    hundreds of megabytes) that keep the owner — and with it the buffers — alive; else copies"""
+    """owner given: the arrays are read-only VIEWS of the library's host buffers (no copy: the rows of a batch of footprints
+    are hundreds of megabytes) that keep the owner — and with it the buffers — alive; the small per-site arrays are copies,
+    so that keeping one of them does not hold hundreds of megabytes of pinned memory.  Else copies."""
     n, ns = int(res.n_rows), int(res.n_sites)
-    ctype = {np.uint32: C.c_uint32, np.float64: C.c_double}
+    ctype = {np.uint32: C.c_uint32, np.float64: C.c_double, np.uint64: C.c_uint64, np.uint8: C.c_uint8, np.uint16: C.c_uint16}
 
-    def a(ptr, count, dt, shape=None, present=True):
+    def a(ptr, count, dt, shape=None, present=True, copy=False):
         if not present:
             return None
         if count == 0 or not ptr:
             out = np.zeros(count if not ptr and count else 0, dt)
-        elif owner is not None:
+        elif owner is not None and not copy:
             buf = (ctype[dt] * count).from_address(C.addressof(ptr.contents))
             buf._owner = owner                       # array -> memoryview -> buf -> owner
             out = np.frombuffer(buf, dtype=dt)
+            out.flags.writeable = False              # library-owned (pinned) memory: not the caller's to edit
         else:
             out = np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
         return out.reshape(shape) if shape else out
-    has_e = bool(res.row_exceed) or (n == 0 and info.get('has_p', False))
+    is_compact = bool(res.compact)
+    has_e = bool(res.row_exceed) or (n == 0 and info.get('has_p', False) and not res.row_exceed16)
     derived = bool(res.row_p_derived)
     has_p = (bool(res.row_p) or (n == 0 and info.get('has_p', False))) and not derived
     has_c = bool(res.row_counts) or (n == 0 and info.get('has_counts', False))
-    return MIResult(a(res.row_i, n, np.uint32), a(res.row_j, n, np.uint32), a(res.row_mi, n, np.float64),
+    compact = None
+    if is_compact:
+        if owner is None:
+            raise ValueError('a compact result needs its owner (lgmi_result_expand_rows reads the library\'s arrays)')
+
+        def expand():
+            ri, rj = np.empty(n, np.uint32), np.empty(n, np.uint32)
+            check(owner.lib.lgmi_result_expand_rows(C.byref(owner.res), ri.ctypes.data_as(_lib.u32p), rj.ctypes.data_as(_lib.u32p)))
+            return ri, rj
+        compact = {'row_begin': a(res.row_begin, ns + 1, np.uint64, copy=True), 'site_row_full': a(res.site_row_full, ns, np.uint8, copy=True),
+                   'row_j_listed': a(res.row_j_listed, int(res.n_row_j_listed), np.uint32),
+                   'row_exceed16': a(res.row_exceed16, n, np.uint16, present=bool(res.row_exceed16)), 'expand': expand}
+    return MIResult(a(res.row_i, n, np.uint32, present=not is_compact), a(res.row_j, n, np.uint32, present=not is_compact),
+                    a(res.row_mi, n, np.float64),
                     a(res.row_p, n, np.float64, present=has_p), a(res.row_exceed, n, np.uint32, present=has_e),
                     a(res.row_counts, 9 * n, np.uint32, (n, 3, 3), present=has_c),
-                    a(res.site_mean_mi, ns, np.float64), a(res.site_n_pairs, ns, np.uint32), info,
-                    n_shuffles=int(res.n_shuffles), p_derived=derived)
+                    a(res.site_mean_mi, ns, np.float64, copy=True), a(res.site_n_pairs, ns, np.uint32, copy=True), info,
+                    n_shuffles=int(res.n_shuffles), p_derived=derived, compact=compact)
 
 
 def make_params(min_common=5, n_shuffles=0, seed=0, het_only=True, emit_counts=False, exact_2x2=False,
-                shard=None, no_row_p=True, stream_site_base=0) -> _lib.Params:
+                shard=None, no_row_p=True, stream_site_base=0, compact=False) -> _lib.Params:
     """shard = (rank, world): compute only that contiguous, cost-balanced slice of the result rows.
-    no_row_p (default): row_p is not made as an array when it is a function of row_exceed (MIResult.row_p derives it)"""
+    no_row_p (default): row_p is not made as an array when it is a function of row_exceed (MIResult.row_p derives it).
+    compact: lgmi_run returns the compact row form (MIResult.row_i / row_j / row_exceed expand it on first use)"""
     if min_common < 0:
         min_common = 0
     rank, world = (0, 0) if shard is None else (int(shard[0]), int(shard[1]))
     return _lib.Params(int(min_common), int(n_shuffles), int(seed) & (2**64 - 1),
                        1 if het_only else 0, 1 if emit_counts else 0, 1 if exact_2x2 else 0, 1 if no_row_p else 0, rank, world,
-                       int(stream_site_base), 0)
+                       int(stream_site_base), 1 if compact else 0, (C.c_uint8 * 3)())
 
 
 def plan_shard(batch: PackedBatch, het_only=True, shard=(0, 1), n_shuffles=0) -> dict:
@@ -157,9 +209,11 @@ class DeviceResult:
         """the permutation stage of a result made with run_device(..., rows_only=True)"""
         _lib.check(self.engine.lib.lgmi_dresult_permute(self.engine.handle, self.handle))
 
-    def fetch(self) -> MIResult:
+    def fetch(self, compact=False) -> MIResult:
+        """compact=True: the compact row form crosses PCIe (lgmi_dresult_fetch_compact); MIResult expands it on first use"""
         res = _lib.Result()
-        _lib.check(self.engine.lib.lgmi_dresult_fetch(self.handle, C.byref(res)))
+        fn = self.engine.lib.lgmi_dresult_fetch_compact if compact else self.engine.lib.lgmi_dresult_fetch
+        _lib.check(fn(self.handle, C.byref(res)))
         return _copy_result(res, self.info(), _HostRows(self.engine.lib, res))
 
     def free(self):
@@ -232,10 +286,10 @@ class Engine:
         _lib.check(self.lib.lgmi_ctx_synchronize(self.handle))
 
     def run(self, batch: PackedBatch, min_common=5, n_shuffles=0, seed=0, het_only=True,
-            emit_counts=False, exact_2x2=False, shard=None, no_row_p=True, stream_site_base=0) -> MIResult:
+            emit_counts=False, exact_2x2=False, shard=None, no_row_p=True, stream_site_base=0, compact=True) -> MIResult:
         self._alive()
         st, prm = batch.as_struct(), make_params(min_common, n_shuffles, seed, het_only, emit_counts, exact_2x2, shard, no_row_p,
-                                                 stream_site_base)
+                                                 stream_site_base, compact)
         res, info = _lib.Result(), _lib.RunInfo()
         _lib.check(self.lib.lgmi_run(self.handle, C.byref(st), C.byref(prm), C.byref(res), C.byref(info)))
         d = info.as_dict()

@@ -834,6 +834,7 @@ typedef struct {
     hg22 hc;                                /* the collapsed table */
     int64_t zlo, zhi;                       /* chords z in (zlo, zhi) */
     int zero;                               /* the zero test fired: thr = 0 */
+    double zero_bound;                      /* ... and the bound it fired on: ln of an upper bound of the tail mass */
 } six_row;
 
 /* last x in [lo, hi] with stat22(h, x) >= s for a predicate that is true then false along x; lo is a sentinel (never evaluated) */
@@ -921,7 +922,7 @@ static int six_plan_x(const perm_tables* t, const uint32_t T[9], uint32_t n_shuf
         b += (double)N;
         b += lnt;
         b -= (double)s->sobs * 3.725290298461914e-09;     /* 2^-28 */
-        if (b < -23.1) { s->zero = 1; return 1; }
+        if (b < -23.1) { s->zero = 1; s->zero_bound = b; return 1; }
     }
     hg22_set(&s->hc, N, s->A[s->o], s->B0, 0.0);
     sc = s->sobs + 8 - (t->G[s->A[s->p]] + t->G[s->A[s->q]] - t->G[s->A[s->p] + s->A[s->q]]);
@@ -1086,7 +1087,13 @@ static uint64_t six_inside_walk(const perm_tables* t, const six_row* s)
 static uint64_t six_thr(const perm_tables* t, const six_row* s, double* p_out)
 {
     uint64_t inside;
-    if (s->zero) { if (p_out) *p_out = 0.0; return 0; }
+    /* the exact p of a row the zero test decided: the BOUND the test fired on (an upper bound of the tail mass, below
+     * e^-23.1 = 9.3e-11), floored at the smallest normal double — never 0.0, which no permutation test can give (the observed
+     * table is itself in the tail) and which breaks -log10(p) downstream (advice r4) */
+    if (s->zero) {
+        if (p_out) { const double pb = lgo_det_exp(s->zero_bound); *p_out = pb > 2.2250738585072014e-308 ? pb : 2.2250738585072014e-308; }
+        return 0;
+    }
     inside = six_inside_walk(t, s);
     if (p_out) { *p_out = 1.0 - (double)inside * 2.168404344971009e-19; if (*p_out < 0.0) *p_out = 0.0; }
     return inside <= 4611686018427387904ull ? (4611686018427387904ull - inside) >> 30 : 0;

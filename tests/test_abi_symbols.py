@@ -46,7 +46,7 @@ def test_abi_version_and_struct_sizes():
     assert lib.lgmi_abi_version() == _lib.ABI_VERSION
     assert C.sizeof(_lib.Batch) == 88
     assert C.sizeof(_lib.Params) == 32
-    assert C.sizeof(_lib.Result) == 96
+    assert C.sizeof(_lib.Result) == 144
     assert C.sizeof(_lib.RunInfo) == 128
     assert C.sizeof(_lib.ShardPlan) == 152
     assert C.sizeof(_lib.GatherOpts) == 8

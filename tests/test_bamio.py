@@ -237,3 +237,109 @@ def test_a_record_size_completed_across_blocks_is_checked_before_it_is_believed(
                         bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000'))
         with pytest.raises(ValueError):
             BamReader(str(bad)).intervals('chr1', threads=2)
+
+
+# ---------------------------------------------------------------- read filters of the pile-up, flag by flag
+# (flag, in the pile-up?) — the rule and where it is documented:
+PILEUP_FLAG_CASES = [
+    ('plain', 0, True),
+    ('reverse_0x10', 16, True),
+    # samtools mpileup, --excl-flags: "default UNMAP,SECONDARY,QCFAIL,DUP"; pysam AlignmentFile.pileup, `flag_filter`:
+    # "ignore reads where any of the bits in the flag are set. The default is BAM_FUNMAP | BAM_FSECONDARY | BAM_FQCFAIL | BAM_FDUP"
+    ('unmapped_0x4', 4, False),
+    ('secondary_0x100', 256, False),
+    ('qcfail_0x200', 512, False),
+    ('duplicate_0x400', 1024, False),
+    # ... and nothing else: a supplementary alignment (0x800) is not in that mask
+    ('supplementary_0x800', 2048, True),
+    # pysam pileup, `ignore_orphans`: "ignore orphans (paired reads that are not in a proper pair)", default True
+    # (samtools mpileup -A / --count-orphans is off by default: "Do not skip anomalous read pairs in variant calling")
+    ('paired_not_proper_0x1', 1, False),
+    ('paired_proper_0x3', 3, True),
+    ('paired_proper_mate_reverse_0x23', 0x23, True),
+]
+
+
+@pytest.mark.parametrize('name,flag,kept', PILEUP_FLAG_CASES, ids=[c[0] for c in PILEUP_FLAG_CASES])
+def test_pileup_read_filter_by_flag(tmp_path, name, flag, kept):
+    """what the reference sees through sam.pileup(contig, start, stop) with pysam's defaults (src/giremi/mismatch.py:160-163):
+    one read with the flag under test between two plain ones.  NOT pinned against pysam (it is not installed here): these
+    are the documented rules, quoted above"""
+    w = BamWriter(str(tmp_path / 'f.bam'), [('c', 1000)])
+    w.write('c', 100, 'before', False, [(0, 50)], 'A' * 50, ':50')
+    w.write('c', 110, 'probe', False, [(0, 50)], 'C' * 50, ':50', flag=flag)
+    w.write('c', 120, 'after', True, [(0, 50)], 'G' * 50, ':50')
+    w.close()
+    rd = BamReader(str(tmp_path / 'f.bam'))
+    cols = {c.pos: (c.get_query_names(), c.get_query_sequences()) for c in rd.pileup('c', 0, 1000)}
+    assert sorted(cols) == list(range(100, 170))
+    want = (['before', 'probe', 'after'], ['A', 'C', 'G']) if kept else (['before', 'after'], ['A', 'G'])
+    assert cols[130] == want
+    if not kept:
+        assert all('probe' not in names for names, _ in cols.values())
+    # the native site extraction applies the same filter to its pile-up step (bamio.cpp: region_sites_impl step 2):
+    # 'probe' as a reference-allele read of a candidate site at 130
+    from lgmi.io import SiteParams
+    w = BamWriter(str(tmp_path / 'g.bam'), [('c', 1000)])
+    for k in range(4):
+        w.write('c', 100, 'alt%d' % k, False, [(0, 50)], 'C' * 30 + 'T' + 'C' * 19, ':30*ct:19')
+    for k in range(2):
+        w.write('c', 105, 'ref%d' % k, False, [(0, 50)], 'C' * 50, ':50')
+    w.write('c', 110, 'probe', False, [(0, 50)], 'C' * 50, ':50', flag=flag)
+    w.close()
+    rd = BamReader(str(tmp_path / 'g.bam'))
+    raw = rd.region_sites('c', 0, 1000, SiteParams(keep_non_spliced_read=1, min_base_quality=13, max_depth=8000, min_dist_from_splice=0,
+                                                   half_window=50, min_allele_depth=1, min_allele_ratio=0.0, min_total_depth=0,
+                                                   max_window_mismatch=10, max_window_mismatch_type=3))
+    assert raw is not None and raw['pos'].tolist() == [130] and raw['ref'].decode() == 'C'
+    alleles = raw['allele_nt'].decode()
+    noff, pool = raw['name_off'], raw['names']
+    names = lambda ids: [pool[noff[i]:noff[i + 1]].decode() for i in ids]
+    by_nt = {alleles[a]: names(raw['reads'][raw['reads_off'][a]:raw['reads_off'][a + 1]].tolist()) for a in range(len(alleles))}
+    assert by_nt['T'] == ['alt0', 'alt1', 'alt2', 'alt3']
+    # (a read on the other strand is in the column but is not a read of this strand's site: mismatch.py:176-180)
+    assert by_nt['C'] == ['ref0', 'ref1'] + (['probe'] if kept and not flag & 16 else [])
+
+
+def test_pileup_base_quality_threshold_and_deletions(tmp_path):
+    """pysam pileup, `min_base_quality`: "Minimum base quality. Bases below the minimum quality will not be output", default 13
+    — a base of quality 12 is not in its column, one of quality 13 is; the read's other bases are unaffected.
+    A deletion spanning the column: pysam's PileupColumn.get_query_sequences() yields an empty string for the read (no
+    base, `add_indels` off) and get_query_names() still lists it; the reference then compares '' with the reference base
+    (src/giremi/mismatch.py:169-175) and never counts the read for the reference allele.  Same for a reference skip (N).
+    Known difference, documented in include/lgmi_io.h: htslib tests min_base_quality at the query position next to a
+    deletion and drops the entry when that base is below it; here the entry stays — it changes nothing the reference
+    computes, since '' never equals a base."""
+    q12 = np.full(50, 40, np.uint8); q12[20] = 12
+    q13 = np.full(50, 40, np.uint8); q13[20] = 13
+    qdel = np.full(45, 40, np.uint8); qdel[19] = 5                              # the base before the deletion is poor
+    w = BamWriter(str(tmp_path / 'q.bam'), [('c', 1000)])
+    w.write('c', 100, 'q12', False, [(0, 50)], 'A' * 50, ':50', quality=q12)
+    w.write('c', 100, 'q13', False, [(0, 50)], 'A' * 50, ':50', quality=q13)
+    w.write('c', 100, 'del', False, [(0, 20), (2, 5), (0, 25)], 'A' * 45, ':20-ccccc:25', quality=qdel)
+    w.write('c', 100, 'skip', True, [(0, 10), (3, 30), (0, 10)], 'A' * 20, ':10~gt30ag:10')
+    w.write('c', 100, 'noqual', False, [(0, 50)], 'A' * 50, ':50', quality=np.full(50, 255, np.uint8))   # '*' in SAM: 0xFF bytes
+    w.close()
+    rd = BamReader(str(tmp_path / 'q.bam'))
+    cols = {c.pos: dict(zip(c.get_query_names(), c.get_query_sequences())) for c in rd.pileup('c', 0, 1000)}
+    assert cols[120] == {'q13': 'A', 'del': '', 'skip': '', 'noqual': 'A'}                       # q12 dropped here ...
+    assert cols[119] == {'q12': 'A', 'q13': 'A', 'skip': '', 'noqual': 'A'}                      # ... only here; del's poor base too
+    assert cols[121]['q12'] == 'A' and cols[124]['del'] == '' and cols[125]['del'] == 'A'
+    assert cols[109]['skip'] == 'A' and cols[110]['skip'] == '' and cols[139]['skip'] == '' and cols[140]['skip'] == 'A'
+    loose = {c.pos: c.get_query_names() for c in rd.pileup('c', 0, 1000, min_base_quality=0)}
+    assert loose[120] == ['q12', 'q13', 'del', 'skip', 'noqual'] and loose[119] == ['q12', 'q13', 'del', 'skip', 'noqual']
+
+
+def test_pileup_max_depth_default(tmp_path):
+    """pysam pileup, `max_depth`: "Maximum read depth permitted. The default limit is '8000'" — 8,005 reads over one column:
+    the first 8,000 in file order are in it.  (htslib caps the reads entering the pile-up, this reader caps each column:
+    the same on reads that all start before the column, as here; include/lgmi_io.h)"""
+    w = BamWriter(str(tmp_path / 'd.bam'), [('c', 1000)])
+    for k in range(8005):
+        w.write('c', 100 + (k >= 8000), 'r%04d' % k, False, [(0, 30)], 'A' * 30, ':30')
+    w.close()
+    rd = BamReader(str(tmp_path / 'd.bam'))
+    cols = {c.pos: c.get_query_names() for c in rd.pileup('c', 0, 1000)}
+    assert len(cols[100]) == 8000 and len(cols[110]) == 8000 and cols[110] == ['r%04d' % k for k in range(8000)]
+    assert len(cols[130]) == 5                                                   # only the five late starters reach 130
+    assert len({c.pos: c for c in rd.pileup('c', 0, 1000, max_depth=9000)}[110].get_query_names()) == 8005

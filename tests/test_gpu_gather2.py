@@ -100,6 +100,32 @@ def test_bench_two_ranks_over_the_stand_in_reports_what_rccl_says(fake_rccl):
     assert ver and ver['equal_to_unsharded'] is True
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_did(fake_rccl):
+    """`python3 bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (how a driver that launches the N = 1 bench
+    with plain python may well launch N > 1): the process starts its two ranks itself as fresh children, makes no GPU call
+    of its own, relays rank 0's one JSON line and exits 0 only if both ranks do — here over the stand-in on the one GPU"""
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+           '--workload', 'small_dense_2kx20k', '--shuffles', '50']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR',
+                                                            'TORCHELASTIC_USE_AGENT_STORE', 'TORCHELASTIC_RUN_ID')}
+    env.update(LGMI_BENCH_DEVICE='0', LGMI_COMM_INIT_TIMEOUT='90', LGMI_GATHER_TIMEOUT='200', LGMI_RCCL_LIB=fake_rccl,
+               LGMI_ALLOW_RCCL_STANDIN='1')
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] and 'degraded' not in line
+    assert line['rccl']['stand_in'] is True and line['rccl']['nranks'] == 2
+    ver = line.get('verify') or line.get('gather_after_permutation', {}).get('verify')
+    assert ver and ver['equal_to_unsharded'] is True
+    # a failing rank is a failing bench: the same launch over the real librccl (two ranks on one device are refused)
+    env.pop('LGMI_RCCL_LIB')
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+
+
 def test_bench_two_ranks_without_a_communicator_is_not_a_success():
     """two ranks on ONE device over the real librccl: the communicator cannot come up (RCCL refuses the duplicate
     device).  The kernel-only figure is still printed, but as `kernel_only_value` of a line marked `degraded` with no

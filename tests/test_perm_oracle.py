@@ -668,6 +668,22 @@ def test_exact_p_entry_covers_enumerated_and_six_cell_tables():
     assert np.isnan(p[11]) and np.isnan(p[12])              # 3 x 3 tables beyond the enumeration: no exact form within reach
 
 
+def test_exact_p_of_a_row_the_zero_test_decides_is_its_bound_never_zero(lib):
+    """advice r4: a six-cell row whose tail the zero test bounds below 2^-33 used to come back with the exact p 0.0 — a
+    value no permutation test can give (the observed table is in its own tail) and one that breaks -log10(p).  It is now
+    the bound the test fired on: an UPPER bound of the tail mass (brute force below), positive, below e^-23.1; floored at
+    the smallest normal double when even the bound underflows"""
+    T = [400, 30, 0, 40, 390, 0, 30, 25, 0]                # a tri-allelic site against a linked one, small enough for brute force
+    rc, o = _six(lib, T, 1000)
+    assert rc == 1 and o['zero'] == 1
+    p = c_oracle.perm_rows_exact(np.array([T]))[0]
+    exact = brute_ptail_six(T)
+    assert 0.0 < exact <= p < 9.4e-11, (exact, p)
+    # strongly linked, deep: the bound itself underflows — the floor, not 0.0
+    p = c_oracle.perm_rows_exact(np.array([[90000, 30, 0, 40, 89000, 0, 2100, 1900, 0]]))[0]
+    assert p == 2.2250738585072014e-308
+
+
 @pytest.mark.parametrize('T', [[0, 0, 0, 0, 30, 14, 0, 12, 28], [12, 30, 0, 60, 45, 0, 40, 28, 0], [0, 0, 0, 40, 35, 20, 25, 60, 18],
                                [10, 3, 2, 2, 9, 4, 1, 3, 12]], ids=['2x2', '3x2', '2x3', '3x3'])
 def test_p_is_the_literal_label_shuffle_test_of_the_references_statistic(T):

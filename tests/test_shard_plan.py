@@ -17,7 +17,7 @@ def item_of_rows(pb, plan, row_i, row_j):
     xrow, xnext = plan['site_xrow'].astype(np.int64), plan['site_xnext'].astype(np.int64)
     i, j = row_i.astype(np.int64), row_j.astype(np.int64)
     i_is_x = xrow[i] != NONE
-    q = np.where(i_is_x, j - i - 1, xrow[j] - xnext[i])
+    q = np.where(i_is_x, j - i - 1, xnext[j] - 1 - xnext[i])              # (x rank of j = xnext[j] - 1; rows hold pseudo rows in between)
     assert (q >= 0).all()
     seg = np.where(i_is_x, q // EMIT_SEG, 0)            # only x-site rows are cut into segments
     key = {(int(s), int(g)): k for k, (s, g) in enumerate(zip(plan['item_site'], plan['item_seg']))}
