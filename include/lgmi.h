@@ -93,6 +93,13 @@ typedef struct lgmi_batch {
     const uint32_t* site_n_words;     /* [n_sites]                             */
     const uint64_t* site_plane_off;   /* [n_sites]                             */
     const uint64_t* planes;           /* [n_plane_words]                       */
+    /* ABI 6, optional (NULL: the library finds out on the device, after the upload): site_tri[s] = 1 when site s has a
+     * read of class 0 (some bit set in lo & hi), else 0 — a packer knows this for free.  With it lgmi_run() can lay out
+     * and plan the run before the planes have moved, and uploads them in pieces of sites with the count kernels of the
+     * pairs whose both sites have arrived running underneath (the planes must then be packed in site order:
+     * site_plane_off[s + 1] == site_plane_off[s] + 2 * site_n_words[s]; otherwise the plain upload is used).  The flags
+     * are checked against the planes on the device: a wrong one is LGMI_E_ARG, never a wrong result. */
+    const uint8_t*  site_tri;         /* [n_sites] or NULL                     */
 } lgmi_batch;
 
 typedef struct lgmi_params {

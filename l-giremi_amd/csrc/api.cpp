@@ -152,8 +152,10 @@ struct PinnedPool {
                 char* const c = static_cast<char*>(p);
                 std::vector<std::thread> th;
                 auto touch = [c, n2, T](unsigned t) { for (size_t i = n2 * t / T; i < n2 * (t + 1) / T; i += 4096) c[i] = 0; };
-                for (unsigned t = 1; t < T; ++t) th.emplace_back(touch, t);
+                unsigned started = 1;                      // (a thread the system refuses — a container's pid limit — is a range this thread touches itself)
+                for (; started < T; ++started) { try { th.emplace_back(touch, started); } catch (...) { break; } }
                 touch(0u);
+                for (unsigned t = started; t < T; ++t) touch(t);
                 for (auto& x : th) x.join();
                 if (hipHostRegister(p, n2, hipHostRegisterDefault) == hipSuccess) {
                     std::lock_guard<std::mutex> lk(mu);
@@ -202,11 +204,17 @@ struct lgmi_ctx {
     uint32_t tables_len = 0;
     void* comm = nullptr;       // ncclComm_t (comm.cpp)
     hipStream_t comm_stream = nullptr;   // the gather runs here, beside the kernels of `stream`
+    hipStream_t copy_stream = nullptr;   // lgmi_run's copies (planes up in pieces, rows down under the permutation stage): a stream
+                                         // of its own, never the one RCCL's collectives were queued on
     hipEvent_t comm_event = nullptr;     // main stream -> communication stream ordering (comm.cpp: comm_after_main)
     int rank = 0, world = 1;
     size_t mem_total = 0;       // device memory, for the "allocate rows by their upper bound" decision
     std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
-    std::vector<hipEvent_t> more_ev;       // events of chunked stages (permute_impl, lgmi_run), made on first use
+    // events of chunked stages, made on first use.  Who uses which: the permutation stage's row ranges (3 each, at most 32
+    // ranges), lgmi_run's transfers behind them, the pieces of a pipelined upload (at most 64) and their trace twins, the
+    // copy -> prep hand-over of a piece, the tri-flag check, main stream -> copy stream ordering
+    enum { EV_PERM = 0, EV_XFER = 96, EV_UP = 128, EV_UPDBG = 192, EV_COPIED = 256, EV_CHECKED = 288, EV_ORDER = 289 };
+    std::vector<hipEvent_t> more_ev;
     hipEvent_t event(size_t k) {           // NULL when the runtime refuses one
         while (more_ev.size() <= k) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; } more_ev.push_back(e); }
         return more_ev[k];
@@ -225,12 +233,12 @@ struct PlanCache {
     bool on_device = false;
     BlockPlan* d_plans = nullptr; uint32_t* d_xlist = nullptr; uint32_t* d_ylist = nullptr; SiteMap* d_smap = nullptr;
     Tile* d_tiles = nullptr; Tile* d_mtiles = nullptr; uint2* d_items = nullptr; uint2* d_units = nullptr;
-    OpGroup* d_opgroups = nullptr;
+    OpGroup* d_opgroups = nullptr; uint32_t* d_xrows = nullptr;
     void release(Pool& p) {
         p.release(d_plans); p.release(d_xlist); p.release(d_ylist); p.release(d_smap); p.release(d_tiles);
-        p.release(d_mtiles); p.release(d_items); p.release(d_units); p.release(d_opgroups);
+        p.release(d_mtiles); p.release(d_items); p.release(d_units); p.release(d_opgroups); p.release(d_xrows);
         d_plans = nullptr; d_xlist = d_ylist = nullptr; d_smap = nullptr; d_tiles = d_mtiles = nullptr;
-        d_items = d_units = nullptr; d_opgroups = nullptr; on_device = false;
+        d_items = d_units = nullptr; d_opgroups = nullptr; d_xrows = nullptr; on_device = false;
     }
 };
 
@@ -245,6 +253,10 @@ struct lgmi_dbatch {
     lgmi_ctx* ctx = nullptr;
     DevBatch d;
     std::shared_ptr<const SiteTable> table;
+    // how many sequential shards a run of this batch needs (split_count builds k shard plans per candidate k: 6 x 33 ms at
+    // 150k x 200k on every call, advice r4) — remembered per (parameters, budget)
+    struct SplitMemo { bool het_only, want_p, keep_p, want_counts; uint32_t n_shuffles; double budget; int k; uint64_t largest; };
+    mutable std::vector<SplitMemo> split_memo;
     mutable std::vector<std::unique_ptr<PlanCache>> plans;   // most recently used plans of this batch (at most PLAN_CACHE_N)
     mutable uint64_t plan_stamp = 0;
     // host copies of the site metadata (planning happens on the host)
@@ -283,6 +295,7 @@ struct lgmi_dresult {
     // the compact row form (ABI 6): per-site integers that add up over shards, and what a compact fetch derives from them
     std::shared_ptr<const SiteTable> table;     // NULL: gathered from ranks that ran different batches
     bool het_only = false;
+    uint32_t first_site = 0xFFFFFFFFu, first_seg = 0;   // the shard's first work item (site, segment of LGMI_EMIT_SEG partners): NONE when it has none
     uint32_t* d_nfirst = nullptr;          // [n_sites] rows whose FIRST site is s
     uint32_t* d_ncand = nullptr;           // [n_sites] pairs s could have emitted as first site
     uint8_t* d_full = nullptr;             // [n_sites]   (from here: made by compact_prepare)
@@ -370,6 +383,7 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     for (auto& ev : ctx->more_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->comm_event) (void)hipEventDestroy(ctx->comm_event);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -381,6 +395,10 @@ hipStream_t ctx_stream(lgmi_ctx* c) { return c->stream; }
 hipStream_t ctx_comm_stream(lgmi_ctx* c) {               // created on first use
     if (!c->comm_stream && hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess) c->comm_stream = nullptr;
     return c->comm_stream ? c->comm_stream : c->stream;
+}
+hipStream_t ctx_copy_stream(lgmi_ctx* c) {               // created on first use; the main stream when the runtime refuses one
+    if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->copy_stream = nullptr; }
+    return c->copy_stream ? c->copy_stream : c->stream;
 }
 hipEvent_t ctx_comm_event(lgmi_ctx* c) {                 // created on first use
     if (!c->comm_event && hipEventCreateWithFlags(&c->comm_event, hipEventDisableTiming) != hipSuccess) c->comm_event = nullptr;
@@ -401,6 +419,9 @@ void dresult_view(const lgmi_dresult* r, DResultView* v) {
     v->mean = r->d_mean; v->npairs = r->d_npairs; v->sum = r->d_sum;
     v->n_shuffles = r->n_shuffles; v->p_from_exceed = r->p_from_exceed;
     v->info = r->info;
+    v->nfirst = r->d_nfirst; v->ncand = r->d_ncand; v->first_site = r->first_site; v->first_seg = r->first_seg;
+    if (r->table) { v->block_site_begin = &r->table->block_site_begin; v->site_type = &r->table->type; v->table_owner = &r->table; }
+    v->het_only = r->het_only;
 }
 // a resident result made by the gather (comm.cpp): arrays come from the context's pool
 lgmi_dresult* dresult_new_gathered(lgmi_ctx* c, const DResultView& v) {
@@ -414,6 +435,10 @@ lgmi_dresult* dresult_new_gathered(lgmi_ctx* c, const DResultView& v) {
     r->has_p = v.exceed != nullptr; r->has_counts = v.counts != nullptr;
     r->n_shuffles = v.n_shuffles; r->p_from_exceed = v.p_from_exceed;
     r->info = v.info;
+    // a gather of shards of one batch keeps the compact form within reach: the summed per-site row counts and the site table
+    r->d_nfirst = const_cast<uint32_t*>(v.nfirst); r->d_ncand = const_cast<uint32_t*>(v.ncand);
+    if (v.table_owner) r->table = *static_cast<const std::shared_ptr<const SiteTable>*>(v.table_owner);
+    r->het_only = v.het_only;
     return r;
 }
 int pool_alloc(lgmi_ctx* c, void** out, size_t bytes) { return c->pool.alloc(out, bytes); }
@@ -484,15 +509,16 @@ static int validate_batch(const lgmi_batch* b) {
         }
         return LGMI_OK;
     };
-    const unsigned T = b->n_sites >= (1u << 16) ? plan_threads(b->n_blocks) : 1u;
-    if (T <= 1) {
+    const unsigned T_want = b->n_sites >= (1u << 16) ? plan_threads(b->n_blocks) : 1u;
+    if (T_want <= 1) {
         for (uint64_t k = 0; k < b->n_blocks; ++k) { const int rc = check_block(k, true); if (rc) return rc; }
         return LGMI_OK;
     }
     // a million sites were 1 ms of a one-shot call on one thread: blocks in ranges of equal site counts, the first bad block
     // of every range, the earliest of them reported exactly as the serial loop would
+    Team team(T_want);
+    const unsigned T = team.T;                              // (what the system granted: plan.h)
     std::vector<uint64_t> first_bad(T, ~0ull);
-    Team team(T);
     team.run([&](unsigned t) {
         const uint64_t s_lo = b->n_sites * t / T, s_hi = b->n_sites * (t + 1) / T;
         // the blocks whose first site lies in [s_lo, s_hi): block_site_begin is only trusted as far as it has been checked,
@@ -524,7 +550,46 @@ static int dev_copy_new(Pool& pool, T** dptr, const T* h, size_t n, hipStream_t 
 // (Round 3 tried a staged upload of the bit planes — threads copying 32-MB pieces into pinned buffers ahead of the DMA
 //  engine — against the plain hipMemcpyAsync from the caller's pageable array: 700 ms host-to-host against 495 ms on the
 //  same box, gpurun_out/exp_upload.txt; the runtime's own path moves the 2.5 GB at ~50 GB/s.  Not kept.)
-extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch** out) {
+//
+// Round 5: the PIPELINED upload of lgmi_run.  With the caller's tri flags (lgmi_batch.site_tri) the column table and the
+// plan need nothing of the planes, so everything but the planes goes up first and the planes follow in pieces of sites
+// on a stream of their own, each piece's layout prep behind it and an event behind that; the count kernels of the tiles
+// whose rows and columns have all arrived run on the main stream meanwhile (run_device_impl).  The 44 ms the 2.5 GB of
+// a north-star chromosome take over PCIe then hide under the 97 ms of its count stage.
+struct UploadPipe {
+    lgmi_ctx* ctx = nullptr;
+    const lgmi_batch* b = nullptr;
+    hipStream_t us = nullptr;                      // the upload stream (the context's copy stream)
+    hipStream_t ps = nullptr;                      // the prep kernels' stream (made on first use)
+    uint32_t K = 0;
+    std::vector<uint64_t> site_begin, word_begin, pseudo_begin;   // [K + 1] chunk k = sites [site_begin[k], site_begin[k + 1]), their plane words, their pseudo columns
+    uint64_t* d_planes = nullptr; uint64_t* d_poff = nullptr; uint32_t* d_nw = nullptr; uint32_t* d_pseudo = nullptr;
+    uint8_t* d_tri_chk = nullptr; int* d_bad = nullptr;
+    // the plan's tiles and operand groups, reordered by the chunk that completes them: chunk k's are [begin[k], begin[k + 1])
+    std::vector<uint32_t> mt_begin, t_begin, og_begin;
+    uint32_t next = 0;                             // chunks already queued
+    ~UploadPipe() {
+        if (!ctx) return;
+        if (us) (void)hipStreamSynchronize(us);
+        if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+        (void)hipStreamSynchronize(ctx->stream);
+        Pool& p = ctx->pool;
+        p.release(d_planes); p.release(d_poff); p.release(d_nw); p.release(d_pseudo); p.release(d_tri_chk); p.release(d_bad);
+    }
+};
+
+// is the batch one the pipelined upload takes?  (flags given, planes packed in site order, enough of them to matter)
+static bool pipe_eligible(const lgmi_batch* b) {
+    if (!b || !b->site_tri || b->n_sites < 64 || getenv("LGMI_NO_UPLOAD_PIPE")) return false;
+    uint64_t min_words = 8ull << 20;                                   // 64 MB of planes
+    if (const char* e = getenv("LGMI_UPLOAD_PIPE_MIN_WORDS")) min_words = strtoull(e, nullptr, 10);
+    if (b->n_plane_words < min_words) return false;
+    uint64_t off = 0;
+    for (uint64_t s = 0; s < b->n_sites; ++s) { if (b->site_plane_off[s] != off) return false; off += 2ull * b->site_n_words[s]; }
+    return off == b->n_plane_words;
+}
+
+static int upload_impl(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch** out, UploadPipe* pipe) {
     if (!ctx || !out) return fail(LGMI_E_ARG, "ctx/out is NULL");
     *out = nullptr;
     HostTrace tr;
@@ -550,9 +615,11 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     hipStream_t st = ctx->stream;
     uint64_t* d_planes = nullptr; uint64_t* d_poff = nullptr; uint32_t* d_nw = nullptr; uint32_t* d_pseudo = nullptr;
     Pool& pool = ctx->pool;
-    struct Tmp { Pool& p; hipStream_t st; uint64_t** a; uint64_t** b; uint32_t** c; uint32_t** d;     // (released once the stream is past them)
-                 ~Tmp() { (void)hipStreamSynchronize(st); p.release(*a); p.release(*b); p.release(*c); p.release(*d); } } tmp{pool, st, &d_planes, &d_poff, &d_nw, &d_pseudo};
-    if ((rc = dev_copy_new(ctx->pool, &d_planes, b->planes, b->n_plane_words, st))) return rc;
+    struct Tmp { Pool& p; hipStream_t st; uint64_t** a; uint64_t** b; uint32_t** c; uint32_t** d; bool keep = false;     // (released once the stream is past them)
+                 ~Tmp() { if (keep) return; (void)hipStreamSynchronize(st); p.release(*a); p.release(*b); p.release(*c); p.release(*d); } } tmp{pool, st, &d_planes, &d_poff, &d_nw, &d_pseudo};
+    if (pipe) {
+        if ((rc = pool.alloc((void**)&d_planes, std::max<uint64_t>(b->n_plane_words, 1) * 8))) return rc;      // filled piece by piece
+    } else if ((rc = dev_copy_new(ctx->pool, &d_planes, b->planes, b->n_plane_words, st))) return rc;
     if ((rc = dev_copy_new(ctx->pool, &d_poff, b->site_plane_off, ns, st))) return rc;
     if ((rc = dev_copy_new(ctx->pool, &d_nw, b->site_n_words, ns, st))) return rc;
     if ((rc = dev_copy_new(ctx->pool, &db->d.d_pos, b->site_pos, ns, st))) return rc;
@@ -561,10 +628,21 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     db->tri.assign(ns, 0);
     if (ns) {
         if ((rc = pool.alloc((void**)&db->d.d_tri, ns))) return rc;
-        HIPCHK(hipMemsetAsync(db->d.d_tri, 0, ns, st));
-        launch_tri_flags(st, (uint32_t)ns, d_nw, d_poff, d_planes, db->d.d_tri);
-        HIPCHK(hipMemcpyAsync(db->tri.data(), db->d.d_tri, ns, hipMemcpyDeviceToHost, st));
-        HIPCHK(wait_stream(st));
+        if (pipe) {
+            // the caller's flags (checked against the planes once those are up: run_device_impl)
+            for (uint64_t s = 0; s < ns; ++s) { if (b->site_tri[s] > 1) return fail(LGMI_E_ARG, "site_tri[%llu] = %u", (unsigned long long)s, b->site_tri[s]); db->tri[s] = b->site_tri[s]; }
+            HIPCHK(hipMemcpyAsync(db->d.d_tri, db->tri.data(), ns, hipMemcpyHostToDevice, st));
+        } else {
+            HIPCHK(hipMemsetAsync(db->d.d_tri, 0, ns, st));
+            launch_tri_flags(st, (uint32_t)ns, d_nw, d_poff, d_planes, db->d.d_tri);
+            HIPCHK(hipMemcpyAsync(db->tri.data(), db->d.d_tri, ns, hipMemcpyDeviceToHost, st));
+            HIPCHK(wait_stream(st));
+            if (b->site_tri)
+                for (uint64_t s = 0; s < ns; ++s)
+                    if ((b->site_tri[s] != 0) != (db->tri[s] != 0))
+                        return fail(LGMI_E_ARG, "site_tri[%llu] = %u, but the planes of the site %s reads of class 0",
+                                    (unsigned long long)s, b->site_tri[s], db->tri[s] ? "hold" : "hold no");
+        }
     }
     tr.mark("tri_flags");
     // column table: real sites, then one pseudo column per tri site.  On several threads over site ranges (a prefix over
@@ -572,8 +650,8 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     db->pseudo_of_site.resize(ns);
     uint64_t off = 0;
     {
-        const unsigned T = plan_threads(ns / 64);
-        Team team(T);
+        Team team(plan_threads(ns / 64));
+        const unsigned T = team.T;
         std::vector<uint64_t> w_real(T + 1, 0), w_tri(T + 1, 0), n_tri(T + 1, 0);
         team.run([&](unsigned t) {
             const uint64_t s0 = ns * t / T, s1 = ns * (t + 1) / T;
@@ -615,12 +693,67 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
     if ((rc = pool.alloc((void**)&db->d.d_cplanes, (off + 1) * sizeof(ulonglong2)))) return rc;
     HIPCHK(hipMemsetAsync(db->d.d_cplanes + off, 0, sizeof(ulonglong2), st));
     tr.mark("cols");
-    launch_prep_cols(st, (uint32_t)db->d.n_cols, (uint32_t)ns, db->d.d_cols, d_pseudo, d_poff, d_planes, db->d.d_cplanes);
-    HIPCHK(hipGetLastError());
-    HIPCHK(wait_stream(st));
+    if (pipe) {
+        // the planes are still on the host: cut the sites into pieces of equal plane words; what follows is queued by
+        // run_device_impl, piece by piece, between its count launches
+        uint32_t K = 8;
+        if (const char* e = getenv("LGMI_UPLOAD_CHUNKS")) K = (uint32_t)std::min(64, std::max(1, atoi(e)));
+        pipe->ctx = ctx; pipe->b = b; pipe->us = ctx_copy_stream(ctx); pipe->K = K;
+        pipe->site_begin.assign(K + 1, ns); pipe->word_begin.assign(K + 1, b->n_plane_words); pipe->pseudo_begin.assign(K + 1, db->pseudo_site.size());
+        uint64_t s = 0, np = 0;
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint64_t target = b->n_plane_words / K * k;
+            while (s < ns && b->site_plane_off[s] < target) { if (db->tri[s]) ++np; ++s; }
+            pipe->site_begin[k] = s; pipe->word_begin[k] = s < ns ? b->site_plane_off[s] : b->n_plane_words; pipe->pseudo_begin[k] = np;
+        }
+        if ((rc = pool.alloc((void**)&pipe->d_tri_chk, std::max<uint64_t>(ns, 1)))) return rc;
+        if ((rc = pool.alloc((void**)&pipe->d_bad, 8))) return rc;
+        HIPCHK(hipMemsetAsync(pipe->d_tri_chk, 0, std::max<uint64_t>(ns, 1), st));
+        HIPCHK(hipMemsetAsync(pipe->d_bad, 0, 8, st));
+        pipe->d_planes = d_planes; pipe->d_poff = d_poff; pipe->d_nw = d_nw; pipe->d_pseudo = d_pseudo;
+        tmp.keep = true;                                         // the pipe owns them now
+        HIPCHK(wait_stream(st));                                 // (small arrays only: the upload stream may read them from here on)
+    } else {
+        launch_prep_cols(st, 0u, (uint32_t)db->d.n_cols, (uint32_t)ns, db->d.d_cols, d_pseudo, d_poff, d_planes, db->d.d_cplanes);
+        HIPCHK(hipGetLastError());
+        HIPCHK(wait_stream(st));
+    }
     tr.mark("prep_done");
     guard.p = nullptr;
     *out = db;
+    return LGMI_OK;
+}
+extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch** out) { return upload_impl(ctx, b, out, nullptr); }
+
+// one piece of a pipelined upload: its planes (copy stream), their layout prep (a stream of its own, so that the next
+// piece's copy does not queue behind a prep kernel that waits for a compute unit the count kernels hold), an event the main
+// stream waits for.  After the last piece the caller's tri flags are checked against the planes — behind the event: the
+// count kernels do not wait for the check, the run's final read-back does (checked: event index 191).
+static int pipe_chunk(UploadPipe& p, lgmi_dbatch* db, uint32_t k, hipEvent_t done) {
+    const uint64_t w0 = p.word_begin[k], w1 = p.word_begin[k + 1], s0 = p.site_begin[k], s1 = p.site_begin[k + 1];
+    const uint32_t ns = (uint32_t)db->d.n_sites;
+    if (!p.ps && hipStreamCreateWithFlags(&p.ps, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); p.ps = nullptr; }
+    hipStream_t ps = p.ps ? p.ps : p.us;
+    if (w1 > w0) HIPCHK(hipMemcpyAsync(p.d_planes + w0, p.b->planes + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, p.us));
+    if (ps != p.us) {
+        hipEvent_t copied = p.ctx->event(lgmi_ctx::EV_COPIED + (k & 31u));
+        if (!copied) return fail(LGMI_E_HIP, "hipEventCreate failed");
+        HIPCHK(hipEventRecord(copied, p.us));
+        HIPCHK(hipStreamWaitEvent(ps, copied, 0));
+    }
+    launch_prep_cols(ps, (uint32_t)s0, (uint32_t)(s1 - s0), ns, db->d.d_cols, p.d_pseudo, p.d_poff, p.d_planes, db->d.d_cplanes);
+    launch_prep_cols(ps, ns + (uint32_t)p.pseudo_begin[k], (uint32_t)(p.pseudo_begin[k + 1] - p.pseudo_begin[k]), ns, db->d.d_cols, p.d_pseudo,
+                     p.d_poff, p.d_planes, db->d.d_cplanes);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(done, ps));
+    if (k + 1 == p.K) {                              // all planes are up: the caller's tri flags against them
+        launch_tri_flags(ps, ns, p.d_nw, p.d_poff, p.d_planes, p.d_tri_chk);
+        launch_flags_differ(ps, ns, db->d.d_tri, p.d_tri_chk, p.d_bad);
+        HIPCHK(hipGetLastError());
+        hipEvent_t checked = p.ctx->event(lgmi_ctx::EV_CHECKED);
+        if (!checked) return fail(LGMI_E_HIP, "hipEventCreate failed");
+        HIPCHK(hipEventRecord(checked, ps));
+    }
     return LGMI_OK;
 }
 
@@ -738,6 +871,7 @@ extern "C" int lgmi_dbatch_download(lgmi_dbatch* db, lgmi_batch* out) {
     out->site_n_words = db->dl_n_words.data();
     out->site_plane_off = db->dl_plane_off.data();
     out->planes = db->dl_planes.data();
+    out->site_tri = db->tri.data();
     return LGMI_OK;
 }
 
@@ -904,8 +1038,69 @@ static PlanCache* plan_for(lgmi_ctx* ctx, const lgmi_dbatch* db, bool het_only, 
     return db->plans.back().get();
 }
 
+// A pipelined upload delivers the sites in order: a count tile (an operand group) can run once the LAST site among its
+// rows and columns is up.  The plan's tiles and operand groups are put in the order of the piece that completes them
+// (stable: inside a piece the planner's L2-friendly order stays) and the pieces' ranges noted.
+static void pipe_order_plan(const lgmi_dbatch* db, Plan& pl, UploadPipe& p) {
+    const uint32_t ns = (uint32_t)db->d.n_sites, K = p.K;
+    auto chunk_of_site = [&](uint32_t s) { return (uint32_t)(std::upper_bound(p.site_begin.begin() + 1, p.site_begin.begin() + K, (uint64_t)s) - (p.site_begin.begin() + 1)); };
+    auto chunk_of_col = [&](uint32_t c) { return chunk_of_site(c < ns ? c : db->pseudo_site[c - ns]); };
+    // per 32-entry group of every block's y list and x list: the latest piece among its columns / rows (either list is
+    // made of runs in site order — other sites, x sites, pseudo columns; x sites with their pseudo rows next to them or
+    // behind them all — so a group may straddle two runs)
+    std::vector<uint32_t> ygrp_begin(pl.plans.size() + 1, 0), xgrp_begin(pl.plans.size() + 1, 0);
+    for (size_t b = 0; b < pl.plans.size(); ++b) {
+        ygrp_begin[b + 1] = ygrp_begin[b] + (pl.plans[b].ny + 31u) / 32u;
+        xgrp_begin[b + 1] = xgrp_begin[b] + (pl.plans[b].nx + 31u) / 32u;
+    }
+    std::vector<uint8_t> ygrp(ygrp_begin.back(), 0), xgrp(xgrp_begin.back(), 0);
+    for (size_t b = 0; b < pl.plans.size(); ++b) {
+        const BlockPlan& bp = pl.plans[b];
+        const uint32_t* yl = pl.ylist.data() + bp.yl_off;
+        const uint32_t* xl = pl.xlist.data() + bp.xl_off;
+        for (uint32_t q = 0; q < bp.ny; ++q) { uint8_t& g = ygrp[ygrp_begin[b] + q / 32u]; g = std::max<uint8_t>(g, (uint8_t)chunk_of_col(yl[q])); }
+        for (uint32_t r = 0; r < bp.nx; ++r) { uint8_t& g = xgrp[xgrp_begin[b] + r / 32u]; g = std::max<uint8_t>(g, (uint8_t)chunk_of_col(xl[r])); }
+    }
+    auto order = [&](std::vector<Tile>& tiles, uint32_t edge, std::vector<uint32_t>& begin) {
+        std::vector<uint8_t> ck(tiles.size());
+        begin.assign(K + 1, 0);
+        for (size_t k = 0; k < tiles.size(); ++k) {
+            const Tile& t = tiles[k];
+            const BlockPlan& bp = pl.plans[t.block];
+            uint32_t c = 0;
+            for (uint32_t g = t.x0 / 32u; g < std::min((bp.nx + 31u) / 32u, (t.x0 + edge) / 32u); ++g) c = std::max<uint32_t>(c, xgrp[xgrp_begin[t.block] + g]);
+            for (uint32_t g = t.y0 / 32u; g < std::min((bp.ny + 31u) / 32u, (t.y0 + edge) / 32u); ++g) c = std::max<uint32_t>(c, ygrp[ygrp_begin[t.block] + g]);
+            ck[k] = (uint8_t)c;
+            ++begin[c + 1];
+        }
+        for (uint32_t k = 0; k < K; ++k) begin[k + 1] += begin[k];
+        std::vector<Tile> sorted(tiles.size());
+        std::vector<uint32_t> at(begin.begin(), begin.end() - 1);
+        for (size_t k = 0; k < tiles.size(); ++k) sorted[at[ck[k]]++] = tiles[k];
+        tiles.swap(sorted);
+    };
+    order(pl.mtiles, 128u, p.mt_begin);
+    order(pl.tiles, (uint32_t)TILE, p.t_begin);
+    {
+        std::vector<uint8_t> ck(pl.op_groups.size());
+        p.og_begin.assign(K + 1, 0);
+        for (size_t k = 0; k < pl.op_groups.size(); ++k) {
+            const OpGroup& g = pl.op_groups[k];
+            const BlockPlan& bp = pl.plans[g.block];
+            (void)bp;
+            ck[k] = g.is_y ? ygrp[ygrp_begin[g.block] + g.group] : xgrp[xgrp_begin[g.block] + g.group];
+            ++p.og_begin[ck[k] + 1u];
+        }
+        for (uint32_t k = 0; k < K; ++k) p.og_begin[k + 1] += p.og_begin[k];
+        std::vector<OpGroup> sorted(pl.op_groups.size());
+        std::vector<uint32_t> at(p.og_begin.begin(), p.og_begin.end() - 1);
+        for (size_t k = 0; k < pl.op_groups.size(); ++k) sorted[at[ck[k]]++] = pl.op_groups[k];
+        pl.op_groups.swap(sorted);
+    }
+}
+
 static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, lgmi_dresult** out, bool defer_perm,
-                           uint64_t cap_hint = 0) {
+                           uint64_t cap_hint = 0, UploadPipe* pipe = nullptr) {
     if (!ctx || !db || !prm || !out) return fail(LGMI_E_ARG, "NULL argument");
     *out = nullptr;
     HostTrace tr;
@@ -936,9 +1131,16 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     bool plan_fresh = false;
     PlanCache* pcache = plan_for(ctx, db, prm->het_only != 0, sh_rank, sh_world, prm->n_shuffles, &plan_fresh);
     Plan& pl = pcache->pl;
+    if (pipe) {
+        // (the tiles are reordered in place: the plan must not be on the device yet — it is the new batch's first)
+        if (pcache->on_device || sh_world > 1) return fail(LGMI_E_STATE, "internal: a pipelined upload needs the batch's first, unsharded plan");
+        pipe_order_plan(db, pl, *pipe);
+    }
     const float ms_plan_host = plan_fresh ? pcache->ms_build : 0.f;      // 0: the batch's cached plan
     tr.mark("planned");
     const size_t n_items = (size_t)(pl.item_end - pl.item_begin);
+    uint32_t first_site = NONE, first_seg = 0;
+    if (n_items) { first_site = pl.items[pl.item_begin].x; first_seg = pl.items[pl.item_begin].y; }
     if (pl.tiles.size() >= 0x7FFFFFFFull || pl.mtiles.size() >= 0x7FFFFFFFull || n_items >= 0x7FFFFFFFull)
         return fail(LGMI_E_ARG, "too many tiles");
     // the permutation kernels carry row numbers in 32 bits (gen_list)
@@ -955,6 +1157,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     res->n_shuffles = prm->n_shuffles;
     res->p_from_exceed = prm->n_shuffles > 0 && !prm->exact_2x2;
     res->table = db->table; res->het_only = prm->het_only != 0;
+    res->first_site = first_site; res->first_seg = first_seg;
     const bool keep_p = want_p && !(res->p_from_exceed && prm->no_row_p);   // row_p as an array of its own
     // scratch (returned to the pool at the end of the call) and the result
     std::vector<void*> scratch;
@@ -979,6 +1182,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         if (!e) e = pp.alloc((void**)&pcache->d_tiles, std::max<size_t>(pl.tiles.size(), 1) * sizeof(Tile));
         if (!e) e = pp.alloc((void**)&pcache->d_mtiles, std::max<size_t>(pl.mtiles.size(), 1) * sizeof(Tile));
         if (!e) e = pp.alloc((void**)&pcache->d_opgroups, std::max<size_t>(pl.op_groups.size(), 1) * sizeof(OpGroup));
+        if (!e) e = pp.alloc((void**)&pcache->d_xrows, std::max<size_t>(pl.xrows.size(), 1) * 4);
         if (e) { pcache->release(pool); return e; }
     }
     BlockPlan* const d_plans = pcache->d_plans; uint32_t* const d_xlist = pcache->d_xlist; uint32_t* const d_ylist = pcache->d_ylist;
@@ -1016,6 +1220,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
         {d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(Tile)},
         {d_mtiles, pl.mtiles.data(), pl.mtiles.size() * sizeof(Tile)},
         {d_opgroups, pl.op_groups.data(), pl.op_groups.size() * sizeof(OpGroup)},
+        {pcache->d_xrows, pl.xrows.data(), pl.xrows.size() * 4},
     };
     size_t up_total = 0;
     if (!pcache->on_device) for (const Up& u : ups) up_total += (u.n + 255) & ~size_t(255);
@@ -1042,23 +1247,55 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HIPCHK(hipMemsetAsync(d_wordpairs, 0, 8, st));
 
     // FP4 matrix-core blocks: operands re-laid in wave-load order (part of "prep": ~2 ms at north-star)
-    if (pl.mfma_fp4 && !pl.mtiles.empty())
-        launch_gather_ops(st, (uint32_t)pl.op_groups.size(), pl.op_max_steps, d_opgroups, d_plans, d_xlist, d_ylist,
-                          db->d.d_cols, db->d.d_cplanes, d_ops);
-    HIPCHK(hipEventRecord(ctx->ev[1], st));
-    if (pl.mfma_fp4)
-        launch_count_mfma_fp4(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_ops, d_slots);
-    else
-        launch_count_mfma(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
-                          db->d.d_cplanes + db->d.n_pairs16, d_slots);
-    launch_count(st, (uint32_t)pl.tiles.size(), d_tiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
-                 d_slots);
+    if (!pipe) {
+        if (pl.mfma_fp4 && !pl.mtiles.empty())
+            launch_gather_ops(st, (uint32_t)pl.op_groups.size(), pl.op_max_steps, d_opgroups, d_plans, d_xlist, d_ylist,
+                              db->d.d_cols, db->d.d_cplanes, d_ops);
+        HIPCHK(hipEventRecord(ctx->ev[1], st));
+        if (pl.mfma_fp4)
+            launch_count_mfma_fp4(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_ops, d_slots);
+        else
+            launch_count_mfma(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
+                              db->d.d_cplanes + db->d.n_pairs16, d_slots);
+        launch_count(st, (uint32_t)pl.tiles.size(), d_tiles, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
+                     d_slots);
+    } else {
+        // the pipelined upload (lgmi_run): piece k of the planes goes up on the upload stream while the tiles that pieces
+        // 0 .. k - 1 completed are counted here; the count stage's time (ms_count) includes what it waited for the planes
+        HIPCHK(hipEventRecord(ctx->ev[1], st));
+        for (uint32_t k = 0; k < pipe->K; ++k) {
+            hipEvent_t up = ctx->event(lgmi_ctx::EV_UP + k);
+            if (!up) return fail(LGMI_E_HIP, "hipEventCreate failed");
+            if ((rc = pipe_chunk(*pipe, const_cast<lgmi_dbatch*>(db), k, up))) return rc;
+            HIPCHK(hipStreamWaitEvent(st, up, 0));
+            const uint32_t og0 = pipe->og_begin[k], og1 = pipe->og_begin[k + 1], mt0 = pipe->mt_begin[k], mt1 = pipe->mt_begin[k + 1],
+                           t0 = pipe->t_begin[k], t1 = pipe->t_begin[k + 1];
+            if (pl.mfma_fp4 && og1 > og0)
+                launch_gather_ops(st, og1 - og0, pl.op_max_steps, d_opgroups + og0, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes, d_ops);
+            if (pl.mfma_fp4) launch_count_mfma_fp4(st, mt1 - mt0, d_mtiles + mt0, d_plans, d_ops, d_slots);
+            else launch_count_mfma(st, mt1 - mt0, d_mtiles + mt0, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
+                                   db->d.d_cplanes + db->d.n_pairs16, d_slots);
+            launch_count(st, t1 - t0, d_tiles + t0, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes, d_slots);
+            HIPCHK(hipGetLastError());
+            if (tr.on && ctx->event(lgmi_ctx::EV_UPDBG + k)) HIPCHK(hipEventRecord(ctx->event(lgmi_ctx::EV_UPDBG + k), st));
+            tr.mark("piece");
+        }
+        if (tr.on) {                                         // when each piece's planes were up / its tiles counted, on the device's clock
+            HIPCHK(hipStreamSynchronize(st));
+            for (uint32_t k = 0; k < pipe->K; ++k) {
+                float up = 0.f, cnt = 0.f;
+                (void)hipEventElapsedTime(&up, ctx->ev[1], ctx->event(lgmi_ctx::EV_UP + k));
+                (void)hipEventElapsedTime(&cnt, ctx->ev[1], ctx->event(lgmi_ctx::EV_UPDBG + k));
+                fprintf(stderr, "[lgmi pipe] piece %u: planes up at %.2f ms, its %u tiles counted at %.2f ms\n", k, up, pipe->mt_begin[k + 1] - pipe->mt_begin[k] + pipe->t_begin[k + 1] - pipe->t_begin[k], cnt);
+            }
+        }
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[2], st));
 
     EmitArgs ea{};
     ea.n_sites = ns; ea.min_common = prm->min_common; ea.het_only = prm->het_only != 0;
-    ea.plans = d_plans; ea.smap = d_smap; ea.xsites = d_ylist; ea.cols = db->d.d_cols;
+    ea.plans = d_plans; ea.smap = d_smap; ea.xsites = d_ylist; ea.xrows = pcache->d_xrows; ea.rows_are_ranks = pl.rows_are_ranks ? 1 : 0; ea.cols = db->d.d_cols;
     ea.type = db->d.d_type; ea.tri = db->d.d_tri;
     ea.slots = d_slots;
     ea.n_items = (uint32_t)n_items; ea.items = d_items;
@@ -1138,9 +1375,15 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     HIPCHK(hipMemcpyAsync(&hs[4], d_gencount + 6, 4, hipMemcpyDeviceToHost, st));    // rows k_perm_six finished
     HIPCHK(hipMemcpyAsync(&hs[2], d_wordpairs, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&hs[3], d_rowstart + n_items, 8, hipMemcpyDeviceToHost, st));
+    hs[7] = 0;
+    if (pipe) {                                              // the tri-flag check ran behind the last piece's event: wait for it here
+        HIPCHK(hipStreamWaitEvent(st, ctx->event(lgmi_ctx::EV_CHECKED), 0));
+        HIPCHK(hipMemcpyAsync(&hs[7], pipe->d_bad, 4, hipMemcpyDeviceToHost, st));
+    }
     tr.mark("enqueued");
     HIPCHK(wait_stream(st));
     tr.mark("drained");
+    if (pipe && (uint32_t)hs[7]) return fail(LGMI_E_ARG, "lgmi_batch.site_tri disagrees with the planes: some site's flag says the opposite of its lo & hi bits");
     const int err = (int)(uint32_t)hs[0]; const unsigned int n_general = (unsigned int)hs[1];
     const unsigned long long wp = hs[2];
     n_rows = hs[3];
@@ -1196,12 +1439,18 @@ static size_t row_bytes_final(bool want_p, bool keep_p, bool want_counts) {
     return 16 + (want_p ? 4 : 0) + (keep_p ? 8 : 0) + (want_counts ? 36 : 0);
 }
 
-static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, const Plan& pl, uint64_t* largest = nullptr) {
+static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, const Plan& pl, uint64_t* largest = nullptr,
+                       float* ms_host = nullptr) {
+    const auto t_enter = std::chrono::steady_clock::now();
     const bool want_p = prm->n_shuffles > 0 || prm->exact_2x2;
     const bool keep_p = want_p && !(prm->n_shuffles > 0 && !prm->exact_2x2 && prm->no_row_p);
     const bool want_counts = prm->emit_counts != 0;
     double budget = 0.70 * (double)ctx->mem_total;
     if (const char* e = getenv("LGMI_MEM_BUDGET_MB")) { const double v = atof(e); if (v > 0.0) budget = v * 1048576.0; }
+    for (const auto& m : db->split_memo)
+        if (m.het_only == (prm->het_only != 0) && m.want_p == want_p && m.keep_p == keep_p && m.want_counts == want_counts &&
+            m.n_shuffles == prm->n_shuffles && m.budget == budget) { if (largest) *largest = m.largest; return m.k; }
+    uint64_t most_seen = 0;
     const double fixed = (double)pl.total_slots * 16.0 + (double)pl.op_total * 16.0;       // what every shard allocates in full
     const double rows_work = (double)pl.n_examined * (double)row_bytes_working(want_p, keep_p, want_counts);
     const double rows_final = (double)pl.n_examined * (double)row_bytes_final(want_p, keep_p, want_counts);
@@ -1234,15 +1483,24 @@ static int split_count(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* 
             }
             const bool fits_mem = fixed + rows_work <= budget || 1.05 * (double)most * per_row <= room;
             const bool fits_32 = !want_p || most < 0xFFFFFFF0ull;
-            if (largest) *largest = most;
+            most_seen = most;
             if (fits_mem && fits_32) break;
         }
+        if (k >= 1024) {                                     // the clamp: the hint must be the clamped count's largest shard, not the last candidate's
+            k = 1024; most_seen = 0;
+            for (int r = 0; r < k; ++r) { Plan sp; build_plan(plan_input(db), prm->het_only != 0, (uint32_t)r, (uint32_t)k, ck, xg, prm->n_shuffles, sp); most_seen = std::max(most_seen, sp.n_examined); }
+        }
     }
-    return std::min(std::max(k, 1), 1024);
+    k = std::min(std::max(k, 1), 1024);
+    if (largest) *largest = most_seen;
+    if (db->split_memo.size() >= 8) db->split_memo.erase(db->split_memo.begin());
+    db->split_memo.push_back({prm->het_only != 0, want_p, keep_p, want_counts, prm->n_shuffles, budget, k, most_seen});
+    if (ms_host) *ms_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    return k;
 }
 
 static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_params* prm, int k, uint64_t bound_rows,
-                            lgmi_dresult** out, uint64_t largest_shard = 0) {
+                            lgmi_dresult** out, uint64_t largest_shard = 0, float ms_split_host = 0.f) {
     const bool want_p = prm->n_shuffles > 0 || prm->exact_2x2;
     const bool p_from_exceed = prm->n_shuffles > 0 && !prm->exact_2x2;
     const bool keep_p = want_p && !(p_from_exceed && prm->no_row_p);
@@ -1299,6 +1557,7 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
         HIPCHK(hipGetLastError());
         HIPCHK(wait_stream(st));                       // the part's arrays go back to the pool next
         const lgmi_run_info& pi = part->info;
+        if (s == 0) { res->first_site = part->first_site; res->first_seg = part->first_seg; }
         if (s == 0) tot = pi;
         else {
             tot.n_rows += pi.n_rows; tot.n_examined += pi.n_examined; tot.n_tile_pairs += pi.n_tile_pairs;
@@ -1318,6 +1577,7 @@ static int run_device_split(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_par
     tot.n_rows = off;
     tot.n_examined = tot.n_examined_total;             // the whole batch was run
     tot.n_seq_shards = (uint32_t)k;
+    tot.ms_plan_host += ms_split_host;                 // (choosing k builds shard plans on the host: not free, so not hidden)
     res->info = tot;
     guard.r = nullptr;
     *out = res;
@@ -1330,8 +1590,9 @@ extern "C" int lgmi_run_device(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_
     if (ctx && db && prm && out && prm->shard_world <= 1 && !getenv("LGMI_NO_AUTO_SPLIT")) {
         const Plan& pl = plan_for(ctx, db, prm->het_only != 0, 0, 1, prm->n_shuffles, nullptr)->pl;   // (the one the run itself uses)
         uint64_t largest = 0;
-        const int k = split_count(ctx, db, prm, pl, &largest);
-        if (k > 1) return run_device_split(ctx, db, prm, k, pl.n_examined, out, largest);
+        float ms_split = 0.f;
+        const int k = split_count(ctx, db, prm, pl, &largest, &ms_split);
+        if (k > 1) return run_device_split(ctx, db, prm, k, pl.n_examined, out, largest, ms_split);
     }
     return run_device_impl(ctx, db, prm, out, false);
 }
@@ -1613,8 +1874,8 @@ extern "C" int lgmi_result_expand_rows(const lgmi_result* res, uint32_t* row_i, 
     { uint64_t o = 0; for (uint64_t s = 0; s < ns; ++s) { lb[s] = o; if (!res->site_row_full[s]) o += rb[s + 1] - rb[s]; } lb[ns] = o; }
     if (lb[ns] != res->n_row_j_listed) return fail(LGMI_E_STATE, "internal: %llu listed partners, the flags ask for %llu",
                                                    (unsigned long long)res->n_row_j_listed, (unsigned long long)lb[ns]);
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(plan_threads(1u << 20), n >> 20));
-    Team team(T);
+    Team team((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(plan_threads(1u << 20), n >> 20)));
+    const unsigned T = team.T;
     team.run([&](unsigned t) {
         // a thread writes the sites whose first row falls into its share of the rows (it walks every block's site list — a
         // site's implicit partners are the later sites of its block — and skips the blocks outside its share)
@@ -1656,7 +1917,12 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
     memset(out, 0, sizeof *out);
     HostTrace tr;
     lgmi_dbatch* db = nullptr;
-    int rc = lgmi_batch_upload(ctx, batch, &db);
+    // the planes may follow the rest of the batch piece by piece, under the count kernels (UploadPipe) — when the caller's
+    // tri flags let the run be planned without them, the planes are packed in site order and one launch sequence holds the run
+    std::unique_ptr<UploadPipe> pipe;
+    const bool piped = prm && prm->shard_world <= 1 && pipe_eligible(batch);
+    if (piped) pipe.reset(new UploadPipe());
+    int rc = upload_impl(ctx, batch, &db, pipe.get());
     if (rc) return rc;
     tr.mark("run:uploaded");
     lgmi_dresult* dr = nullptr;
@@ -1666,11 +1932,24 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
         const Plan& pl = plan_for(ctx, db, prm->het_only != 0, 0, 1, prm->n_shuffles, nullptr)->pl;
         const uint64_t bound = pl.n_examined;               // (before the shards' plans may evict this one)
         uint64_t largest = 0;
-        const int k = split_count(ctx, db, prm, pl, &largest);
-        if (k > 1) { split = true; rc = run_device_split(ctx, db, prm, k, bound, &dr, largest); }
+        float ms_split = 0.f;
+        const int k = split_count(ctx, db, prm, pl, &largest, &ms_split);
+        if (k > 1) {
+            if (pipe) {                                      // the shards need all the planes: bring them up now, in one go
+                for (uint32_t c = 0; c < pipe->K && !rc; ++c) { hipEvent_t e = ctx->event(lgmi_ctx::EV_UP + c); rc = e ? pipe_chunk(*pipe, db, c, e) : fail(LGMI_E_HIP, "hipEventCreate failed"); }
+                if (!rc && (hipStreamSynchronize(pipe->us) != hipSuccess || (pipe->ps && hipStreamSynchronize(pipe->ps) != hipSuccess))) rc = fail(LGMI_E_HIP, "upload failed");
+                if (!rc) { int bad = 0; if (hipMemcpy(&bad, pipe->d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(LGMI_E_HIP, "upload check failed"); else if (bad) rc = fail(LGMI_E_ARG, "lgmi_batch.site_tri disagrees with the planes"); }
+                pipe.reset();
+            }
+            split = true;
+            if (!rc) rc = run_device_split(ctx, db, prm, k, bound, &dr, largest, ms_split);
+        }
     }
     tr.mark("planned");
-    if (!split) rc = run_device_impl(ctx, db, prm, &dr, true);
+    if (!split && !rc) {
+        rc = run_device_impl(ctx, db, prm, &dr, true, 0, pipe.get());
+        pipe.reset();                                        // (waits for the upload stream; releases the planes' staging copies)
+    }
     tr.mark("rows");
     if (!rc) {
         const bool compact = prm->compact_rows != 0;
@@ -1678,8 +1957,8 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
         tr.mark("compact");
         HostResult* h = new HostResult();
         h->pool = ctx->pinned;
-        hipStream_t cs = ctx_comm_stream(ctx), ms = ctx->stream;
-        hipEvent_t ce = ctx_comm_event(ctx);
+        hipStream_t cs = ctx_copy_stream(ctx), ms = ctx->stream;
+        hipEvent_t ce = ctx->event(lgmi_ctx::EV_ORDER);
         if (!rc && cs != ms) {                                   // the communication stream behind what made the rows (and the compact form)
             if (!ce) rc = fail(LGMI_E_HIP, "no event for the communication stream");
             else if (hipEventRecord(ce, ms) != hipSuccess || hipStreamWaitEvent(cs, ce, 0) != hipSuccess) rc = fail(LGMI_E_HIP, "stream ordering failed in lgmi_run");
@@ -1696,7 +1975,7 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
                 // the range's counts: narrowed behind its kernels, then on their way while the next range is computed
                 if (narrow) { launch_narrow_u16(ms, nr, dr->d_exceed + r0, dr->d_exceed16 + r0); HIPCHK(hipGetLastError()); }
                 if (cs != ms) {
-                    hipEvent_t e = ctx->event(96 + k_ev++);
+                    hipEvent_t e = ctx->event(lgmi_ctx::EV_XFER + k_ev++);
                     if (!e) return fail(LGMI_E_HIP, "hipEventCreate failed");
                     HIPCHK(hipEventRecord(e, ms));
                     HIPCHK(hipStreamWaitEvent(cs, e, 0));

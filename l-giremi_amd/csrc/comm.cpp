@@ -236,7 +236,34 @@ __global__ void k_fill_nan(double* __restrict__ mean, uint32_t* __restrict__ cnt
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) { mean[k] = __longlong_as_double(0x7ff8000000000000ll); cnt[k] = 0u; sum[k] = 0ull; }
 }
-enum { M_ROWS = 0, M_FLAGS, M_BASE, M_SITES, M_EXAMINED, M_GENERAL, M_SHUFFLES, M_N };
+// ---- the compact gather (shards of ONE batch): row_i never travels, row_j only from a rank that skipped a pair, the
+// permutation counts in 16 bits when they fit.  The root rebuilds row_i / row_j of rank r's rows from the rank's per-site
+// row counts: rows are in reference order (mutual_information.py:10-12), a site's rows are consecutive, and a rank that
+// emitted every pair it examined holds, for each site, a run of consecutive candidates starting at c0 — 0, or where the
+// rank's first work item starts inside its first site's row.
+// one wave per site
+__global__ __launch_bounds__(256) void k_expand_rows(uint32_t n_sites, const uint32_t* __restrict__ nfirst, const uint64_t* __restrict__ row_off,
+                                                     uint64_t base, int write_j, uint32_t first_site, uint32_t first_c0,
+                                                     const uint8_t* __restrict__ isx, const uint32_t* __restrict__ cand0,
+                                                     const uint32_t* __restrict__ xs, uint32_t* __restrict__ gi, uint32_t* __restrict__ gj)
+{
+    const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (s >= n_sites) return;
+    const uint32_t n = nfirst[s];
+    if (!n) return;
+    const uint64_t o = base + row_off[s];
+    const uint32_t c0 = cand0[s] + (s == first_site ? first_c0 : 0u);
+    const bool x = isx[s] != 0;
+    for (uint32_t k = lane; k < n; k += 64u) {
+        gi[o + k] = s;
+        if (write_j) gj[o + k] = x ? c0 + k : xs[c0 + k];
+    }
+}
+__global__ void k_widen_u16(uint64_t n, const uint16_t* __restrict__ in, uint32_t* __restrict__ out) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = in[k];
+}
+enum { M_ROWS = 0, M_FLAGS, M_BASE, M_SITES, M_EXAMINED, M_GENERAL, M_SHUFFLES, M_ALL, M_FSITE, M_FSEG, M_N };
 }  // namespace
 
 extern "C" int lgmi_dresult_fetch(lgmi_dresult* r, lgmi_result* out);
@@ -254,11 +281,20 @@ struct lgmi_gather {
     uint32_t *gi = nullptr, *gj = nullptr, *gexc = nullptr, *gcnt = nullptr, *gnp = nullptr;
     double *gmi = nullptr, *gp = nullptr, *gmean = nullptr;
     unsigned long long* gsum = nullptr;
+    // compact form
+    bool compact = false, narrow = false;
+    uint32_t* gnfirst_all = nullptr;       // root: [world][n_sites] the ranks' rows by first site
+    uint32_t* gnfirst = nullptr;           // root: their sum (the gathered result's own)
+    uint32_t* gncand = nullptr;
+    uint16_t* g16 = nullptr;               // root: the ranks' 16-bit counts as they arrive; elsewhere: this rank's narrowed counts
     uint64_t M(int r, int k) const { return meta[(size_t)r * M_N + k]; }
+    void release_tmp() { pool_release(ctx, gnfirst_all); pool_release(ctx, g16); gnfirst_all = nullptr; g16 = nullptr; }
     void release_all() {
         pool_release(ctx, gi); pool_release(ctx, gj); pool_release(ctx, gmi); pool_release(ctx, gp); pool_release(ctx, gexc);
         pool_release(ctx, gcnt); pool_release(ctx, gmean); pool_release(ctx, gnp); pool_release(ctx, gsum);
-        gi = gj = gexc = gcnt = gnp = nullptr; gmi = gp = gmean = nullptr; gsum = nullptr;
+        pool_release(ctx, gnfirst); pool_release(ctx, gncand);
+        gi = gj = gexc = gcnt = gnp = nullptr; gmi = gp = gmean = nullptr; gsum = nullptr; gnfirst = gncand = nullptr;
+        release_tmp();
     }
 };
 
@@ -292,6 +328,11 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
     my_meta[M_EXAMINED] = v.info.n_examined;
     my_meta[M_GENERAL] = 0;
     my_meta[M_SHUFFLES] = v.n_shuffles;
+    // compact gather: this rank can take part (bit 32 of the flags: every rank must), and emitted every pair it examined
+    static const bool legacy = getenv("LGMI_GATHER_LEGACY") != nullptr;
+    if (o.same_batch && !legacy && v.nfirst && v.ncand && v.site_type && v.block_site_begin) my_meta[M_FLAGS] |= 1ull << 32;
+    my_meta[M_ALL] = v.n_rows == v.info.n_examined ? 1u : 0u;
+    my_meta[M_FSITE] = v.first_site; my_meta[M_FSEG] = v.first_seg;
     lgmi_gather* h = new lgmi_gather();
     struct Drop { lgmi_gather* p; ~Drop() { if (p) { p->release_all(); delete p; } } } drop{h};
     h->ctx = ctx; h->mine = mine; h->root = root; h->world = world; h->rank = rank;
@@ -315,6 +356,8 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
     h->derive_p = h->M(0, M_FLAGS) & 8u;               // p travels as its exceed count
     h->no_p_array = h->M(0, M_FLAGS) & 16u;            // and is not materialised on the root either
     h->n_shuffles = (uint32_t)h->M(0, M_SHUFFLES);
+    h->compact = h->same_batch && (h->M(0, M_FLAGS) >> 32 & 1u);       // (the flags are equal on all ranks: checked above)
+    h->narrow = h->compact && h->has_p && h->derive_p && h->n_shuffles <= 65535u;
     const uint64_t total = h->total, total_sites = h->total_sites;
 
     // ---- 2. the root allocates; the outcome is agreed on before anything is posted
@@ -330,12 +373,17 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
         if (!e) e = pool_alloc(ctx, (void**)&h->gmean, tsn * 8);
         if (!e) e = pool_alloc(ctx, (void**)&h->gnp, tsn * 4);
         if (!e) e = pool_alloc(ctx, (void**)&h->gsum, tsn * 8);
+        if (!e && h->compact) e = pool_alloc(ctx, (void**)&h->gnfirst_all, tsn * 4 * (size_t)world);
+        if (!e && h->compact) e = pool_alloc(ctx, (void**)&h->gnfirst, tsn * 4);
+        if (!e && h->compact) e = pool_alloc(ctx, (void**)&h->gncand, tsn * 4);
+        if (!e && h->narrow) e = pool_alloc(ctx, (void**)&h->g16, tn * 2 + 4);
         if (e) my_status = 1;
     } else if (h->same_batch) {
         // ncclReduce only writes recvbuff on the root, but every rank hands RCCL a valid device pointer
         const size_t tsn = (size_t)std::max<uint64_t>(v.n_sites, 1);
         int e = pool_alloc(ctx, (void**)&h->gnp, tsn * 4);
         if (!e) e = pool_alloc(ctx, (void**)&h->gsum, tsn * 8);
+        if (!e && h->narrow) e = pool_alloc(ctx, (void**)&h->g16, (size_t)std::max<uint64_t>(v.n_rows, 1) * 2 + 4);
         if (e) my_status = 1;
     }
     std::vector<uint64_t> status(world);
@@ -357,21 +405,24 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
     if (rank != root) {
         const uint64_t n = v.n_rows;
         if (n) {
-            NC(g.Send(v.i, n, ncclUint32, root, comm, st));
-            NC(g.Send(v.j, n, ncclUint32, root, comm, st));
+            // compact: row_i is a run-length code of the per-site counts below; row_j only if this rank skipped a pair
+            if (!h->compact) NC(g.Send(v.i, n, ncclUint32, root, comm, st));
+            if (!h->compact || !h->M(rank, M_ALL)) NC(g.Send(v.j, n, ncclUint32, root, comm, st));
             NC(g.Send(v.mi, n, ncclFloat64, root, comm, st));
             if (h->has_counts) NC(g.Send(v.counts, n * 9, ncclUint32, root, comm, st));
         }
+        if (h->compact && v.n_sites) NC(g.Send(v.nfirst, v.n_sites, ncclUint32, root, comm, st));
     } else {
         uint64_t off = 0;
         for (int r = 0; r < world; ++r) {
             const uint64_t c = h->M(r, M_ROWS);
             if (r != root && c) {
-                NC(g.Recv(h->gi + off, c, ncclUint32, r, comm, st));
-                NC(g.Recv(h->gj + off, c, ncclUint32, r, comm, st));
+                if (!h->compact) NC(g.Recv(h->gi + off, c, ncclUint32, r, comm, st));
+                if (!h->compact || !h->M(r, M_ALL)) NC(g.Recv(h->gj + off, c, ncclUint32, r, comm, st));
                 NC(g.Recv(h->gmi + off, c, ncclFloat64, r, comm, st));
                 if (h->has_counts) NC(g.Recv(h->gcnt + 9 * off, c * 9, ncclUint32, r, comm, st));
             }
+            if (r != root && h->compact && v.n_sites) NC(g.Recv(h->gnfirst_all + (size_t)r * v.n_sites, v.n_sites, ncclUint32, r, comm, st));
             off += c;
         }
     }
@@ -390,6 +441,7 @@ extern "C" int lgmi_comm_gather_begin(lgmi_ctx* ctx, const lgmi_dresult* mine, i
         };
         d2d(h->gi + off, v.i, n * 4); d2d(h->gj + off, v.j, n * 4); d2d(h->gmi + off, v.mi, n * 8);
         if (h->has_counts) d2d(h->gcnt + 9 * off, v.counts, n * 36);
+        if (h->compact) { d2d(h->gnfirst_all + (size_t)root * v.n_sites, v.nfirst, v.n_sites * 4); d2d(h->gncand, v.ncand, v.n_sites * 4); }
         if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_error(LGMI_E_HIP, hipGetErrorString(e)); }
     }
 #undef NC
@@ -434,7 +486,10 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
         const uint64_t n = v.n_rows;
         if (n && h->has_p) {
             if (!h->derive_p) NC(g.Send(v.p, n, ncclFloat64, root, comm, st));
-            NC(g.Send(v.exceed, n, ncclUint32, root, comm, st));
+            if (h->narrow) {                         // every count is at most n_shuffles <= 65535: 2 bytes instead of 4
+                launch_narrow_u16(st, n, v.exceed, h->g16);
+                NC(g.Send(h->g16, 2 * n, ncclUint8, root, comm, st));
+            } else NC(g.Send(v.exceed, n, ncclUint32, root, comm, st));
         }
         if (!h->same_batch && v.n_sites) {
             NC(g.Send(v.mean, v.n_sites, ncclFloat64, root, comm, st));
@@ -447,7 +502,8 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
             if (r != root) {
                 if (c && h->has_p) {
                     if (!h->derive_p) NC(g.Recv(h->gp + off, c, ncclFloat64, r, comm, st));
-                    NC(g.Recv(h->gexc + off, c, ncclUint32, r, comm, st));
+                    if (h->narrow) NC(g.Recv(h->g16 + off, 2 * c, ncclUint8, r, comm, st));
+                    else NC(g.Recv(h->gexc + off, c, ncclUint32, r, comm, st));
                 }
                 if (!h->same_batch && sn) {
                     NC(g.Recv(h->gmean + sb, sn, ncclFloat64, r, comm, st));
@@ -472,6 +528,55 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
         const hipError_t es = hipStreamSynchronize(st);
         if (es != hipSuccess) return set_error(LGMI_E_HIP, hipGetErrorString(es));
         return LGMI_OK;
+    }
+    if (h->compact && h->total) {
+        // ---- 4b. root, compact form: row_i (and the row_j of the ranks that emitted every pair) from the ranks' per-site row
+        //          counts; the 16-bit counts widened into place.  Host tables of the batch's candidates: per site its first
+        //          candidate (an x site: the next site; another site: its place in the block's x-site list), the x sites by rank
+        const uint32_t ns = (uint32_t)v.n_sites;
+        const std::vector<uint64_t>& bsb = *v.block_site_begin;
+        const std::vector<uint8_t>& typ = *v.site_type;
+        std::vector<uint8_t> isx(ns);
+        std::vector<uint32_t> cand0(ns), xs;
+        xs.reserve(ns);
+        for (size_t b = 0; b + 1 < bsb.size(); ++b) {
+            const uint32_t x0 = (uint32_t)xs.size();
+            for (uint64_t s = bsb[b]; s < bsb[b + 1]; ++s) if (!v.het_only || typ[s] == LGMI_TYPE_HET_SNP) xs.push_back((uint32_t)s);
+            uint32_t xnext = 0;
+            for (uint64_t s = bsb[b]; s < bsb[b + 1]; ++s) {
+                isx[s] = (!v.het_only || typ[s] == LGMI_TYPE_HET_SNP) ? 1 : 0;
+                if (isx[s]) { ++xnext; cand0[s] = (uint32_t)s + 1u; } else cand0[s] = x0 + xnext;
+            }
+        }
+        uint8_t* d_isx = nullptr; uint32_t* d_cand0 = nullptr; uint32_t* d_xs = nullptr; uint64_t* d_off = nullptr; uint64_t* d_tmp = nullptr;
+        struct Tmp { lgmi_ctx* c; hipStream_t st; void** p[5]; ~Tmp() { (void)hipStreamSynchronize(st); for (auto q : p) pool_release(c, *q); } }
+            tmp{ctx, st, {(void**)&d_isx, (void**)&d_cand0, (void**)&d_xs, (void**)&d_off, (void**)&d_tmp}};
+        int e2 = pool_alloc(ctx, (void**)&d_isx, std::max<size_t>(ns, 1));
+        if (!e2) e2 = pool_alloc(ctx, (void**)&d_cand0, std::max<size_t>(ns, 1) * 4);
+        if (!e2) e2 = pool_alloc(ctx, (void**)&d_xs, std::max<size_t>(xs.size(), 1) * 4);
+        if (!e2) e2 = pool_alloc(ctx, (void**)&d_off, ((size_t)ns + 1) * 8);
+        if (!e2) e2 = pool_alloc(ctx, (void**)&d_tmp, scan_tmp_words(ns) * 8);
+        if (e2) return e2;
+        HIPCHK2(hipMemcpyAsync(d_isx, isx.data(), ns, hipMemcpyHostToDevice, st));
+        HIPCHK2(hipMemcpyAsync(d_cand0, cand0.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
+        if (!xs.empty()) HIPCHK2(hipMemcpyAsync(d_xs, xs.data(), xs.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK2(hipMemsetAsync(h->gnfirst, 0, (size_t)ns * 4, st));
+        uint64_t roff = 0;
+        for (int r = 0; r < world; ++r) {
+            const uint64_t c = h->M(r, M_ROWS);
+            const uint32_t* nf = h->gnfirst_all + (size_t)r * ns;
+            if (c) {
+                launch_scan(st, nf, d_off, ns, d_tmp);
+                hipLaunchKernelGGL(k_expand_rows, dim3((ns + 3u) / 4u), dim3(256), 0, st, ns, nf, d_off, roff, h->M(r, M_ALL) ? 1 : 0,
+                                   (uint32_t)h->M(r, M_FSITE), (uint32_t)h->M(r, M_FSEG) * LGMI_EMIT_SEG, d_isx, d_cand0, d_xs, h->gi, h->gj);
+                if (h->narrow && r != root)
+                    hipLaunchKernelGGL(k_widen_u16, dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, c, h->g16 + roff, h->gexc + roff);
+            }
+            launch_add_u32(st, ns, h->gnfirst, nf);
+            roff += c;
+        }
+        HIPCHK2(hipGetLastError());
+        HIPCHK2(hipStreamSynchronize(st));            // (the host vectors above go out of scope)
     }
     // ---- 5. root: its own p / exceed, the site bases, the per-site means
     hipError_t e = hipSuccess;
@@ -502,6 +607,11 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
     gv.i = h->gi; gv.j = h->gj; gv.mi = h->gmi; gv.p = h->gp; gv.exceed = h->gexc; gv.counts = h->gcnt;
     gv.mean = h->gmean; gv.npairs = h->gnp; gv.sum = h->gsum;
     gv.n_shuffles = h->n_shuffles; gv.p_from_exceed = h->derive_p;
+    if (h->compact) {                       // the gathered result keeps its compact form within reach
+        gv.nfirst = h->gnfirst; gv.ncand = h->gncand; gv.table_owner = v.table_owner; gv.het_only = v.het_only;
+        gv.first_site = (uint32_t)h->M(0, M_FSITE); gv.first_seg = (uint32_t)h->M(0, M_FSEG);
+    }
+    h->release_tmp();
     gv.info = v.info;                       // stage times stay the root's own
     gv.info.n_rows = total; gv.info.n_examined = h->examined; gv.info.n_general_rows = general;
     *out = dresult_new_gathered(ctx, gv);

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/lgmi.h"
 
 namespace lgmi {
@@ -74,6 +76,12 @@ struct DResultView {
     uint32_t n_shuffles = 0;      // with p_from_exceed: row_p == (1 + row_exceed) / (n_shuffles + 1) for every row
     bool p_from_exceed = false;
     lgmi_run_info info = {};
+    // the compact gather (same batch on every rank): rows by first site, candidate counts, the shard's first work item, and
+    // what names a site's candidates (host tables: x sites of every block by rank, per site its first candidate)
+    const uint32_t* nfirst = nullptr; const uint32_t* ncand = nullptr;
+    uint32_t first_site = 0xFFFFFFFFu, first_seg = 0;
+    const std::vector<uint64_t>* block_site_begin = nullptr; const std::vector<uint8_t>* site_type = nullptr; bool het_only = false;
+    const void* table_owner = nullptr;      // shared_ptr<const SiteTable>* of the source result, for the gathered one to share
 };
 
 static const int TILE = 64;      // tile edge in columns
@@ -120,6 +128,8 @@ struct EmitArgs {
     const BlockPlan* plans;
     const SiteMap* smap;
     const uint32_t* xsites;   // the y list (its x part, [yl_off + n_sites_of_block - nxs, + nxs), lists the x sites by rank)
+    const uint32_t* xrows;    // parallel to it: the slot-matrix row of the x site of that rank
+    int rows_are_ranks;       // 1: pseudo rows sit behind the last x site (unsharded plan): row of rank r == r
     const Col* cols;
     const uint8_t* type;
     const uint8_t* tri;
@@ -196,10 +206,11 @@ hipError_t launch_ecdf(hipStream_t st, uint32_t n_ref, const double* ref, double
 // synth.hip: layout prep for uploaded batches and the dense synthetic generator
 void launch_tri_flags(hipStream_t st, uint32_t n_sites, const uint32_t* site_nw,
                       const uint64_t* site_plane_off, const uint64_t* planes, uint8_t* tri);
-// column c (real: site c; pseudo: col_site[c - n_sites]) <- (C, A) pairs from lo/hi planes
-void launch_prep_cols(hipStream_t st, uint32_t n_cols, uint32_t n_sites, const Col* cols,
+// columns [c0, c0 + n_cols) (real: site c; pseudo: col_site[c - n_sites]) <- (C, A) pairs from lo/hi planes
+void launch_prep_cols(hipStream_t st, uint32_t c0, uint32_t n_cols, uint32_t n_sites, const Col* cols,
                       const uint32_t* pseudo_site, const uint64_t* site_plane_off,
                       const uint64_t* planes, ulonglong2* cplanes);
+void launch_flags_differ(hipStream_t st, uint32_t n, const uint8_t* a, const uint8_t* b, int* out);
 void launch_synth_depth(hipStream_t st, const lgmi_synth_spec& sp, uint32_t W, uint32_t* depth3);
 void launch_synth_write(hipStream_t st, const lgmi_synth_spec& sp, uint32_t W, const uint32_t* depth3,
                         const uint32_t* pseudo_of_site, ulonglong2* cplanes, uint32_t site_base);

@@ -1,10 +1,11 @@
 // plan.cpp — host-side planner (see plan.h).  No HIP runtime call in this file.
 //
 // Layout of a block's slot matrix: rows = x sites in position order (all sites, or the het_snp ones when het_only —
-// src/giremi/mismatch.py:392-396), the pseudo row of a tri x site RIGHT AFTER the site's own row (round 5; until then
-// all pseudo rows sat behind the last x site, in tile rows of their own that every shard of a multi-GPU run needed for
-// nearly all of its columns: 4,000 of the 4,700 tiles eight shards of the north-star computed on top of the unsharded
-// 29,000 — next to its site's row a pseudo row lives in a tile row the shard computes anyway); columns = non-x sites,
+// src/giremi/mismatch.py:392-396) and one pseudo row per tri x site: behind the last x site in an unsharded plan, RIGHT
+// AFTER the site's own row in a sharded one (round 5: behind the last x site the pseudo rows sit in tile rows of their
+// own that every shard of a multi-GPU run needs for nearly all of its columns — 4,000 of the 4,700 tiles eight shards of
+// the north-star computed on top of the unsharded 29,000; next to its site's row a pseudo row lives in a tile row the
+// shard computes anyway: 33,768 -> 31,669 tiles, slowest of eight shards 34.3 -> 33.2 ms on one box); columns = non-x sites,
 // x sites (in x-rank order: this part of the y list is also the rank -> site table of the emit kernels), one pseudo column
 // per tri site.  A row's number is therefore NOT its site's x rank: SiteMap::xrow / prow are rows, SiteMap::xnext counts ranks.  Rows of the RESULT are in the reference's order
 // (itertools.combinations of the sorted positions, src/giremi/mutual_information.py:10-12): site i's row lists its
@@ -68,10 +69,14 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
 {
     if (shard_world == 0) { shard_world = 1; shard_rank = 0; }
     const bool sharded = shard_world > 1;
+    // where a tri x site's pseudo row goes (see pass 1b); LGMI_PSEUDO_ROWS=end|next forces one (A/B runs, tests)
+    static const int pr_env = [] { const char* e = getenv("LGMI_PSEUDO_ROWS"); return !e ? 0 : (e[0] == 'e' ? 1 : (e[0] == 'n' ? 2 : 0)); }();
+    const bool interleave = pr_env ? pr_env == 2 : sharded;
+    pl.rows_are_ranks = !interleave;
     if (count_kernel == 3) pl.mfma_fp4 = false;
     const uint64_t ns = in.n_sites, nb = in.n_blocks;
-    const unsigned T = plan_threads(nb);
-    Team team(T);
+    Team team(plan_threads(nb));
+    const unsigned T = team.T;                           // (what the system granted: plan.h)
     pl.smap.resize(ns);                                  // (PodVec: not initialised here — every site is written in pass 1b)
     pl.plans.resize(nb);
 
@@ -126,6 +131,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
     pl.total_slots = blk_slots[nb];
     pl.xlist.resize(blk_x[nb]);
     pl.ylist.resize(blk_y[nb]);
+    pl.xrows.resize(blk_y[nb]);
     n_items = blk_items[nb];
     pl.items.resize(n_items);
     item_cost.resize(sharded ? n_items : 0);
@@ -143,21 +149,26 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
             uint32_t* const xl = pl.xlist.data() + bp.xl_off;
             uint32_t* const yl = pl.ylist.data() + bp.yl_off;
             for (uint32_t s = sb; s < se; ++s) pl.smap[s] = SiteMap{NONE, NONE, NONE, NONE, 0, 0};
-            // x list: x sites in position order, the pseudo row of a tri x site right behind its own row
+            // x list: x sites in position order; the pseudo row of a tri x site right behind its own row in a SHARDED plan
+            // (a shard then finds it in a tile row it computes anyway), behind the last x site otherwise (row == rank for
+            // the real rows: the emit kernels' column walk measured 12 % faster that way, 13.8 against 15.5 ms at north-star)
             uint32_t nxs = 0, nx = 0;
             for (uint32_t s = sb; s < se; ++s) {
                 const bool in_x = !het_only || in.type[s] == LGMI_TYPE_HET_SNP;
                 if (in_x) {
                     pl.smap[s].xrow = nx; xl[nx++] = s; ++nxs;
-                    if (in.tri[s]) { pl.smap[s].prow = nx; xl[nx++] = in.pseudo_of_site[s]; }
+                    if (interleave && in.tri[s]) { pl.smap[s].prow = nx; xl[nx++] = in.pseudo_of_site[s]; }
                 }
                 pl.smap[s].xnext = nxs;
                 pl.smap[s].block = (uint32_t)b;
             }
+            if (!interleave)
+                for (uint32_t s = sb; s < se; ++s)
+                    if (pl.smap[s].xrow != NONE && in.tri[s]) { pl.smap[s].prow = nx; xl[nx++] = in.pseudo_of_site[s]; }
             // y list: non-x sites, x sites (same order as the x list), pseudo cols of every tri site
             uint32_t ny = 0;
             for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow == NONE) { pl.smap[s].ycol = ny; yl[ny++] = s; }
-            for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow != NONE) { pl.smap[s].ycol = ny; yl[ny++] = s; }
+            for (uint32_t s = sb; s < se; ++s) if (pl.smap[s].xrow != NONE) { pl.smap[s].ycol = ny; pl.xrows[bp.yl_off + ny] = pl.smap[s].xrow; yl[ny++] = s; }
             for (uint32_t s = sb; s < se; ++s) if (in.tri[s]) { pl.smap[s].pcol = ny; yl[ny++] = in.pseudo_of_site[s]; }
             // examined pairs: pairs a wave of the emit kernel will look at
             const uint64_t W = std::max<uint64_t>(1, ((uint64_t)in.block_n_reads[b] + 63u) / 64u);
@@ -252,7 +263,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
     }
 
     // ---- pass 2: count tiles, block by block; a sharded run keeps the tiles its items read from
-    std::vector<uint32_t> xmin, xmax, ymin, ymax, xbefore, tribefore, row_rank;
+    std::vector<uint32_t> xmin, xmax, ymin, ymax, xbefore, tribefore, row_rank, tile_min_rank, trix_before;
     NeedMap need;
     for (uint64_t b = b0; b < b1; ++b) {
         const BlockPlan& bp = pl.plans[b];
@@ -273,23 +284,26 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         std::vector<Tile>& out_tiles = use_mfma ? part_mtiles[t] : part_tiles[t];
         const uint32_t ntx = (bp.nx + edge - 1) / edge, nty = (bp.ny + edge - 1) / edge;
 
-        // x rank of every row (a pseudo row has its site's): rows are in rank order
+        // x rank of every row (a pseudo row has its site's), then the smallest rank in every tile row
         row_rank.assign(bp.nx, 0);
         for (uint32_t s = sb; s < se; ++s) {
             const SiteMap& m = pl.smap[s];
             if (m.xrow != NONE) row_rank[m.xrow] = m.xnext - 1u;
             if (m.prow != NONE) row_rank[m.prow] = m.xnext - 1u;
         }
+        tile_min_rank.assign(ntx, 0xFFFFFFFFu);
+        for (uint32_t r = 0; r < bp.nx; ++r) tile_min_rank[r / edge] = std::min(tile_min_rank[r / edge], row_rank[r]);
         const uint32_t* const yl_x = pl.ylist.data() + bp.yl_off + y_xpart;      // x rank -> site
         if (sharded) {
             need.reset(ntx, nty, edge);
             const uint64_t a = std::max(blk_item_begin, pl.item_begin), e = std::min(blk_item_end, pl.item_end);
             if (a >= e) continue;                        // none of this block's rows belong to the shard
-            xbefore.assign(P + 1, 0); tribefore.assign(P + 1, 0);
+            xbefore.assign(P + 1, 0); tribefore.assign(P + 1, 0); trix_before.assign(nxs + 1, 0);
             for (uint32_t k = 0; k < P; ++k) {
                 const bool is_x = pl.smap[sb + k].xrow != NONE;
                 xbefore[k + 1] = xbefore[k] + (is_x ? 1u : 0u);
                 tribefore[k + 1] = tribefore[k] + (in.tri[sb + k] ? 1u : 0u);
+                if (is_x) trix_before[xbefore[k + 1]] = trix_before[xbefore[k]] + (in.tri[sb + k] ? 1u : 0u);
             }
             for (uint64_t it = a; it < e; ++it) {
                 const uint32_t i = pl.items[it].x, g = pl.items[it].y;
@@ -306,11 +320,18 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                     }
                 } else {
                     (void)g;                                     // (always 0: one item per such site)
-                    // its partners are the x sites of rank xnext and later: their rows and pseudo rows are every row from
-                    // the first of them on
-                    const uint32_t ra = mi.xnext < nxs ? pl.smap[yl_x[mi.xnext]].xrow : bp.nx, rb = bp.nx;
-                    need.mark(ra, rb, mi.ycol, mi.ycol + 1u);
-                    if (mi.pcol != NONE) need.mark(ra, rb, mi.pcol, mi.pcol + 1u);
+                    // its partners are the x sites of rank xnext and later: their rows and pseudo rows
+                    if (interleave) {                            // every row from the first of them on
+                        const uint32_t ra = mi.xnext < nxs ? pl.smap[yl_x[mi.xnext]].xrow : bp.nx, rb = bp.nx;
+                        need.mark(ra, rb, mi.ycol, mi.ycol + 1u);
+                        if (mi.pcol != NONE) need.mark(ra, rb, mi.pcol, mi.pcol + 1u);
+                    } else {                                     // real rows [xa, nxs), and the pseudo rows behind them of the tri ones
+                        const uint32_t xa = mi.xnext, xb = nxs;
+                        const uint32_t pa = nxs + trix_before[xa], pb = nxs + trix_before[xb];
+                        need.mark(xa, xb, mi.ycol, mi.ycol + 1u);
+                        need.mark(pa, pb, mi.ycol, mi.ycol + 1u);
+                        if (mi.pcol != NONE) { need.mark(xa, xb, mi.pcol, mi.pcol + 1u); need.mark(pa, pb, mi.pcol, mi.pcol + 1u); }
+                    }
                 }
             }
         }
@@ -341,7 +362,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                     const uint32_t x0 = tx * edge, x1 = std::min(x0 + edge, bp.nx);
                     // rows (an x site's and its pseudo row alike) against x site cols: only row rank < col rank is ever read
                     (void)x1;
-                    if (y0 >= y_xpart && y1 <= y_xpart + nxs && row_rank[x0] >= (y1 - 1 - y_xpart)) continue;
+                    if (y0 >= y_xpart && y1 <= y_xpart + nxs && tile_min_rank[tx] >= (y1 - 1 - y_xpart)) continue;
                     const uint32_t k0 = std::max(xmin[tx], ymin[ty]), k1 = std::min(xmax[tx], ymax[ty]);
                     if (k0 >= k1) continue;
                     if (sharded && !need.get(tx, ty)) continue;

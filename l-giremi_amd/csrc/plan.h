@@ -7,7 +7,10 @@
 // independent (src/giremi/mutual_information.py:12), so ANY cut of the ordered row list is a valid shard.
 #pragma once
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -28,22 +31,61 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 template <class T> using PodVec = std::vector<T, NoInitAlloc<T>>;
 
 // one team of host threads for a multi-phase pass over a batch: spawned once, phases separated by a spinning barrier (the
-// phases are a few hundred microseconds each: a spawn / join round per phase costs more than the work)
+// phases are a few hundred microseconds each: a spawn / join round per phase costs more than the work).
+// The threads are made by the CONSTRUCTOR and parked: T is what the system granted, not what was asked for — under a
+// container's thread / pid limit std::thread throws, and an exception that unwinds a vector of joinable threads (or leaves
+// fewer threads than a barrier waits for) ended the host process where an LGMI_E_* code belongs (advice r4).  Callers size
+// their per-thread arrays and ranges by team.T after construction.
 struct Team {
-    unsigned T;
+    unsigned T = 1;
     std::atomic<unsigned> count{0}, gen{0};
-    explicit Team(unsigned t) : T(t) {}
+    explicit Team(unsigned want) {
+        for (unsigned t = 1; t < want; ++t) {
+            try { th.emplace_back([this, t] { park(t); }); } catch (...) { break; }
+            ++T;
+        }
+    }
+    ~Team() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        for (auto& x : th) x.join();
+    }
+    Team(const Team&) = delete;
+    Team& operator=(const Team&) = delete;
     void barrier() {
         if (T <= 1) return;
         const unsigned g = gen.load(std::memory_order_acquire);
         if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == T) { count.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_acq_rel); }
         else while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
     }
-    template <class F> void run(F body) {                   // body(thread)
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(body, t);
+    template <class F> void run(F body) {                   // body(thread), on every thread of the team; returns when all are done
+        if (T > 1) {
+            { std::lock_guard<std::mutex> lk(mu); job = [&body](unsigned t) { body(t); }; ++job_no; left = T - 1; }
+            cv.notify_all();
+        }
         body(0u);
-        for (auto& x : th) x.join();
+        if (T > 1) { std::unique_lock<std::mutex> lk(mu); done.wait(lk, [this] { return left == 0; }); }
+    }
+private:
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done;
+    std::function<void(unsigned)> job;
+    unsigned job_no = 0, left = 0;
+    bool quit = false;
+    void park(unsigned t) {
+        unsigned seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || job_no != seen; });
+                if (quit) return;
+                seen = job_no; f = job;
+            }
+            f(t);
+            { std::lock_guard<std::mutex> lk(mu); if (--left == 0) done.notify_all(); }
+        }
     }
 };
 
@@ -61,8 +103,10 @@ struct PlanInput {
 struct Plan {
     std::vector<BlockPlan> plans;
     PodVec<uint32_t> xlist, ylist;
+    PodVec<uint32_t> xrows;         // parallel to ylist; its x part holds the slot-matrix ROW of the x site of that rank (pseudo rows sit in between)
     PodVec<SiteMap> smap;
     bool mfma_fp4 = true;           // every matrix-core block has fewer than 2^24 reads: f32 accumulation is exact
+    bool rows_are_ranks = true;     // pseudo rows behind the last x site of every block: a real x row's number is its site's x rank
     std::vector<Tile> tiles;        // 64 x 64 tiles for k_count (VALU popcount) — this shard's
     std::vector<Tile> mtiles;       // 128 x 128 tiles for the matrix-core count kernels — this shard's
     std::vector<OpGroup> op_groups; // FP4 matrix-core blocks: the 32-column operand groups this shard's tiles read

@@ -27,13 +27,13 @@ void launch_tri_flags(hipStream_t st, uint32_t n_sites, const uint32_t* site_nw,
     hipLaunchKernelGGL(k_tri_flags, dim3(n_sites), dim3(256), 0, st, n_sites, site_nw, site_plane_off, planes, tri);
 }
 
-__global__ __launch_bounds__(256) void k_prep_cols(uint32_t n_cols, uint32_t n_sites, const Col* __restrict__ cols,
+__global__ __launch_bounds__(256) void k_prep_cols(uint32_t c0, uint32_t n_cols, uint32_t n_sites, const Col* __restrict__ cols,
                                                    const uint32_t* __restrict__ pseudo_site,
                                                    const uint64_t* __restrict__ site_plane_off,
                                                    const uint64_t* __restrict__ planes, ulonglong2* __restrict__ cplanes)
 {
-    const uint32_t c = blockIdx.x;
-    if (c >= n_cols) return;
+    if (blockIdx.x >= n_cols) return;
+    const uint32_t c = c0 + blockIdx.x;              // columns [c0, c0 + n_cols): a pipelined upload preps them piece by piece
     const bool pseudo = c >= n_sites;
     const uint32_t s = pseudo ? pseudo_site[c - n_sites] : c;
     const Col ci = cols[c];
@@ -48,12 +48,22 @@ __global__ __launch_bounds__(256) void k_prep_cols(uint32_t n_cols, uint32_t n_s
     }
 }
 
-void launch_prep_cols(hipStream_t st, uint32_t n_cols, uint32_t n_sites, const Col* cols,
+void launch_prep_cols(hipStream_t st, uint32_t c0, uint32_t n_cols, uint32_t n_sites, const Col* cols,
                       const uint32_t* pseudo_site, const uint64_t* site_plane_off,
                       const uint64_t* planes, ulonglong2* cplanes) {
     if (!n_cols) return;
-    hipLaunchKernelGGL(k_prep_cols, dim3(n_cols), dim3(256), 0, st, n_cols, n_sites, cols, pseudo_site,
+    hipLaunchKernelGGL(k_prep_cols, dim3(n_cols), dim3(256), 0, st, c0, n_cols, n_sites, cols, pseudo_site,
                        site_plane_off, planes, cplanes);
+}
+
+// *out = 1 when two flag arrays differ anywhere (a caller's lgmi_batch.site_tri against what the planes say)
+__global__ void k_flags_differ(uint32_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && (a[k] != 0) != (b[k] != 0)) *out = 1;
+}
+void launch_flags_differ(hipStream_t st, uint32_t n, const uint8_t* a, const uint8_t* b, int* out) {
+    if (n) hipLaunchKernelGGL(k_flags_differ, dim3((n + 255u) / 256u), dim3(256), 0, st, n, a, b, out);
 }
 
 // ---------------------------------------------------------------- dense synthetic chromosome

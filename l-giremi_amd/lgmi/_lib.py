@@ -26,7 +26,7 @@ class Batch(C.Structure):
     _fields_ = [('n_blocks', C.c_uint64), ('n_sites', C.c_uint64), ('n_plane_words', C.c_uint64),
                 ('block_site_begin', u64p), ('block_n_reads', u32p), ('site_pos', i64p),
                 ('site_type', u8p), ('site_word_off', u32p), ('site_n_words', u32p),
-                ('site_plane_off', u64p), ('planes', u64p)]
+                ('site_plane_off', u64p), ('planes', u64p), ('site_tri', u8p)]
 
 
 class Params(C.Structure):

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import argparse
 import logging
+import os
 import sys
 from collections import defaultdict
 
@@ -86,7 +87,11 @@ class _RemovedWriter:
     one _write_removed over the whole table"""
 
     def __init__(self, path):
-        self.path, self.parts = path, 0
+        # written under a temporary name and renamed when the run has succeeded: a run that fails half-way (advice r4: an
+        # IndexError parity check, an out-of-memory kill) must not leave a truncated table that looks like a result
+        self.final, self.path, self.parts = path, path + '.partial', 0
+        if os.path.exists(self.final):
+            os.remove(self.final)                          # (a stale table of an earlier run next to this run's other files)
 
     def __call__(self, df):
         _write_removed(df, self.path, header=(self.parts == 0), append=(self.parts > 0))
@@ -96,6 +101,11 @@ class _RemovedWriter:
         if not self.parts:
             import pandas as pd
             _write_removed(pd.DataFrame({c: [] for c in ('chromosome', 'strand', 'pos', 'removed')}), self.path)
+        os.replace(self.path, self.final)
+
+    def abort(self):
+        if os.path.exists(self.path):
+            os.remove(self.path)
 
 
 def _write_removed(df, path, header=True, append=False):
@@ -271,17 +281,22 @@ def main(argv=None):
     # one rank: the removed-site table (one row per covered position: most of what a run writes) goes out part by part
     # while later footprints are still being extracted
     removed_writer = _RemovedWriter(args.output_prefix + '.removed.txt') if world == 1 else None
-    df_sites, df_mi, df_removed = regions_mismatch_analysis(
-        jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
-        engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta), timing=timing,
-        group=group, removed_sink=removed_writer,
-        keep_non_spliced_read=args.keep_non_spliced_read,
-        min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
-        min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
-        homopoly_length=args.homopoly_length, min_het_snp_ratio=args.min_het_snp_ratio,
-        max_het_snp_ratio=args.max_het_snp_ratio, mismatch_window_size=args.mismatch_window_size,
-        max_window_mismatch=args.max_window_mismatch, max_window_mismatch_type=args.max_window_mismatch_type,
-        mode=args.mode)
+    try:
+        df_sites, df_mi, df_removed = regions_mismatch_analysis(
+            jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
+            engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta), timing=timing,
+            group=group, removed_sink=removed_writer,
+            keep_non_spliced_read=args.keep_non_spliced_read,
+            min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
+            min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
+            homopoly_length=args.homopoly_length, min_het_snp_ratio=args.min_het_snp_ratio,
+            max_het_snp_ratio=args.max_het_snp_ratio, mismatch_window_size=args.mismatch_window_size,
+            max_window_mismatch=args.max_window_mismatch, max_window_mismatch_type=args.max_window_mismatch_type,
+            mode=args.mode)
+    except BaseException:
+        if removed_writer is not None:
+            removed_writer.abort()                         # no half-written table next to missing .mi.txt / .strand.txt files
+        raise
     t0 = time.perf_counter()
     strand_df = pd.DataFrame.from_records([], columns=['read_name', 'original_read_strand', 'corrected_read_strand'])
     if world > 1:

@@ -35,6 +35,7 @@ class PackedBatch:
     planes: np.ndarray
     type_names: List[str] = field(default_factory=list)   # original type string of every site
     bad_sites: np.ndarray = None                          # sites whose depth dict has < 2 alleles
+    site_tri: np.ndarray = None                           # uint8 [n_sites]: the site has class-0 reads (lgmi_batch.site_tri), or None
 
     @property
     def n_blocks(self):
@@ -51,7 +52,9 @@ class PackedBatch:
                           p(self.block_site_begin, _lib.u64p), p(self.block_n_reads, _lib.u32p),
                           p(self.site_pos, _lib.i64p), p(self.site_type, _lib.u8p),
                           p(self.site_word_off, _lib.u32p), p(self.site_n_words, _lib.u32p),
-                          p(self.site_plane_off, _lib.u64p), p(self.planes, _lib.u64p))
+                          p(self.site_plane_off, _lib.u64p), p(self.planes, _lib.u64p),
+                          p(self.site_tri, _lib.u8p) if self.site_tri is not None and len(self.site_tri) == self.n_sites
+                          else C.cast(None, _lib.u8p))
 
     @classmethod
     def from_struct(cls, b: _lib.Batch) -> 'PackedBatch':
@@ -65,7 +68,7 @@ class PackedBatch:
                    a(b.site_pos, ns, np.int64), types, a(b.site_word_off, ns, np.uint32),
                    a(b.site_n_words, ns, np.uint32), a(b.site_plane_off, ns, np.uint64),
                    a(b.planes, int(b.n_plane_words), np.uint64), [names[t] for t in types],
-                   np.zeros(ns, bool))
+                   np.zeros(ns, bool), a(b.site_tri, ns, np.uint8) if b.site_tri else None)
 
 
 def concat_batches(parts: Sequence['PackedBatch']) -> 'PackedBatch':
@@ -80,7 +83,8 @@ def concat_batches(parts: Sequence['PackedBatch']) -> 'PackedBatch':
     return PackedBatch(np.concatenate(bsb), cat('block_n_reads', np.uint32), cat('site_pos', np.int64),
                        cat('site_type', np.uint8), cat('site_word_off', np.uint32), cat('site_n_words', np.uint32),
                        np.concatenate(poff), cat('planes', np.uint64), sum((list(p.type_names) for p in parts), []),
-                       np.concatenate([p.bad_sites if p.bad_sites is not None else np.zeros(p.n_sites, bool) for p in parts]))
+                       np.concatenate([p.bad_sites if p.bad_sites is not None else np.zeros(p.n_sites, bool) for p in parts]),
+                       np.concatenate([p.site_tri for p in parts]).astype(np.uint8) if all(p.site_tri is not None for p in parts) else None)
 
 
 def _or_scatter(planes: np.ndarray, target: np.ndarray, bits: np.ndarray):
@@ -94,7 +98,7 @@ def _or_scatter(planes: np.ndarray, target: np.ndarray, bits: np.ndarray):
 def _pack_one(mismatches: dict):
     """one block, vectorised: the only per-read Python work is list.extend of the name lists; read numbering,
     duplicate handling, band limits and the two bit planes are array operations.
-    -> (pos, type names, bad flags, n_reads, word_off, n_words, planes of the block, plane offsets inside it)"""
+    -> (pos, type names, bad flags, n_reads, word_off, n_words, planes of the block, plane offsets inside it, tri flags)"""
     positions = sorted(mismatches.keys())
     P = len(positions)
     names_flat: List[str] = []
@@ -116,7 +120,7 @@ def _pack_one(mismatches: dict):
     n = len(names_flat)
     if n == 0:
         z = np.zeros(P, np.int64)
-        return pos, type_names, bad, 0, z, z, np.zeros(0, np.uint64), z
+        return pos, type_names, bad, 0, z, z, np.zeros(0, np.uint64), z, np.zeros(P, np.uint8)
     # reads are numbered in order of first appearance (sites by position, alleles in `nt` order): what factorize does
     import pandas as pd
     code, uniques = pd.factorize(np.asarray(names_flat, dtype=object))
@@ -143,16 +147,17 @@ def _pack_one(mismatches: dict):
     m_lo, m_hi = cls_u != 2, cls_u != 1                          # class 1 and class 0 set lo; class 2 and class 0 set hi
     _or_scatter(planes, lo_at[m_lo], bit[m_lo])
     _or_scatter(planes, (lo_at + nw[site_u])[m_hi], bit[m_hi])
-    return pos, type_names, bad, R, w0, nw, planes, poff
+    tri = (np.bincount(site_u[cls_u == 0], minlength=P) > 0).astype(np.uint8)     # lgmi_batch.site_tri: the site has class-0 reads
+    return pos, type_names, bad, R, w0, nw, planes, poff, tri
 
 
 def pack_blocks(blocks: Sequence[dict]) -> PackedBatch:
     """one block per ``mismatches[strand]`` dict (positions -> site dict)."""
-    bsb, n_reads, pos, names, woff, nwords, poff, chunks, bad = [0], [], [], [], [], [], [], [], []
+    bsb, n_reads, pos, names, woff, nwords, poff, chunks, bad, tri = [0], [], [], [], [], [], [], [], [], []
     total = 0
     for mismatches in blocks:
-        p, tn, b, R, w0, nw, planes, po = _pack_one(mismatches)
-        pos.append(p); names.extend(tn); bad.append(b); woff.append(w0); nwords.append(nw)
+        p, tn, b, R, w0, nw, planes, po, tr = _pack_one(mismatches)
+        pos.append(p); names.extend(tn); bad.append(b); woff.append(w0); nwords.append(nw); tri.append(tr)
         poff.append(po + total)
         chunks.append(planes)
         total += planes.size
@@ -164,4 +169,4 @@ def pack_blocks(blocks: Sequence[dict]) -> PackedBatch:
     typ = np.asarray([TYPE_CODE.get(t, _lib.TYPE_MISMATCH) for t in names], np.uint8)
     return PackedBatch(np.asarray(bsb, np.uint64), np.asarray(n_reads, np.uint32), cat(pos, np.int64), typ,
                        cat(woff, np.uint32), cat(nwords, np.uint32), cat(poff, np.uint64),
-                       np.ascontiguousarray(cat(chunks, np.uint64)), names, cat(bad, bool))
+                       np.ascontiguousarray(cat(chunks, np.uint64)), names, cat(bad, bool), cat(tri, np.uint8))

@@ -15,6 +15,24 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    _native_stack_on_abort()
+
+
+def _native_stack_on_abort():
+    """a crash inside the native libraries (an abort of the HIP runtime, a glibc heap check, a GPU fault surfacing as
+    SIGABRT) otherwise leaves only Python's "Fatal Python error: Aborted": tools/src/abort_bt.c prints the native stack
+    first.  Best effort — no compiler, no helper."""
+    import ctypes
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, 'tools', 'src', 'abort_bt.c')
+    out = os.path.join(tempfile.gettempdir(), 'lgmi_abort_bt_%d.so' % os.getuid())
+    try:
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            subprocess.run(['gcc', '-shared', '-fPIC', '-o', out, src], check=True, capture_output=True, timeout=60)
+        ctypes.CDLL(out).lgmi_abort_bt_install()
+    except Exception:                                  # noqa: BLE001
+        pass
 
 
 def load_golden(name):

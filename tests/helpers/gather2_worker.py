@@ -69,6 +69,37 @@ def main():
         checked.append('same_batch counts=%s rows=%d' % (counts, ref.n_rows))
     db.free()
 
+    # ---- (1b) the same on banded blocks where many pairs fall below min_common: a rank that skipped a pair sends its
+    #           partners (row_j), one that emitted all of its pairs does not (compact gather: comm.cpp) — several blocks,
+    #           so that some shards are of either kind; the gathered result also has a compact form of its own
+    pbb = random_batch(5200, n_blocks=5, P=(30, 260), R=(200, 2500), banded=True, tri_frac=0.2)
+    dense_small = random_batch(5201, n_blocks=2, P=(120, 200), R=(300, 600), banded=False)
+    from lgmi.pack import concat_batches
+    dbb = eng.upload(concat_batches([dense_small, pbb, dense_small]))
+    for het_only in (True, False):
+        kw = dict(min_common=6, het_only=het_only, n_shuffles=30, seed=5, emit_counts=False)
+        whole = eng.run_device(dbb, **kw)
+        ref = whole.fetch()
+        whole.free()
+        dr = eng.run_device(dbb, shard=(rank, world), **kw)
+        g, begins = eng.comm_gather(dr, root=0, site_base=0, same_batch=True)
+        if rank == 0:
+            same(g.fetch(), ref, False, 'banded one-call gather, het_only=%s' % het_only)
+            if os.environ.get('LGMI_TEST_GATHER_FORM') == 'plain':
+                try:                                           # the plain gather carries no per-site row counts: no compact form
+                    g.fetch(compact=True)
+                    raise AssertionError('a compact fetch of a plainly gathered result was accepted')
+                except lgmi._lib.LgmiError as e:
+                    assert e.code == lgmi._lib.E_STATE, str(e)
+            else:
+                c = g.fetch(compact=True)
+                assert c.compact
+                same(c, ref, False, 'banded gather, compact fetch of the gathered result')
+            g.free()
+        dr.free()
+        checked.append('banded same_batch het_only=%s rows=%d' % (het_only, ref.n_rows))
+    dbb.free()
+
     # ---- (2) blocks dealt to ranks: every rank runs ITS OWN batch; site indices are shifted by the rank's site base,
     #          per-site figures are concatenated
     pbs = [random_batch(4100 + r, n_blocks=3, P=(2, 80), R=(6, 600), tri_frac=0.3) for r in range(world)]

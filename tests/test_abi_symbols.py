@@ -44,7 +44,7 @@ def test_io_library_exports_every_declared_symbol():
 def test_abi_version_and_struct_sizes():
     lib = _lib.load()
     assert lib.lgmi_abi_version() == _lib.ABI_VERSION
-    assert C.sizeof(_lib.Batch) == 88
+    assert C.sizeof(_lib.Batch) == 96
     assert C.sizeof(_lib.Params) == 32
     assert C.sizeof(_lib.Result) == 144
     assert C.sizeof(_lib.RunInfo) == 128

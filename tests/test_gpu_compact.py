@@ -196,3 +196,75 @@ def test_empty_results(engine):
     a = engine.run(pb, min_common=1, n_shuffles=10, compact=True)
     assert a.n_rows == 0 and len(a.row_i) == 0 and len(a.row_j) == 0 and len(a.row_exceed) == 0
     assert (a.row_begin == 0).all()
+
+
+# ---------------------------------------------------------------- the pipelined upload of lgmi_run (lgmi_batch.site_tri)
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize('pieces', ['1', '3', '8', '64'])
+def test_planes_uploaded_in_pieces_under_the_count_kernels(engine, pieces):
+    """with the packer's tri flags (lgmi_batch.site_tri) lgmi_run plans before the planes have moved and uploads them in
+    pieces of sites, the count kernels of the tiles a piece completes running meanwhile: same rows, tables and counts as
+    the plain upload — on small / banded / multi-block batches (VALU tiles), on a dense block (matrix-core tiles, FP4
+    operand groups) and with the int8 matrix-core kernel"""
+    import lgmi
+    from lgmi.pack import concat_batches
+    db = engine.synth_dense(lgmi.default_synth_spec(1800, 9000, seed=3))
+    dense = db.download()
+    db.free()
+    assert dense.site_tri is not None and dense.site_tri.any() and not dense.site_tri.all()
+    # (batches from random_batch carry no flags: make them the way a packer would)
+    def with_flags(pb):
+        if pb.site_tri is None:
+            tri = np.zeros(pb.n_sites, np.uint8)
+            for s in range(pb.n_sites):
+                o, w = int(pb.site_plane_off[s]), int(pb.site_n_words[s])
+                tri[s] = bool((pb.planes[o:o + w] & pb.planes[o + w:o + 2 * w]).any())
+            pb.site_tri = tri
+        return pb
+    parts = [random_batch(70, n_blocks=7, P=(20, 200), R=(100, 2000), tri_frac=0.3), dense,
+             random_batch(71, n_blocks=4, P=(2, 60), R=(6, 500), banded=True)]
+    mixed = concat_batches([with_flags(p) for p in parts])
+    assert mixed.site_tri is not None
+    for pb, extra in ((mixed, {}), (dense, {}), (dense, {'LGMI_COUNT_KERNEL': 'mfma_i8'}), (dense, {'LGMI_COUNT_KERNEL': 'valu'})):
+        kw = dict(min_common=5, het_only=True, n_shuffles=25, seed=6, emit_counts=True)
+        plain = _with_env(dict(extra, LGMI_NO_UPLOAD_PIPE='1'), lambda: engine.run(pb, **kw))
+        piped = _with_env(dict(extra, LGMI_UPLOAD_PIPE_MIN_WORDS='0', LGMI_UPLOAD_CHUNKS=pieces), lambda: engine.run(pb, **kw))
+        for f in ('row_i', 'row_j', 'row_mi', 'row_counts', 'row_exceed', 'site_n_pairs', 'site_mean_mi'):
+            np.testing.assert_array_equal(getattr(piped, f), getattr(plain, f), err_msg=f)
+        assert piped.n_rows > 1000
+
+
+def test_wrong_tri_flags_are_an_error_not_a_wrong_result(engine):
+    import lgmi
+    db = engine.synth_dense(lgmi.default_synth_spec(600, 5000, seed=4))
+    pb = db.download()
+    db.free()
+    good = pb.site_tri.copy()
+    for flip in (int(np.nonzero(good)[0][0]), int(np.nonzero(good == 0)[0][5])):
+        pb.site_tri = good.copy()
+        pb.site_tri[flip] ^= 1
+        for env in ({'LGMI_UPLOAD_PIPE_MIN_WORDS': '0'}, {'LGMI_NO_UPLOAD_PIPE': '1'}):
+            with pytest.raises(lgmi._lib.LgmiError) as e:
+                _with_env(env, lambda: engine.run(pb, min_common=5))
+            assert e.value.code == lgmi._lib.E_ARG and 'site_tri' in str(e.value)
+    pb.site_tri = good
+    assert _with_env({'LGMI_UPLOAD_PIPE_MIN_WORDS': '0'}, lambda: engine.run(pb, min_common=5)).n_rows > 0
+    # planes that are not packed in site order: the plain upload is taken, the result is the same
+    pb2 = lgmi.pack.PackedBatch(pb.block_site_begin, pb.block_n_reads, pb.site_pos, pb.site_type, pb.site_word_off, pb.site_n_words,
+                                (pb.site_plane_off + np.uint64(3)), np.concatenate([np.zeros(3, np.uint64), pb.planes]), pb.type_names,
+                                pb.bad_sites, good)
+    a = _with_env({'LGMI_UPLOAD_PIPE_MIN_WORDS': '0'}, lambda: engine.run(pb2, min_common=5))
+    b = engine.run(pb, min_common=5)
+    np.testing.assert_array_equal(a.row_mi, b.row_mi)

@@ -45,8 +45,57 @@ def engine():
     eng.close()
 
 
-@pytest.mark.parametrize('n_sites,n_reads,n_shuffles', [(10_000, 50_000, 1000), (50_000, 200_000, 1000), (50_000, 200_000, 0)],
-                         ids=['cfg2_10kx50k_S1000', 'north_star_50kx200k_S1000', 'north_star_50kx200k_S0'])
+def test_north_star_without_shuffles(engine):
+    """what `bench.py --shuffles 0` times (BASELINE.json north_star, MI only): ordering, sampled tables against numpy
+    popcounts, the pattern of exact zeros against the C oracle, per-site pair counts.  The tables are not shipped (the
+    S = 1000 case below checks all 4.5e8 of them): the sampled and the exactly-zero rows' tables are recomputed from the
+    downloaded planes; the rows come over in the compact form"""
+    import lgmi
+    from oracle import c_oracle
+    P, R = 50_000, 200_000
+    db = engine.synth_dense(lgmi.default_synth_spec(P, R, seed=20250808))
+    dr = engine.run_device(db, min_common=6, het_only=True, n_shuffles=0, seed=11)
+    info = dr.info()
+    res = dr.fetch(compact=True)
+    dr.free()
+    pb = db.download()
+    db.free()
+    het = pb.site_type == 2
+    H = int(het.sum())
+    assert info['n_examined'] == H * (P - H) + H * (H - 1) // 2 == res.n_rows and info['ms_perm'] < 0.1
+    assert res.row_p is None and res.row_exceed is None
+    assert res.site_row_full.all() and len(res.row_j_listed) == 0
+    # the per-site offsets ARE the candidate counts (an x site: every later site; another site: the later x sites)
+    xafter = H - np.cumsum(het)
+    want = np.where(het, P - 1 - np.arange(P), xafter)
+    np.testing.assert_array_equal(np.diff(res.row_begin.astype(np.int64)), want)
+    ri, rj = res.row_i, res.row_j
+    rng = np.random.default_rng(3)
+    for s in rng.choice(P, 300, replace=False):                   # expanded rows of sampled sites: partners in position order
+        a, e = int(res.row_begin[s]), int(res.row_begin[s + 1])
+        assert (ri[a:e] == s).all()
+        np.testing.assert_array_equal(rj[a:e], np.arange(s + 1, P) if het[s] else np.nonzero(het[s + 1:])[0] + s + 1)
+    zero = np.nonzero(res.row_mi == 0.0)[0]
+    pick = np.concatenate([rng.choice(res.n_rows, 1500, replace=False), zero[:3000]])
+    planes = {}
+    n_zero_nondegen = 0
+    for r in pick:
+        a, b = int(ri[r]), int(rj[r])
+        for s_ in (a, b):
+            if s_ not in planes:
+                planes[s_] = site_class_planes(pb, s_)
+        tab = np.array([[popcount64(planes[a][x] & planes[b][y]).sum() for y in range(3)] for x in range(3)], np.uint32)
+        assert abs(mi_numpy(tab) - res.row_mi[r]) <= 1e-6
+        o = c_oracle.mi_from_table(tab)
+        assert (o == 0.0) == (res.row_mi[r] == 0.0) and abs(o - res.row_mi[r]) <= 1e-12, (int(r), o, res.row_mi[r])
+        n_zero_nondegen += int(res.row_mi[r] == 0.0 and (tab.sum(axis=1) > 0).sum() > 1 and (tab.sum(axis=0) > 0).sum() > 1)
+    assert res.row_mi.min() >= 0.0 and res.row_mi.max() <= np.log(3) + 1e-12
+    cnts = np.bincount(ri, minlength=P) + np.bincount(rj, minlength=P)
+    np.testing.assert_array_equal(cnts, res.site_n_pairs)
+
+
+@pytest.mark.parametrize('n_sites,n_reads,n_shuffles', [(10_000, 50_000, 1000), (50_000, 200_000, 1000)],
+                         ids=['cfg2_10kx50k_S1000', 'north_star_50kx200k_S1000'])
 def test_full_size_properties(engine, n_sites, n_reads, n_shuffles):
     import lgmi
     spec = lgmi.default_synth_spec(n_sites, n_reads, seed=20250808)

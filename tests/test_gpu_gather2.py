@@ -31,13 +31,20 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('world', [2, 3, 4])      # (a test box admits 6 processes on its card, the test runner being one: 4 leaves a margin; 8 ranks: tests/test_dist_gloo.py)
-def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world):
+# (a test box admits 6 processes on its card, the test runner being one: 4 leaves a margin; 8 ranks: tests/test_dist_gloo.py)
+# form: the compact gather (row_i never travels, row_j only from ranks that skipped a pair, 16-bit counts: the default
+# between shards of one batch) and the plain one (LGMI_GATHER_LEGACY=1: every array as it is)
+@pytest.mark.parametrize('world,form', [(2, 'compact'), (3, 'compact'), (4, 'compact'), (4, 'plain')])
+def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world, form):
     port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
                    LGMI_RDZV_PORT=str(port), LGMI_RCCL_LIB=fake_rccl, LGMI_ALLOW_RCCL_STANDIN='1')
+        env.pop('LGMI_GATHER_LEGACY', None)
+        if form == 'plain':
+            env['LGMI_GATHER_LEGACY'] = '1'
+        env['LGMI_TEST_GATHER_FORM'] = form
         env.pop('TORCHELASTIC_USE_AGENT_STORE', None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'helpers', 'gather2_worker.py')], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -58,7 +65,7 @@ def test_gather_between_ranks_sharing_one_gpu(fake_rccl, world):
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (rank, se[-3000:])
     line = json.loads(outs[0][0].strip().splitlines()[-1])
-    assert line['ok'] and line['world'] == world and len(line['checked']) == 5
+    assert line['ok'] and line['world'] == world and len(line['checked']) == 7
     assert line['comm_info']['stand_in'] is True and line['comm_info']['nranks'] == world
 
 

@@ -40,7 +40,7 @@ def test_stub_declares_the_structs_of_the_shipped_library():
                [(f[0], getattr(theirs, f[0]).offset, getattr(theirs, f[0]).size) for f in theirs._fields_], name
     lib = _lib.load()
     assert lib.lgmi_abi_version() == 6 and 'lgmi_abi_version() == 6' in stub_source()
-    assert [lib.lgmi_struct_size(k) for k in range(9)] == [88, 32, 144, 128, 48, 152, 8, 540, 0]
+    assert [lib.lgmi_struct_size(k) for k in range(9)] == [96, 32, 144, 128, 48, 152, 8, 540, 0]
 
 
 def test_struct_size_handshake_refuses_a_stale_declaration():
