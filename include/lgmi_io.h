@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGIO_ABI_VERSION 2
+#define LGIO_ABI_VERSION 3
 #define LGIO_OK        0
 #define LGIO_E_ARG    -1
 #define LGIO_E_IO     -2   /* open / read / seek failed                     */
@@ -160,6 +160,10 @@ typedef struct lgio_sites {
     const uint64_t* name_off;           /* [n_reads + 1] into names                                               */
     const char*     names;
     void* owner_;
+    /* ABI 3: read_uid[r] = the first read of the footprint with r's NAME (r itself for a name seen once).  The reference
+     * keys its read -> allele maps by name (mutual_information.py:15-16), so two records of one name are ONE read to it;
+     * a caller that packs the footprint from read ids (no name strings made) uses these instead of the names. */
+    const uint32_t* read_uid;           /* [n_reads]                                                              */
 } lgio_sites;
 
 int  lgio_bam_region_sites(lgio_bam* bam, int tid, int64_t start, int64_t end, const lgio_site_params* params,
@@ -178,6 +182,17 @@ typedef struct lgio_intervals {
 } lgio_intervals;
 int  lgio_bam_ref_intervals(lgio_bam* bam, int tid, int threads, lgio_intervals* out);
 void lgio_intervals_free(lgio_intervals* iv);
+
+/* ---- round 5 (ABI 3): the removed-site table, written natively.  One row per covered position of every footprint — 15
+ * million rows for 8,000 genes — as pandas' to_csv(sep='\t', index=False) writes them (src/giremi/script/giremi.py:403-409:
+ * chromosome, strand, pos, removed), from dictionary codes: row k = chrom_names[chrom_code[k]] TAB '+' or '-' (strand[k] 0
+ * / 1) TAB pos[k] TAB reason_names[reason_code[k]] NEWLINE.  header != 0 writes the column line first; append != 0 appends
+ * to the file.  The rows are formatted by `threads` threads into buffers written in order.  (Names must not hold a tab,
+ * a quote or a newline — pandas would quote them: such a table is refused, LGIO_E_ARG, and the caller takes pandas.) */
+int  lgio_write_removed_table(const char* path, int append, int header, uint64_t n, const int32_t* chrom_code,
+                              const int8_t* strand, const int64_t* pos, const int8_t* reason_code,
+                              const char* const* chrom_names, uint32_t n_chrom, const char* const* reason_names,
+                              uint32_t n_reasons, int threads);
 
 /* bytes of compressed file read so far through this handle (tests use it to show that a region query does not
  * read the whole file) */

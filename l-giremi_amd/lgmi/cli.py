@@ -97,6 +97,20 @@ class _RemovedWriter:
         _write_removed(df, self.path, header=(self.parts == 0), append=(self.parts > 0))
         self.parts += 1
 
+    def write_arrays(self, arrays):
+        """a chunk's removed sites as its extraction worker flattened them (lgmi.region._removed_arrays: names + codes):
+        formatted by liblgmi_io (lgio_write_removed_table) — no DataFrame, no categoricals; 15 M rows of an 8,000-gene run
+        were 1.3 s of the parent's time through pandas + pyarrow"""
+        from .io import write_removed_table
+        chroms, reasons, g_chrom, g_strand, g_pos, g_reason = arrays
+        try:
+            write_removed_table(self.path, chroms, reasons, g_chrom, g_strand, g_pos, g_reason, header=(self.parts == 0),
+                                append=(self.parts > 0))
+        except ValueError:                                  # a name pandas would quote: pandas writes it
+            from .region import _removed_frame_from_arrays
+            return self(_removed_frame_from_arrays(arrays, {}, {}))
+        self.parts += 1
+
     def close(self):
         if not self.parts:
             import pandas as pd

@@ -68,7 +68,7 @@ class _Sites(C.Structure):       # lgio_sites
                 ('ref', C.c_void_p), ('neighbor', _u32p), ('allele_off', _u64p), ('allele_nt', C.c_void_p),
                 ('reads_off', _u64p), ('reads', _u32p), ('n_removed', C.c_uint64 * 2), ('removed_pos', _i64p * 2),
                 ('removed_code', _u8p * 2), ('n_reads', C.c_uint64), ('name_off', _u64p), ('names', C.c_void_p),
-                ('owner_', C.c_void_p)]
+                ('owner_', C.c_void_p), ('read_uid', _u32p)]
 
 
 class _Intervals(C.Structure):   # lgio_intervals
@@ -97,7 +97,24 @@ IO_SYMBOLS = {
     'lgio_sites_free': (None, [C.POINTER(_Sites)]),
     'lgio_bam_ref_intervals': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(_Intervals)]),
     'lgio_intervals_free': (None, [C.POINTER(_Intervals)]),
+    'lgio_write_removed_table': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int8), _i64p,
+                                           C.POINTER(C.c_int8), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_int]),
 }
+
+
+def write_removed_table(path, chrom_names, reason_names, chrom_code, strand, pos, reason_code, header=True, append=False, threads=4):
+    """lgio_write_removed_table: the removed-site table of script/giremi.py:403-409 from dictionary codes, the bytes
+    pandas' to_csv(sep='\\t', index=False) writes.  Raises ValueError when a name would need quoting (the caller takes pandas)"""
+    lib = load_io()
+    cc = np.ascontiguousarray(chrom_code, np.int32)
+    st = np.ascontiguousarray(strand, np.int8)
+    ps = np.ascontiguousarray(pos, np.int64)
+    rc_ = np.ascontiguousarray(reason_code, np.int8)
+    cn = (C.c_char_p * max(len(chrom_names), 1))(*[str(c).encode() for c in chrom_names])
+    rn = (C.c_char_p * max(len(reason_names), 1))(*[str(r).encode() for r in reason_names])
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a.size else C.cast(None, C.POINTER(t))
+    _check(lib.lgio_write_removed_table(str(path).encode(), 1 if append else 0, 1 if header else 0, len(ps), p(cc, C.c_int32), p(st, C.c_int8),
+                                        p(ps, C.c_int64), p(rc_, C.c_int8), cn, len(chrom_names), rn, len(reason_names), int(threads)))
 _iolib = None
 
 
@@ -110,6 +127,8 @@ def load_io():
         for name, (res, args) in IO_SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.lgio_abi_version() != 3:
+            raise RuntimeError('liblgmi_io.so ABI %d != binding ABI 3 (rebuild with `make -C l-giremi_amd`)' % lib.lgio_abi_version())
         _iolib = lib
     return _iolib
 
@@ -340,7 +359,7 @@ class BamReader:
                     'reads': _arr(st.reads, int(roff[-1]) if na else 0, np.int64),
                     'removed': [(_arr(st.removed_pos[k], int(st.n_removed[k]), np.int64),
                                  _arr(st.removed_code[k], int(st.n_removed[k]), np.uint8)) for k in range(2)],
-                    'name_off': noff, 'names': _pool(st.names, int(noff[-1]) if nr else 0)}
+                    'name_off': noff, 'names': _pool(st.names, int(noff[-1]) if nr else 0), 'read_uid': _arr(st.read_uid, nr, np.int64)}
         finally:
             self._lib.lgio_sites_free(C.byref(st))
 

@@ -123,7 +123,8 @@ def _pack_one(mismatches: dict):
         return pos, type_names, bad, 0, z, z, np.zeros(0, np.uint64), z, np.zeros(P, np.uint8)
     # reads are numbered in order of first appearance (sites by position, alleles in `nt` order): what factorize does
     import pandas as pd
-    code, uniques = pd.factorize(np.asarray(names_flat, dtype=object))
+    # (read "names" may be integer read ids — lgmi.region's native extraction with read_ids: same identity, no strings)
+    code, uniques = pd.factorize(np.asarray(names_flat, np.int64) if isinstance(names_flat[0], int) else np.asarray(names_flat, dtype=object))
     R = len(uniques)
     site_of = np.repeat(np.asarray(run_site, np.int64), run_len)
     cls_of = np.repeat(np.asarray(run_cls, np.uint8), run_len)

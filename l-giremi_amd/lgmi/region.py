@@ -277,13 +277,15 @@ def region_sites_native(chromosome, start_pos, end_pos, sam, genome,
                         homopoly_length=5, simple_repeat_intervals=[], snp_positions=[],
                         read_strand_dict=None, min_het_snp_ratio=0.35, max_het_snp_ratio=0.65,
                         mismatch_window_size=100, max_window_mismatch=10,
-                        max_window_mismatch_type=3, mode='cs'):
+                        max_window_mismatch_type=3, mode='cs', read_ids=False):
     """``get_region_mismatches_with_filters`` with the BAM-only steps (1-6) in liblgmi_io (lgio_bam_region_sites) and
     the removed sites as arrays: -> (sites, (removed, reasons)) with ``sites`` what the Python routine returns as its
     first value (plain dicts per strand) and ``(removed, reasons)`` what ``_compact_gone`` makes of its second — or None
     when this footprint has to go through the Python routine (a caller-provided read_strand_dict, an alignment object
     without the native entry point, a cs string or a base the native walk does not cover).  tests/test_region_fast.py
-    holds the two against each other."""
+    holds the two against each other.  ``read_ids``: the allele read lists hold integer read ids (the index of the first
+    record of the read's NAME in the footprint, lgio_sites.read_uid) instead of name strings — what a caller that only
+    packs the footprint needs, without ~500 Python strings per site made and hashed (0.28 of 1.9 s per 200 footprints)."""
     from .io import SiteParams, REMOVED_REASONS
     if (mode != 'cs' or read_strand_dict is not None or not hasattr(sam, 'region_sites')
             or not _is_whole(min_dist_from_splice) or start_pos is None or end_pos is None or start_pos < 0
@@ -307,14 +309,16 @@ def region_sites_native(chromosome, start_pos, end_pos, sam, genome,
         return got
 
     sites = {'+': {}, '-': {}}
-    aoff, roff, reads = raw['allele_off'], raw['reads_off'], raw['reads'].tolist()
+    aoff, roff = raw['allele_off'], raw['reads_off']
+    reads = (raw['read_uid'][raw['reads']] if read_ids else raw['reads']).tolist()
     ref_b, nt_b = raw['ref'].decode(), raw['allele_nt'].decode()
     for k in range(len(raw['pos'])):
         strand = '-' if raw['strand'][k] else '+'
         site = _new_site()
         site['ref'] = ref_b[k]
         for a in range(int(aoff[k]), int(aoff[k + 1])):
-            site['nt'][nt_b[a]] = [name(i) for i in reads[int(roff[a]):int(roff[a + 1])]]
+            ids = reads[int(roff[a]):int(roff[a + 1])]
+            site['nt'][nt_b[a]] = ids if read_ids else [name(i) for i in ids]
         for t in np.flatnonzero(raw['neighbor'][k]).tolist():
             r, alt = _ACGT[t >> 2], _ACGT[t & 3]
             change = '%s>%s' % (r, alt) if strand == '+' else '%s>%s' % (_COMP4[r], _COMP4[alt])
@@ -373,7 +377,7 @@ def _extract_chunk(job, sam=None, genome=None):
                     snp_positions=fp.get('snp_positions', []), simple_repeat_intervals=fp.get('simple_repeat_intervals', []),
                     read_strand_dict=fp.get('read_strand_dict'), **filter_kwargs)
         # a whole run (compact): the BAM-only steps natively, when the footprint is one the native walk covers
-        fast = region_sites_native(**args) if compact and not os.environ.get('LGMI_PY_SITES') else None
+        fast = region_sites_native(read_ids=bool(pack and _STRIP_READS), **args) if compact and not os.environ.get('LGMI_PY_SITES') else None
         if fast is not None:
             out.append((fp['chromosome'],) + fast)
             continue
@@ -399,8 +403,45 @@ def _extract_chunk(job, sam=None, genome=None):
                 for strand in '+-':
                     for site in sites[strand].values():
                         site['nt'] = {a: len(v) for a, v in site['nt'].items()}     # (allele order kept; _site_rows reads depth)
-        return out, batch
+        # ... and builds what the parent would otherwise build footprint by footprint while the pool waits for it (round 5:
+        # with the extraction itself three times faster the parent's 0.8 s of site rows and 0.7 s of removed-site arrays per
+        # 8,000 footprints were the pipeline's longest leg): the rows of the mismatch table, their mean_mi still empty (the
+        # parent fills the column in from the GPU's per-site means), and the chunk's removed sites as four flat arrays
+        nothing = {'+': {}, '-': {}}
+        extras = {'site_rows': [_site_rows(chrom, sites, nothing) for chrom, sites, _gone in out],
+                  'removed': _removed_arrays(out) if compact else None}
+        return out, batch, extras
     return out
+
+
+def _removed_arrays(staged):
+    """the removed sites of a chunk of footprints as flat arrays with chunk-local codes:
+    -> (chromosome names, reason strings, chromosome code int32[n], strand int8[n], pos int64[n], reason code int8[n])"""
+    chroms, reasons = {}, {}
+    g_chrom, g_strand, g_pos, g_reason = [], [], [], []
+    for chrom, _sites, (gone, rs) in staged:
+        cc = chroms.setdefault(chrom, len(chroms))
+        remap = np.array([reasons.setdefault(r, len(reasons)) for r in rs], np.int8)
+        for k, strand in enumerate('+-'):
+            pos, codes = gone[strand]
+            if len(pos):
+                g_chrom.append(np.full(len(pos), cc, np.int32))
+                g_strand.append(np.full(len(pos), k, np.int8))
+                g_pos.append(pos)
+                g_reason.append(remap[codes])
+    cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+    return list(chroms), list(reasons), cat(g_chrom, np.int32), cat(g_strand, np.int8), cat(g_pos, np.int64), cat(g_reason, np.int8)
+
+
+def _removed_frame_from_arrays(arrays, chrom_code, reason_code):
+    """_removed_frame of a chunk whose worker already flattened it (_removed_arrays): the chunk's codes mapped onto the run's"""
+    chroms, reasons, g_chrom, g_strand, g_pos, g_reason = arrays
+    cmap = np.array([chrom_code.setdefault(c, len(chrom_code)) for c in chroms] or [0], np.int32)
+    rmap = np.array([reason_code.setdefault(r, len(reason_code)) for r in reasons] or [0], np.int8)
+    as_cat = lambda codes, names: pd.Categorical.from_codes(codes, categories=list(names))
+    return pd.DataFrame({'chromosome': as_cat(cmap[g_chrom], chrom_code), 'strand': as_cat(g_strand, '+-'),
+                         'pos': g_pos, 'removed': as_cat(rmap[g_reason], reason_code)},
+                        columns=['chromosome', 'strand', 'pos', 'removed'])
 
 
 def _removed_frame(staged, chrom_code, reason_code):
@@ -465,7 +506,8 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
                 t_gpu = t_tab = 0.0
                 site_base, site_rows, pair_frames, removed_frames = 0, [], [], []
                 chrom_code, reason_code = {}, {}
-                for part, b in parts:
+                nan = float('nan')
+                for part, b, extras in parts:
                     t1 = time.perf_counter()
                     kw = {'site_base': site_base} if site_base else {}
                     df_c, means_c = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in part], min_common_reads,
@@ -473,13 +515,20 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
                     site_base += len(b.site_pos) if b is not None else 0
                     pair_frames.append(df_c)
                     t2 = time.perf_counter()
-                    for (chrom, sites, _gone), mean_mi in zip(part, means_c):
-                        site_rows.extend(_site_rows(chrom, sites, mean_mi))
-                    gone_frame = _removed_frame(part, chrom_code if removed_sink is None else {}, reason_code if removed_sink is None else {})
-                    if removed_sink is not None:
-                        removed_sink(gone_frame)
+                    # the worker made the footprints' rows of the mismatch table; their last column is the GPU's per-site mean
+                    for rows, mean_mi in zip(extras['site_rows'], means_c):
+                        for row in rows:
+                            row[12] = mean_mi[row[2]].get(row[3], nan)
+                        site_rows.extend(rows)
+                    if removed_sink is not None and hasattr(removed_sink, 'write_arrays'):
+                        removed_sink.write_arrays(extras['removed'])          # (formatted natively: no frame is made)
                     else:
-                        removed_frames.append(gone_frame)
+                        gone_frame = _removed_frame_from_arrays(extras['removed'], chrom_code if removed_sink is None else {},
+                                                                reason_code if removed_sink is None else {})
+                        if removed_sink is not None:
+                            removed_sink(gone_frame)
+                        else:
+                            removed_frames.append(gone_frame)
                     t_gpu += t2 - t1
                     t_tab += time.perf_counter() - t2
                 if removed_sink is not None:
@@ -503,8 +552,8 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
             parts = pool.map(_extract_chunk, jobs)
         if concat:
             from .pack import concat_batches
-            staged = [x for part, _b in parts for x in part]
-            batches = [b for _part, b in parts if b is not None]
+            staged = [x for part, _b, _extras in parts for x in part]
+            batches = [b for _part, b, _extras in parts if b is not None]
             prepacked = concat_batches(batches) if batches else None
         else:
             staged = [x for part in parts for x in part]

@@ -343,3 +343,60 @@ def test_pileup_max_depth_default(tmp_path):
     assert len(cols[100]) == 8000 and len(cols[110]) == 8000 and cols[110] == ['r%04d' % k for k in range(8000)]
     assert len(cols[130]) == 5                                                   # only the five late starters reach 130
     assert len({c.pos: c for c in rd.pileup('c', 0, 1000, max_depth=9000)}[110].get_query_names()) == 8005
+
+
+def test_site_extraction_beyond_max_depth_takes_the_first_reads_of_a_column(tmp_path):
+    """lgio_bam_region_sites counts a read at a column only while the column holds fewer than max_depth reads (pysam's
+    `max_depth`; the fast, segment-wise form of its pile-up step is exact only below that and hands over to the base-by-base
+    form otherwise): with max_depth 5 the column of the site at 130 takes alt0..alt3 and ref0 — ref1 and ref2 come too late"""
+    from lgmi.io import SiteParams
+    w = BamWriter(str(tmp_path / 'm.bam'), [('c', 1000)])
+    for k in range(4):
+        w.write('c', 100, 'alt%d' % k, False, [(0, 50)], 'C' * 30 + 'T' + 'C' * 19, ':30*ct:19')
+    for k in range(3):
+        w.write('c', 105 + k, 'ref%d' % k, False, [(0, 50)], 'C' * 50, ':50')
+    w.close()
+    rd = BamReader(str(tmp_path / 'm.bam'))
+    got = {}
+    for depth in (5, 8000):
+        raw = rd.region_sites('c', 0, 1000, SiteParams(keep_non_spliced_read=1, min_base_quality=13, max_depth=depth, min_dist_from_splice=0,
+                                                       half_window=50, min_allele_depth=1, min_allele_ratio=0.0, min_total_depth=0,
+                                                       max_window_mismatch=10, max_window_mismatch_type=3))
+        assert raw['pos'].tolist() == [130]
+        alleles = raw['allele_nt'].decode()
+        noff, pool = raw['name_off'], raw['names']
+        got[depth] = {alleles[a]: [pool[noff[i]:noff[i + 1]].decode() for i in raw['reads'][raw['reads_off'][a]:raw['reads_off'][a + 1]].tolist()]
+                      for a in range(len(alleles))}
+    assert got[8000] == {'T': ['alt0', 'alt1', 'alt2', 'alt3'], 'C': ['ref0', 'ref1', 'ref2']}
+    assert got[5] == {'T': ['alt0', 'alt1', 'alt2', 'alt3'], 'C': ['ref0']}
+
+
+def test_native_removed_table_writer_equals_pandas(tmp_path):
+    """lgio_write_removed_table against what the CLI wrote before (pandas / pyarrow, lgmi.cli._write_removed): the same bytes —
+    header or not, appended parts, one thread or several, an empty part; names that would need quoting are refused"""
+    import pandas as pd
+    from lgmi.cli import _write_removed
+    from lgmi.io import write_removed_table
+    rng = np.random.default_rng(8)
+    chroms, reasons = ['chr1', 'chrX', 'scaffold_12.1'], ['too many window mismatches', 'too few usable reads after filters', 'in homopoly regions']
+    n = 300_000
+    cc, st = rng.integers(0, 3, n).astype(np.int32), rng.integers(0, 2, n).astype(np.int8)
+    ps, rc = rng.integers(0, 250_000_000, n).astype(np.int64), rng.integers(0, 3, n).astype(np.int8)
+    ps[:3] = [0, 9, 10]
+    df = pd.DataFrame({'chromosome': pd.Categorical.from_codes(cc, categories=chroms), 'strand': pd.Categorical.from_codes(st, categories=list('+-')),
+                       'pos': ps, 'removed': pd.Categorical.from_codes(rc, categories=reasons)})
+    a, b = str(tmp_path / 'a.txt'), str(tmp_path / 'b.txt')
+    _write_removed(df, a)
+    for threads in (1, 5):
+        write_removed_table(b, chroms, reasons, cc, st, ps, rc, threads=threads)
+        assert open(a, 'rb').read() == open(b, 'rb').read()
+    # in parts, the way the run writes it
+    cut = 123_457
+    write_removed_table(b, chroms, reasons, cc[:cut], st[:cut], ps[:cut], rc[:cut], header=True, append=False)
+    write_removed_table(b, chroms, reasons, cc[:0], st[:0], ps[:0], rc[:0], header=False, append=True)
+    write_removed_table(b, chroms[::-1], reasons, 2 - cc[cut:], st[cut:], ps[cut:], rc[cut:], header=False, append=True)   # (a part's own name order)
+    assert open(a, 'rb').read() == open(b, 'rb').read()
+    with pytest.raises(ValueError):
+        write_removed_table(b, ['chr\t1'], reasons, cc[:5] * 0, st[:5], ps[:5], rc[:5])
+    with pytest.raises(ValueError):
+        write_removed_table(b, chroms, reasons, cc[:5] + 7, st[:5], ps[:5], rc[:5])

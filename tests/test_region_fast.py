@@ -122,6 +122,33 @@ def test_native_extraction_quirks(tmp_path):
     assert 'dup' in sites['+'][30]['nt']['G'] and 'dup' not in sites['-'][30]['nt'].get('G', [])
 
 
+def test_packing_from_read_ids_equals_packing_from_names(tmp_path):
+    """the run's pipeline packs a footprint from integer read ids (lgio_sites.read_uid: the first record of the read's
+    NAME) instead of name strings: the packed block — read numbering by first appearance, last-allele-wins for a read
+    listed twice, bit planes — must be the one the names give, also when a name occurs on two records"""
+    from lgmi.pack import pack_blocks
+    from lgmi.region import region_sites_native
+    recs = []
+    for k in range(14):
+        recs.append(_spliced(0, 'r%02d' % k, False, 30, alt='g' if k < 9 else 'c'))
+    for k in range(6):
+        recs.append((0, 'm%02d' % k, False, [(0, 60), (3, 100), (0, 60)], 'A' * 120, ':60~gt100ag:60', 0, 40))
+    for k in range(8):                                              # a second site at 45, overlapping read sets
+        recs.append(_spliced(2, 's%02d' % k, False, 43, alt='t'))
+    # one NAME on two records (a supplementary alignment): one read to the reference — listed under both alleles of site 30
+    recs.append(_spliced(0, 'twice', False, 30, alt='g'))
+    recs.append((0, 'twice', False, [(0, 60), (3, 100), (0, 60)], 'A' * 120, ':60~gt100ag:60', 2048, 40))
+    sam, genome = _write_records(tmp_path, recs)
+    kw = dict(chromosome='c', start_pos=0, end_pos=400, sam=sam, genome=genome, min_total_depth=2, min_allele_depth=1, min_allele_ratio=0.0)
+    by_name, _ = region_sites_native(**kw)
+    by_id, _ = region_sites_native(read_ids=True, **kw)
+    assert list(by_name['+']) == list(by_id['+']) and len(by_name['+']) >= 2
+    assert any('twice' in names for site in by_name['+'].values() for names in site['nt'].values())
+    a, b = pack_blocks([by_name['+'], by_name['-']]), pack_blocks([by_id['+'], by_id['-']])
+    for f in ('block_site_begin', 'block_n_reads', 'site_pos', 'site_type', 'site_word_off', 'site_n_words', 'site_plane_off', 'planes', 'site_tri'):
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
+
+
 @pytest.mark.parametrize('cs', [None, ':30*an:29~gt100ag:60', ':30*na:29~gt100ag:60', '=AAAA*ag=AAAA', ':30*ag:29~gt100:60', ':60~100:60',
                                 ':3x', '*agt:4'])
 def test_native_extraction_leaves_the_rest_to_python(tmp_path, cs):
