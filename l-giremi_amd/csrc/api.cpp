@@ -581,7 +581,10 @@ struct UploadPipe {
 // is the batch one the pipelined upload takes?  (flags given, planes packed in site order, enough of them to matter)
 static bool pipe_eligible(const lgmi_batch* b) {
     if (!b || !b->site_tri || b->n_sites < 64 || getenv("LGMI_NO_UPLOAD_PIPE")) return false;
-    uint64_t min_words = 8ull << 20;                                   // 64 MB of planes
+    // from 512 MB of planes on (their copy takes ~10 ms): below that the pieces' fixed costs — eight copies, prep launches and
+    // count launches instead of one each, the plan's tiles put in piece order — cost more than the copy they hide (20,000
+    // footprint blocks, 150 MB: 29 against 21 ms per call; a 10k x 50k chromosome, 125 MB: 11.9 against 11.3)
+    uint64_t min_words = 64ull << 20;
     if (const char* e = getenv("LGMI_UPLOAD_PIPE_MIN_WORDS")) min_words = strtoull(e, nullptr, 10);
     if (b->n_plane_words < min_words) return false;
     uint64_t off = 0;
