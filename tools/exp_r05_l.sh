@@ -1,0 +1,4 @@
+set -u
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu --durations=6 > gpurun_out/t_gpu_all.log 2>&1; echo rc=$?; grep -v "^  File\|Extension modules" gpurun_out/t_gpu_all.log | tail -14 | cut -c1-200
+bash tools/profile_round.sh r05 > gpurun_out/profile_round_r05.log 2>&1; echo profile rc=$?
+bash tools/bench_all.sh r05 2>&1 | tail -10

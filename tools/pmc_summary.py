@@ -50,7 +50,11 @@ def counters(d):
 
 
 def short(name):
-    return name.split('(')[0].replace('void ', '').replace('lgmi::', '').strip()
+    s = name.split('(')[0].replace('void ', '').replace('lgmi::', '').strip()
+    # k_emit<2, true> / k_emit<2, false> (round 5: one kernel per row layout) keep round 4's key
+    if s.startswith('k_emit<'):
+        s = s.split(',')[0].rstrip('>') + '>'
+    return s
 
 
 def main():
