@@ -234,11 +234,15 @@ struct PlanCache {
     BlockPlan* d_plans = nullptr; uint32_t* d_xlist = nullptr; uint32_t* d_ylist = nullptr; SiteMap* d_smap = nullptr;
     Tile* d_tiles = nullptr; Tile* d_mtiles = nullptr; uint2* d_items = nullptr; uint2* d_units = nullptr;
     OpGroup* d_opgroups = nullptr; uint32_t* d_xrows = nullptr;
+    // the FP4 kernel's operands in wave-load order (k_gather_ops): a function of the resident batch and this plan, like
+    // the plan itself — kept with it (round 5) instead of being re-laid by every run: 1.6 ms of a 206-ms north-star step,
+    // 1.2 of a 34-ms shard.  (The pool is grow-only: as scratch the same bytes stayed allocated between runs anyway.)
+    uint4* d_ops = nullptr; bool ops_ready = false;
     void release(Pool& p) {
         p.release(d_plans); p.release(d_xlist); p.release(d_ylist); p.release(d_smap); p.release(d_tiles);
-        p.release(d_mtiles); p.release(d_items); p.release(d_units); p.release(d_opgroups); p.release(d_xrows);
+        p.release(d_mtiles); p.release(d_items); p.release(d_units); p.release(d_opgroups); p.release(d_xrows); p.release(d_ops);
         d_plans = nullptr; d_xlist = d_ylist = nullptr; d_smap = nullptr; d_tiles = d_mtiles = nullptr;
-        d_items = d_units = nullptr; d_opgroups = nullptr; d_xrows = nullptr; on_device = false;
+        d_items = d_units = nullptr; d_opgroups = nullptr; d_xrows = nullptr; d_ops = nullptr; on_device = false; ops_ready = false;
     }
 };
 
@@ -1166,7 +1170,15 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     std::vector<void*> scratch;
     struct Guard {
         Pool& p; std::vector<void*>& s; lgmi_dresult* r;
-        ~Guard() { for (void* q : s) p.release(q); if (r) lgmi_dresult_free(r); }
+        PlanCache* transient_ops = nullptr; hipStream_t st = nullptr;      // a sequential shard's operand layout is used once: not kept
+        ~Guard() {
+            for (void* q : s) p.release(q);
+            if (transient_ops && transient_ops->d_ops) {
+                (void)hipStreamSynchronize(st);
+                p.release(transient_ops->d_ops); transient_ops->d_ops = nullptr; transient_ops->ops_ready = false;
+            }
+            if (r) lgmi_dresult_free(r);
+        }
     } guard{pool, scratch, res};
     auto salloc = [&](void** p, size_t bytes) { int e = pool.alloc(p, bytes); if (!e) scratch.push_back(*p); return e; };
 
@@ -1192,8 +1204,15 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
     SiteMap* const d_smap = pcache->d_smap; Tile* const d_tiles = pcache->d_tiles; Tile* const d_mtiles = pcache->d_mtiles;
     uint2* const d_items = pcache->d_items; uint2* const d_units = pcache->d_units;
     if ((rc = salloc((void**)&d_slots, pl.total_slots * sizeof(uint4)))) return rc;
-    uint4* d_ops = nullptr; OpGroup* const d_opgroups = pcache->d_opgroups;
-    if ((rc = salloc((void**)&d_ops, std::max<uint64_t>(pl.op_total, 1) * sizeof(uint4)))) return rc;
+    OpGroup* const d_opgroups = pcache->d_opgroups;
+    static const bool keep_ops = getenv("LGMI_NO_OPS_CACHE") == nullptr;
+    if (!pcache->d_ops) {
+        pcache->ops_ready = false;
+        if ((rc = pool.alloc((void**)&pcache->d_ops, std::max<uint64_t>(pl.op_total, 1) * sizeof(uint4)))) return rc;
+    }
+    uint4* const d_ops = pcache->d_ops;
+    if (cap_hint) { guard.transient_ops = pcache; guard.st = st; }     // (cap_hint: one of a run's sequential shards, api.cpp: run_device_split)
+    const bool lay_ops = !(keep_ops && pcache->ops_ready);          // (LGMI_NO_OPS_CACHE: re-lay them every run, as up to round 4)
     if ((rc = salloc((void**)&d_rowcnt, std::max<size_t>(n_items, 1) * 4))) return rc;
     if ((rc = salloc((void**)&d_rowstart, (n_items + 1) * 8))) return rc;
     if ((rc = pool.alloc((void**)&res->d_sum, std::max<size_t>(ns, 1) * 8))) return rc;
@@ -1251,9 +1270,11 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
 
     // FP4 matrix-core blocks: operands re-laid in wave-load order (part of "prep": ~2 ms at north-star)
     if (!pipe) {
-        if (pl.mfma_fp4 && !pl.mtiles.empty())
+        if (pl.mfma_fp4 && !pl.mtiles.empty() && lay_ops) {
             launch_gather_ops(st, (uint32_t)pl.op_groups.size(), pl.op_max_steps, d_opgroups, d_plans, d_xlist, d_ylist,
                               db->d.d_cols, db->d.d_cplanes, d_ops);
+            pcache->ops_ready = true;                            // (queued on the batch's one stream: every later run is behind it)
+        }
         HIPCHK(hipEventRecord(ctx->ev[1], st));
         if (pl.mfma_fp4)
             launch_count_mfma_fp4(st, (uint32_t)pl.mtiles.size(), d_mtiles, d_plans, d_ops, d_slots);
@@ -1273,7 +1294,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
             HIPCHK(hipStreamWaitEvent(st, up, 0));
             const uint32_t og0 = pipe->og_begin[k], og1 = pipe->og_begin[k + 1], mt0 = pipe->mt_begin[k], mt1 = pipe->mt_begin[k + 1],
                            t0 = pipe->t_begin[k], t1 = pipe->t_begin[k + 1];
-            if (pl.mfma_fp4 && og1 > og0)
+            if (pl.mfma_fp4 && og1 > og0)                      // (a pipelined run is the batch's first: nothing laid out yet)
                 launch_gather_ops(st, og1 - og0, pl.op_max_steps, d_opgroups + og0, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes, d_ops);
             if (pl.mfma_fp4) launch_count_mfma_fp4(st, mt1 - mt0, d_mtiles + mt0, d_plans, d_ops, d_slots);
             else launch_count_mfma(st, mt1 - mt0, d_mtiles + mt0, d_plans, d_xlist, d_ylist, db->d.d_cols, db->d.d_cplanes,
@@ -1283,6 +1304,7 @@ static int run_device_impl(lgmi_ctx* ctx, const lgmi_dbatch* db, const lgmi_para
             if (tr.on && ctx->event(lgmi_ctx::EV_UPDBG + k)) HIPCHK(hipEventRecord(ctx->event(lgmi_ctx::EV_UPDBG + k), st));
             tr.mark("piece");
         }
+        if (pl.mfma_fp4 && !pl.mtiles.empty()) pcache->ops_ready = true;
         if (tr.on) {                                         // when each piece's planes were up / its tiles counted, on the device's clock
             HIPCHK(hipStreamSynchronize(st));
             for (uint32_t k = 0; k < pipe->K; ++k) {
