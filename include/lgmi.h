@@ -320,8 +320,13 @@ int  lgmi_ecdf(lgmi_ctx* ctx, uint64_t n_ref, const double* ref, uint64_t n_quer
  * one of the shard's count tiles.  A work item is (site i, segment g): the partners number
  * [g * LGMI_EMIT_SEG, (g+1) * LGMI_EMIT_SEG) of site i's row, rows being in reference order.  Rows of x sites (every
  * site, or the het_snp sites when het_only) are cut into such segments; the row of any other site (its partners are
- * the later x sites) is one item, segment 0. */
+ * the later x sites) into segments of LGMI_EMIT_SEG_Q partners. */
 #define LGMI_EMIT_SEG 8192u
+/* ... and the row of any other site (its partners: the later x sites, in x-rank order) into segments of
+ * LGMI_EMIT_SEG_Q partners (round 5; one item per such site until then): the kernels reach those slots by a walk
+ * down a column of the slot matrix, a chain of dependent look-ups per 16 partners — a walk of 10,000 partners was the
+ * longest thing a shard of a multi-GPU run waited for */
+#define LGMI_EMIT_SEG_Q 1024u
 typedef struct lgmi_shard_plan {
     uint64_t n_items_total;      /* work items of the whole batch                                  */
     uint64_t item_begin;         /* this shard's items are [item_begin, item_end)                  */

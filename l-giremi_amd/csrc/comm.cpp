@@ -567,8 +567,12 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
             const uint32_t* nf = h->gnfirst_all + (size_t)r * ns;
             if (c) {
                 launch_scan(st, nf, d_off, ns, d_tmp);
+                // the rank's first work item may start inside its first site's row: segment g of an x site starts at partner
+                // g * LGMI_EMIT_SEG, of another site at g * LGMI_EMIT_SEG_Q
+                const uint32_t fs = (uint32_t)h->M(r, M_FSITE);
+                const uint32_t c0 = (uint32_t)h->M(r, M_FSEG) * ((fs < ns && isx[fs]) ? LGMI_EMIT_SEG : LGMI_EMIT_SEG_Q);
                 hipLaunchKernelGGL(k_expand_rows, dim3((ns + 3u) / 4u), dim3(256), 0, st, ns, nf, d_off, roff, h->M(r, M_ALL) ? 1 : 0,
-                                   (uint32_t)h->M(r, M_FSITE), (uint32_t)h->M(r, M_FSEG) * LGMI_EMIT_SEG, d_isx, d_cand0, d_xs, h->gi, h->gj);
+                                   fs, c0, d_isx, d_cand0, d_xs, h->gi, h->gj);
                 if (h->narrow && r != root)
                     hipLaunchKernelGGL(k_widen_u16, dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, c, h->g16 + roff, h->gexc + roff);
             }

@@ -139,7 +139,8 @@ struct EmitArgs {
     uint32_t n_items;
     const uint2* items;       // [n_items] (site, segment)
     uint32_t n_units;         // one wave per unit: an x site's item, or up to four other sites sharing a line of slots
-    const uint2* units;       // [n_units] (first item, n items | kind << 16); kind 1 = quad
+    const uint2* units;       // [n_units] (first item, n items | kind << 16 | stride << 20); kind 1 = quad: segment g of up to four
+                              //           sites whose items lie `stride` apart (each site's segments are consecutive items)
     uint32_t* row_cnt;        // [n_items]   pass 1 out
     const uint64_t* row_start;// [n_items+1] pass 2 in
     uint32_t* out_i; uint32_t* out_j; double* out_mi; uint32_t* out_counts; // pass 2 out
@@ -154,6 +155,7 @@ struct EmitArgs {
     unsigned long long* unit_words;  // [n_units] pass 1: per unit, the sum over its examined pairs of overlapping words
 };
 static const uint32_t EMIT_SEG = LGMI_EMIT_SEG;   // multiple of 64
+static const uint32_t EMIT_SEG_Q = LGMI_EMIT_SEG_Q;   // multiple of 16 (a quad trip covers 16 x ranks)
 void launch_emit_count(hipStream_t st, const EmitArgs& a);
 size_t scan_tmp_words(uint32_t n);
 void launch_scan(hipStream_t st, const uint32_t* cnt, uint64_t* start, uint32_t n, uint64_t* tmp);

@@ -114,7 +114,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                 const bool is_x = !het_only || in.type[s] == LGMI_TYPE_HET_SNP;
                 if (is_x) ++xseen;
                 const uint32_t ncand = is_x ? (se - 1 - s) : (nxs - xseen);
-                if (is_x) n_it += ((uint64_t)ncand + EMIT_SEG - 1) / EMIT_SEG; else n_it += ncand ? 1u : 0u;
+                n_it += ((uint64_t)ncand + (is_x ? EMIT_SEG : EMIT_SEG_Q) - 1) / (is_x ? EMIT_SEG : EMIT_SEG_Q);
             }
             blk_items[b + 1] = n_it;
             pl.plans[b] = bp;
@@ -194,11 +194,11 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                 const uint32_t ncand = is_x ? (se - 1 - s) : (nxs - pl.smap[s].xnext);
                 examined += ncand;
                 // an x site's row is cut into segments of EMIT_SEG partners; another site's row (at most nxs partners: a
-                // column walk of the slot matrix, done four sites at a time, emit.hip: emit_quad) is one item
-                const uint32_t seg_len = is_x ? EMIT_SEG : 0xFFFFFFFFu;
+                // column walk of the slot matrix, done four sites at a time, emit.hip: emit_quad) into segments of EMIT_SEG_Q
+                const uint32_t seg_len = is_x ? EMIT_SEG : EMIT_SEG_Q;
                 for (uint32_t g = 0; (uint64_t)g * seg_len < ncand; ++g) {
                     pl.items[it] = make_uint2(s, g);
-                    const uint32_t q_a = is_x ? g * EMIT_SEG : 0u;
+                    const uint32_t q_a = g * seg_len;
                     const uint32_t n_in_seg = std::min<uint32_t>(seg_len, ncand - q_a);
                     item_ncand[it] = n_in_seg;
                     if (sharded) {
@@ -206,7 +206,7 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                         if (n_shuffles) {
                             if (in.tri[s]) n_general = n_in_seg;
                             else if (is_x) n_general = tri_pre[s + 1 + q_a + n_in_seg - sb] - tri_pre[s + 1 + q_a - sb];
-                            else n_general = trix_pre[nxs] - trix_pre[pl.smap[s].xnext];
+                            else n_general = trix_pre[pl.smap[s].xnext + q_a + n_in_seg] - trix_pre[pl.smap[s].xnext + q_a];
                         }
                         item_cost[it] = (uint64_t)n_in_seg * pair_cost + n_general * std::min<uint64_t>((uint64_t)n_shuffles * COST_DRAW, COST_SIX);
                         if (!is_x && nxs) item_cost[it] += (uint64_t)n_in_seg * walk_cost * ncand / nxs;
@@ -247,17 +247,27 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
         {
             const uint64_t a = std::max(blk_items[b0], pl.item_begin), e = std::min(blk_items[b1], pl.item_end);
             std::vector<uint2>& u = part_units[t];
-            for (uint64_t k = a; k < e;) {
-                const SiteMap& m = pl.smap[pl.items[k].x];
-                if (m.xrow != NONE) { u.push_back(make_uint2((uint32_t)(k - pl.item_begin), 1u)); ++k; continue; }
+            std::vector<uint8_t> taken((size_t)(e > a ? e - a : 0), 0);     // items a quad of an earlier site took along
+            for (uint64_t k = a; k < e; ++k) {
+                if (taken[(size_t)(k - a)]) continue;
+                const uint32_t s0 = pl.items[k].x, g = pl.items[k].y;
+                const SiteMap& m = pl.smap[s0];
+                if (m.xrow != NONE) { u.push_back(make_uint2((uint32_t)(k - pl.item_begin), 1u)); continue; }
+                // segment g of site s0 and of the up to three sites behind it in the same aligned group of four columns
+                // that have the same partners (the same later x sites, so the same number of segments G): their items lie
+                // G apart in the list (a site's segments are consecutive items)
+                const BlockPlan& bp = pl.plans[m.block];
+                const uint32_t G = (bp.nxs - m.xnext + EMIT_SEG_Q - 1u) / EMIT_SEG_Q;
                 uint32_t n = 1;
-                while (n < 4u && k + n < e) {
-                    const SiteMap& m2 = pl.smap[pl.items[k + n].x];
-                    if (m2.xrow != NONE || m2.block != m.block || (m2.ycol >> 2) != (m.ycol >> 2) || m2.ycol != m.ycol + n) break;
+                while (n < 4u && G < 4096u && k + (uint64_t)n * G < e) {
+                    const uint2 it2 = pl.items[k + (uint64_t)n * G];
+                    const SiteMap& m2 = pl.smap[it2.x];
+                    if (it2.x != s0 + n || it2.y != g || m2.xrow != NONE || m2.block != m.block || m2.xnext != m.xnext ||
+                        (m2.ycol >> 2) != (m.ycol >> 2) || m2.ycol != m.ycol + n) break;
                     ++n;
                 }
-                u.push_back(make_uint2((uint32_t)(k - pl.item_begin), n | (1u << 16)));
-                k += n;
+                for (uint32_t j = 1; j < n; ++j) taken[(size_t)(k + (uint64_t)j * G - a)] = 1;
+                u.push_back(make_uint2((uint32_t)(k - pl.item_begin), n | (1u << 16) | ((n > 1u ? G : 0u) << 20)));
             }
         }
     }
@@ -319,14 +329,13 @@ void build_plan(const PlanInput& in, bool het_only, uint32_t shard_rank, uint32_
                         if (mi.prow != NONE) need.mark(mi.prow, mi.prow + 1u, c0[part], c1[part]);
                     }
                 } else {
-                    (void)g;                                     // (always 0: one item per such site)
-                    // its partners are the x sites of rank xnext and later: their rows and pseudo rows
-                    if (interleave) {                            // every row from the first of them on
-                        const uint32_t ra = mi.xnext < nxs ? pl.smap[yl_x[mi.xnext]].xrow : bp.nx, rb = bp.nx;
+                    // its partners in this segment: the x sites of ranks [xa, xb); their rows and pseudo rows
+                    const uint32_t xa = std::min(nxs, mi.xnext + g * EMIT_SEG_Q), xb = std::min(nxs, xa + EMIT_SEG_Q);
+                    if (interleave) {                            // every row from the first of them to the row before the next rank's
+                        const uint32_t ra = xa < nxs ? pl.smap[yl_x[xa]].xrow : bp.nx, rb = xb < nxs ? pl.smap[yl_x[xb]].xrow : bp.nx;
                         need.mark(ra, rb, mi.ycol, mi.ycol + 1u);
                         if (mi.pcol != NONE) need.mark(ra, rb, mi.pcol, mi.pcol + 1u);
-                    } else {                                     // real rows [xa, nxs), and the pseudo rows behind them of the tri ones
-                        const uint32_t xa = mi.xnext, xb = nxs;
+                    } else {                                     // real rows [xa, xb), and the pseudo rows behind the last x site of the tri ones
                         const uint32_t pa = nxs + trix_before[xa], pb = nxs + trix_before[xb];
                         need.mark(xa, xb, mi.ycol, mi.ycol + 1u);
                         need.mark(pa, pb, mi.ycol, mi.ycol + 1u);

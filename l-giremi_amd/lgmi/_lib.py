@@ -14,6 +14,7 @@ OK, E_ARG, E_OOM, E_HIP, E_RCCL, E_NODEV, E_STATE, E_DOMAIN = 0, -1, -2, -3, -4,
 TYPE_MISMATCH, TYPE_SNP, TYPE_HET_SNP = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 EMIT_SEG = 8192
+EMIT_SEG_Q = 1024
 EXCEED_EXACT = 0xFFFFFFFF
 NONE = 0xFFFFFFFF
 

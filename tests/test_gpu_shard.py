@@ -71,6 +71,35 @@ def test_shards_of_one_dense_block_on_the_matrix_cores(engine):
     db.free()
 
 
+def test_column_walk_rows_in_several_segments_and_shards(engine):
+    """a site that is not an x site has its row — the later x sites, reached by a walk down a column of the slot matrix —
+    cut into segments of LGMI_EMIT_SEG_Q = 1024 partners (round 5): 2,600 sites of which every second is a het SNP give
+    the early sites two segments; whole run against the C oracle, then 3 and 7 shards (cuts inside a site's segments,
+    quads whose members fall into different shards) against the whole, compact gather form included"""
+    import lgmi
+    from oracle import c_oracle
+    spec = lgmi.default_synth_spec(2600, 3000, seed=41)
+    spec.het_every = 2
+    spec.tri_per_1024 = 60
+    db = engine.synth_dense(spec)
+    pb = db.download()
+    kw = dict(min_common=6, het_only=True, n_shuffles=20, seed=3, emit_counts=True)
+    dr = engine.run_device(db, **kw)
+    whole = dr.fetch()
+    dr.free()
+    ora = c_oracle.run(pb, min_common=6, het_only=True, n_shuffles=20, seed=3)
+    np.testing.assert_array_equal(whole.row_i, ora['row_i'])
+    np.testing.assert_array_equal(whole.row_j, ora['row_j'])
+    np.testing.assert_array_equal(whole.row_counts, ora['row_counts'])
+    np.testing.assert_array_equal(whole.row_exceed, ora['row_exceed'])
+    plan = lgmi.plan_shard(pb, True, (0, 1))
+    assert plan['item_seg'][plan['site_xrow'][plan['item_site']] == lgmi._lib.NONE].max() >= 1     # a column-walk row in two segments
+    for world in (3, 7):
+        parts = run_shards(engine, db, world, **kw)
+        assert_shards_equal_whole(whole, parts, True)
+    db.free()
+
+
 def test_shard_arguments_are_checked(engine):
     import lgmi
     pb = random_batch(1, n_blocks=1)

@@ -9,7 +9,7 @@ from oracle import c_oracle
 from util_synth import pack_class_matrix, random_batch, random_block
 
 import lgmi
-from lgmi._lib import EMIT_SEG, NONE, LgmiError
+from lgmi._lib import EMIT_SEG, EMIT_SEG_Q, NONE, LgmiError
 
 
 def item_of_rows(pb, plan, row_i, row_j):
@@ -19,7 +19,7 @@ def item_of_rows(pb, plan, row_i, row_j):
     i_is_x = xrow[i] != NONE
     q = np.where(i_is_x, j - i - 1, xnext[j] - 1 - xnext[i])              # (x rank of j = xnext[j] - 1; rows hold pseudo rows in between)
     assert (q >= 0).all()
-    seg = np.where(i_is_x, q // EMIT_SEG, 0)            # only x-site rows are cut into segments
+    seg = np.where(i_is_x, q // EMIT_SEG, q // EMIT_SEG_Q)       # (other sites' rows: segments of EMIT_SEG_Q partners, round 5)
     key = {(int(s), int(g)): k for k, (s, g) in enumerate(zip(plan['item_site'], plan['item_seg']))}
     return np.array([key[(int(a), int(b))] for a, b in zip(i, seg)], np.int64)
 
