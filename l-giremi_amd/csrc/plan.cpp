@@ -48,7 +48,9 @@ static const uint64_t COST_PAIR = 2000, COST_PAIR_NO_P = 500, COST_DRAW = 180, C
 // other: k_emit<2> 3.56 -> 1.69 ms and k_gather_ops 1.62 -> 0.55 ms from the first shard to the last, for the same number
 // of rows.  COST_WALK x (the walk's share of the x list) is added per such row (fitted to that profile), scaled down
 // for blocks whose slot matrix is smaller than 4 GB.
-static const uint64_t COST_WALK = 2000;
+static const uint64_t COST_WALK_DEFAULT = 2000;
+static uint64_t cost_walk() { static const uint64_t v = [] { const char* e = getenv("LGMI_COST_WALK"); return e ? (uint64_t)atoll(e) : COST_WALK_DEFAULT; }(); return v; }
+#define COST_WALK cost_walk()
 
 // Blocks are independent of one another, so every per-block phase runs on several threads over contiguous block ranges
 // (what a thread produces is laid down at offsets from a prefix over the blocks, or concatenated in thread = block order:
