@@ -1205,6 +1205,133 @@ extern "C" void lgio_intervals_free(lgio_intervals* iv) {
     memset(iv, 0, sizeof *iv);
 }
 
+// Round 5: the scan in SEGMENTS that start at record boundaries the index already names.  The serial part of the windowed
+// scan below — walking record to record over blocks other threads inflated, one cold cache line per record — had become
+// its floor once libdeflate took the inflation below it (4 M reads: 1.03 s whatever the thread count).  The BAI's linear
+// index holds, per 16-kb window of the reference, the virtual offset of the first read overlapping it: each is a RECORD
+// START, so the stretch of the file between two consecutive ones can be inflated AND walked by one thread, start to end,
+// with nothing to wait for (the blocks are walked while they are in the cache of the core that inflated them).
+// -> 0 ok, 1 not applicable (no anchors: the caller takes the windowed scan), negative error
+static int ref_intervals_segments(lgio_bam* b, int tid, int threads, int fd, uint64_t first_voff, IntervalsOwner* o) {
+    std::vector<uint64_t> anchors;
+    for (uint64_t v : b->index[tid].linear) if (v > first_voff) anchors.push_back(v);
+    std::sort(anchors.begin(), anchors.end());
+    anchors.erase(std::unique(anchors.begin(), anchors.end()), anchors.end());
+    anchors.insert(anchors.begin(), first_voff);
+    if (anchors.size() < 2) return 1;
+    const size_t n_seg = anchors.size();
+    struct Seg { std::vector<int64_t> start, end; uint64_t bytes = 0; bool saw_other = false; };
+    std::vector<Seg> segs(n_seg);
+    std::atomic<size_t> take{0};
+    std::atomic<size_t> stop_at{n_seg};          // the first segment in which another reference's record turned up: later ones hold none of ours
+    std::atomic<int> err{0};
+    std::mutex mu;
+    std::string why;
+    auto bad = [&](int code, const std::string& msg) { std::lock_guard<std::mutex> g(mu); if (!err.load()) { err = code; why = msg; } };
+    auto work = [&] {
+        std::vector<uint8_t> comp, data, rec;
+        std::string msg;
+        for (;;) {
+            const size_t k = take.fetch_add(1);
+            if (k >= n_seg || k > stop_at.load() || err.load()) return;
+            Seg& sg = segs[k];
+            const uint64_t v_end = k + 1 < n_seg ? anchors[k + 1] : ~0ull;
+            uint64_t addr = anchors[k] >> 16, next = 0;
+            size_t upos = (size_t)(anchors[k] & 0xFFFF);
+            bool have = false, eof = false;
+            // the next n bytes of the stream into dst (dst == NULL: skipped); false at the end of the file
+            auto load = [&]() -> int {
+                BlockRef br;
+                const int rc = block_ref(fd, addr, br, next);
+                if (rc == 1) { eof = true; return 1; }
+                if (rc) { bad(rc, lgio_last_error()); return rc; }
+                const int ri = inflate_block(fd, br, comp, data, msg);
+                if (ri) { bad(ri, msg); return ri; }
+                sg.bytes += br.head + br.clen + 8;
+                have = true;
+                return 0;
+            };
+            auto take_bytes = [&](uint8_t* dst, size_t n) -> int {       // 0 ok, 1 clean end before the first byte, 2 end inside, negative error
+                size_t done = 0;
+                while (done < n) {
+                    if (!have || upos >= data.size()) {
+                        if (have) { addr = next; upos = 0; }
+                        const int rc = load();
+                        if (rc == 1) return done ? 2 : 1;
+                        if (rc) return rc;
+                        if (upos > data.size()) { bad(LGIO_E_FORMAT, "virtual offset beyond its block"); return LGIO_E_FORMAT; }
+                        continue;
+                    }
+                    const size_t t = std::min(n - done, data.size() - upos);
+                    if (dst) memcpy(dst + done, data.data() + upos, t);
+                    upos += t; done += t;
+                }
+                return 0;
+            };
+            for (;;) {
+                // where the next record starts (a position at the end of a block belongs to the following block)
+                const uint64_t here = !have ? anchors[k] : (upos >= data.size() ? next << 16 : (addr << 16) | upos);
+                if (here >= v_end) break;
+                uint8_t head[36];
+                int rc = take_bytes(head, 4);
+                if (rc == 1) break;                                  // the file ends here
+                if (rc) { if (rc == 2) bad(LGIO_E_FORMAT, "file ends inside a record"); return; }
+                const uint32_t bs = le32(head);
+                if (bs < 32 || bs > (1u << 29)) { bad(LGIO_E_FORMAT, "implausible BAM record size"); return; }
+                rc = take_bytes(head + 4, 32);
+                if (rc) { if (rc > 0) bad(LGIO_E_FORMAT, "file ends inside a record"); return; }
+                const uint8_t* r = head + 4;
+                const int32_t rtid = (int32_t)le32(r);
+                if (rtid != tid) {                                   // the reference is over (a sorted file): nothing of ours behind this
+                    size_t cur = stop_at.load();
+                    while (k < cur && !stop_at.compare_exchange_weak(cur, k)) {}
+                    sg.saw_other = true;
+                    break;
+                }
+                const int64_t pos = (int32_t)le32(r + 4);
+                const uint32_t l_name = r[8], n_cigar = le16(r + 12), flag = le16(r + 14), l_seq = le32(r + 16);
+                if (32ull + l_name + 4ull * n_cigar + (l_seq + 1ull) / 2 + l_seq > bs || l_name == 0) { bad(LGIO_E_FORMAT, "BAM record fields exceed the record"); return; }
+                size_t left = bs - 32;
+                if (!(flag & 4) && pos < MAX_POS) {
+                    rec.resize((size_t)l_name + 4ull * n_cigar);
+                    rc = take_bytes(rec.data(), rec.size());
+                    if (rc) { if (rc > 0) bad(LGIO_E_FORMAT, "file ends inside a record"); return; }
+                    left -= rec.size();
+                    int64_t span = 0;
+                    const uint8_t* c = rec.data() + l_name;
+                    for (uint32_t q = 0; q < n_cigar; ++q) {
+                        const uint32_t v = le32(c + 4 * q), op = v & 0xF;
+                        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4;
+                    }
+                    sg.start.push_back(pos);
+                    sg.end.push_back(pos + (span > 0 ? span : 1));
+                }
+                rc = take_bytes(nullptr, left);
+                if (rc) { if (rc > 0) bad(LGIO_E_FORMAT, "file ends inside a record"); return; }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        const int nt = (int)std::min<size_t>((size_t)threads, n_seg);
+        int started = 1;
+        for (; started < nt; ++started) { try { pool.emplace_back(work); } catch (...) { break; } }
+        work();
+        for (std::thread& t : pool) t.join();
+    }
+    if (err.load()) return fail(err.load(), "%s", why.c_str());
+    const size_t last = std::min(stop_at.load(), n_seg - 1);
+    size_t total = 0;
+    for (size_t k = 0; k <= last; ++k) total += segs[k].start.size();
+    o->start.reserve(total); o->end.reserve(total);
+    for (size_t k = 0; k <= last; ++k) {
+        o->start.insert(o->start.end(), segs[k].start.begin(), segs[k].start.end());
+        o->end.insert(o->end.end(), segs[k].end.begin(), segs[k].end.end());
+        b->z.bytes_read += segs[k].bytes;
+    }
+    return 0;
+}
+
 static int ref_intervals_impl(lgio_bam* b, int tid, int threads, lgio_intervals* out) {
     if (!b || !out) return fail(LGIO_E_ARG, "NULL argument");
     memset(out, 0, sizeof *out);
@@ -1224,6 +1351,11 @@ static int ref_intervals_impl(lgio_bam* b, int tid, int threads, lgio_intervals*
     const int fd = open(b->path.c_str(), O_RDONLY);
     if (fd < 0) return fail(LGIO_E_IO, "cannot open %s", b->path.c_str());
     struct Close { int fd; ~Close() { close(fd); } } closer{fd};
+    if (!getenv("LGIO_SCAN_WINDOWS")) {                      // (LGIO_SCAN_WINDOWS=1: the windowed scan below, for comparisons and tests)
+        const int rs = ref_intervals_segments(b, tid, threads, fd, chunks[0].beg, o);
+        if (rs < 0) return rs;
+        if (rs == 0) return finish();
+    }
     // the reads of a reference are contiguous in a sorted file: from the first record the index points at until the
     // reference id changes.  Windows of WIN blocks: headers hopped over by the calling thread, blocks inflated by the worker
     // threads, records walked by the calling thread (a record may straddle blocks and windows: `stream` carries the

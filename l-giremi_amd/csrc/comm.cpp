@@ -479,6 +479,11 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
     for (int r = 0; r < world; ++r) general += gen[r];
 
     // ---- 4. what the permutation stage made, then the per-site figures
+    // (every count is at most n_shuffles <= 65535: 2 bytes instead of 4 — narrowed here, outside the group of sends)
+    if (rank != root && h->narrow && v.n_rows && h->has_p) {
+        launch_narrow_u16(st, v.n_rows, v.exceed, h->g16);
+        if (hipGetLastError() != hipSuccess) { (void)hipStreamSynchronize(st); return set_error(LGMI_E_HIP, "narrowing kernel"); }
+    }
     ncclResult_t nr = ncclSuccess;
 #define NC(expr) do { if (nr == ncclSuccess) nr = (expr); } while (0)
     NC(g.GroupStart());
@@ -486,10 +491,8 @@ extern "C" int lgmi_comm_gather_finish(lgmi_gather* h, lgmi_dresult** out, uint6
         const uint64_t n = v.n_rows;
         if (n && h->has_p) {
             if (!h->derive_p) NC(g.Send(v.p, n, ncclFloat64, root, comm, st));
-            if (h->narrow) {                         // every count is at most n_shuffles <= 65535: 2 bytes instead of 4
-                launch_narrow_u16(st, n, v.exceed, h->g16);
-                NC(g.Send(h->g16, 2 * n, ncclUint8, root, comm, st));
-            } else NC(g.Send(v.exceed, n, ncclUint32, root, comm, st));
+            if (h->narrow) NC(g.Send(h->g16, 2 * n, ncclUint8, root, comm, st));    // (narrowed before the group was opened)
+            else NC(g.Send(v.exceed, n, ncclUint32, root, comm, st));
         }
         if (!h->same_batch && v.n_sites) {
             NC(g.Send(v.mean, v.n_sites, ncclFloat64, root, comm, st));
