@@ -87,11 +87,16 @@ struct Pool {
     std::map<void*, size_t> live_;
     int alloc(void** out, size_t bytes) {
         size_t n = std::max<size_t>(256, (bytes + 255) & ~size_t(255));
+        // LGMI_POOL_POISON=1 (debugging aid): every block handed out is filled with 0xA5 first, device-synchronously, so that
+        // a kernel that reads what it never wrote fails the same way every time instead of once in a hundred runs
+        static const bool poison = getenv("LGMI_POOL_POISON") != nullptr;
         auto it = free_.lower_bound(n);
         if (it != free_.end() && it->first <= 2 * n + (1u << 20)) {
             *out = it->second;
             live_[it->second] = it->first;
+            const size_t got = it->first;
             free_.erase(it);
+            if (poison) { (void)hipDeviceSynchronize(); (void)hipMemset(*out, 0xA5, got); (void)hipDeviceSynchronize(); }
             return LGMI_OK;
         }
         void* p = nullptr;
@@ -106,6 +111,7 @@ struct Pool {
         }
         live_[p] = n;
         *out = p;
+        if (poison) { (void)hipDeviceSynchronize(); (void)hipMemset(p, 0xA5, n); (void)hipDeviceSynchronize(); }
         return LGMI_OK;
     }
     void release(void* p) {
@@ -173,14 +179,16 @@ struct PinnedPool {
     }
     void* take(size_t bytes, size_t* got) {
         const size_t n = std::max<size_t>(4096, (bytes + 4095) & ~size_t(4095));
+        static const bool poison = getenv("LGMI_POOL_POISON") != nullptr;      // (see Pool::alloc)
+        void* p = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = free_.lower_bound(n);
-            if (it != free_.end() && it->first <= 2 * n + (1u << 20)) {
-                void* p = it->second; *got = it->first; free_.erase(it); return p;
-            }
+            if (it != free_.end() && it->first <= 2 * n + (1u << 20)) { p = it->second; *got = it->first; free_.erase(it); }
         }
-        return pin_new(n, got);
+        if (!p) p = pin_new(n, got);
+        if (p && poison) memset(p, 0xA5, *got);
+        return p;
     }
     void give(void* p, size_t n) { if (p) { std::lock_guard<std::mutex> lk(mu); free_.emplace(n, p); } }
     ~PinnedPool() {

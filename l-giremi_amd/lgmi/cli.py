@@ -122,6 +122,40 @@ class _RemovedWriter:
             os.remove(self.path)
 
 
+class _PairsWriter:
+    """PREFIX.mi.txt written chunk by chunk while later footprints are still being extracted (regions_mismatch_analysis:
+    pairs_sink) — the bytes of one df.to_csv(sep='\\t', index=False) over the whole table (every value is formatted on its
+    own); under a temporary name until the run has succeeded"""
+
+    FLUSH_ROWS = 32768            # one to_csv call costs ~1.5 ms whatever its size: a few hundred small chunks are gathered first
+
+    def __init__(self, path):
+        self.final, self.path, self.parts, self.held, self.n_held = path, path + '.partial', 0, [], 0
+
+    def __call__(self, df):
+        self.held.append(df)
+        self.n_held += len(df)
+        if self.n_held >= self.FLUSH_ROWS:
+            self._flush()
+
+    def _flush(self):
+        if self.held:
+            df = self.held[0] if len(self.held) == 1 else pd.concat(self.held, ignore_index=True)
+            df.to_csv(self.path, sep='\t', index=False, header=(self.parts == 0), mode='a' if self.parts else 'w')
+            self.parts, self.held, self.n_held = self.parts + 1, [], 0
+
+    def close(self, whole):
+        """whole: the run's complete pair table — written here when no chunk came through the sink (serial runs, empty tables)"""
+        self._flush()
+        if not self.parts:
+            whole.to_csv(self.path, sep='\t', index=False)
+        os.replace(self.path, self.final)
+
+    def abort(self):
+        if os.path.exists(self.path):
+            os.remove(self.path)
+
+
 def _write_removed(df, path, header=True, append=False):
     """the removed-site table (strings and one integer column, millions of rows: one per covered position of every
     footprint) as pandas' to_csv(sep='\t', index=False) writes it, byte for byte, through pyarrow's CSV writer when it is
@@ -295,11 +329,12 @@ def main(argv=None):
     # one rank: the removed-site table (one row per covered position: most of what a run writes) goes out part by part
     # while later footprints are still being extracted
     removed_writer = _RemovedWriter(args.output_prefix + '.removed.txt') if world == 1 else None
+    pairs_writer = _PairsWriter(args.output_prefix + '.mi.txt') if world == 1 else None
     try:
         df_sites, df_mi, df_removed = regions_mismatch_analysis(
             jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
             engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta), timing=timing,
-            group=group, removed_sink=removed_writer,
+            group=group, removed_sink=removed_writer, pairs_sink=pairs_writer,
             keep_non_spliced_read=args.keep_non_spliced_read,
             min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
             min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,
@@ -310,6 +345,8 @@ def main(argv=None):
     except BaseException:
         if removed_writer is not None:
             removed_writer.abort()                         # no half-written table next to missing .mi.txt / .strand.txt files
+        if pairs_writer is not None:
+            pairs_writer.abort()
         raise
     t0 = time.perf_counter()
     strand_df = pd.DataFrame.from_records([], columns=['read_name', 'original_read_strand', 'corrected_read_strand'])
@@ -332,8 +369,8 @@ def main(argv=None):
         group.barrier()
     else:
         strand_df.to_csv(args.output_prefix + '.strand.txt', sep='\t', index=False)
-        df_mi.to_csv(args.output_prefix + '.mi.txt', sep='\t', index=False)
-        removed_writer.close()                           # (its parts were written as the run went)
+        pairs_writer.close(df_mi)                        # (its parts were written as the run went; a serial run's table here)
+        removed_writer.close()
     if args.mip_table:
         # script/giremi.py:415-429: mip = ECDF of the het-SNP rows' mean_mi (those that have one) at every row's mean_mi.
         # Several ranks: the ECDF needs every rank's het-SNP means — the site tables go to rank 0 through the socket group.

@@ -468,7 +468,7 @@ def _removed_frame(staged, chrom_code, reason_code):
 
 def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
                               concat=False, threads=1, reopen=None, timing=None, group=None, removed_sink=None,
-                              **filter_kwargs):
+                              pairs_sink=None, **filter_kwargs):
     """``region_mismatch_analysis`` over many footprints with the MI blocks of many footprints per GPU batch — the shape the
     reference's per-chunk loop (src/giremi/script/giremi.py:32-88) takes when the MI step is a device call.
 
@@ -482,7 +482,9 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     footprints come back from the pool in order, and while the workers extract the later ones the parent runs each
     chunk's own batch on the GPU (``stream_site_base`` = the sites before it: pair for pair the permutation draws of the one
     batch holding every footprint), builds its rows of the two site tables and hands its part of the removed-site table to
-    ``removed_sink`` (a callable taking a DataFrame; the returned df_removed is then empty)."""
+    ``removed_sink`` (a callable taking a DataFrame; the returned df_removed is then empty); ``pairs_sink`` (a callable taking a
+    chunk's pair rows as a DataFrame, in order) lets the caller write the pair table while the run goes on — the returned
+    df_pairs is still the whole table."""
     import time
     t0 = time.perf_counter()
     footprints = list(footprints)
@@ -514,6 +516,8 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
                                                           n_shuffles=n_shuffles, seed=seed, engine=engine, batch=b, **kw)
                     site_base += len(b.site_pos) if b is not None else 0
                     pair_frames.append(df_c)
+                    if pairs_sink is not None and len(df_c):
+                        pairs_sink(df_c)
                     t2 = time.perf_counter()
                     # the worker made the footprints' rows of the mismatch table; their last column is the GPU's per-site mean
                     for rows, mean_mi in zip(extras['site_rows'], means_c):

@@ -339,3 +339,32 @@ def test_removed_table_writer_matches_pandas(tmp_path):
         frame.to_csv(a, sep='\t', index=False, header=header)
         _write_removed(frame, b, header=header)
         assert filecmp.cmp(a, b, shallow=False)
+
+
+def test_pair_table_written_in_parts_matches_one_to_csv(tmp_path):
+    """cli._PairsWriter: the chunks of a pipelined run appended one by one give the bytes of one to_csv over the whole table;
+    a run that sent no chunk writes the whole table at close; abort leaves nothing behind"""
+    import filecmp
+    from lgmi.cli import _PairsWriter
+    rng = np.random.default_rng(3)
+    n = 3000
+    df = pd.DataFrame({'chromosome': np.array(['chr1', 'chr2'], dtype=object)[rng.integers(0, 2, n)],
+                       'site1_pos': rng.integers(1, 10 ** 8, n), 'site2_pos': rng.integers(1, 10 ** 8, n),
+                       'mi': rng.random(n) * np.where(rng.random(n) < 0.1, 0.0, 1.0), 'n': rng.integers(6, 2000, n),
+                       'p_perm': rng.integers(1, 1002, n) / 1001.0})
+    want = str(tmp_path / 'want.txt')
+    df.to_csv(want, sep='\t', index=False)
+    w = _PairsWriter(str(tmp_path / 'parts.txt'))
+    w.FLUSH_ROWS = 900                                    # several flushes, one of them of gathered chunks, and a rest at close
+    for a, b in ((0, 1), (1, 500), (500, 1700), (1700, 2800), (2800, n)):
+        w(df.iloc[a:b])
+    assert not os.path.exists(w.final)
+    w.close(df)
+    assert filecmp.cmp(want, w.final, shallow=False) and not os.path.exists(w.path)
+    w = _PairsWriter(str(tmp_path / 'whole.txt'))
+    w.close(df)
+    assert filecmp.cmp(want, w.final, shallow=False)
+    w = _PairsWriter(str(tmp_path / 'gone.txt'))
+    w(df.iloc[:5])
+    w.abort()
+    assert not os.path.exists(w.path) and not os.path.exists(w.final)
