@@ -90,17 +90,43 @@ class _RemovedWriter:
         # written under a temporary name and renamed when the run has succeeded: a run that fails half-way (advice r4: an
         # IndexError parity check, an out-of-memory kill) must not leave a truncated table that looks like a result
         self.final, self.path, self.parts = path, path + '.partial', 0
+        self._q = self._thread = self._err = None
         if os.path.exists(self.final):
             os.remove(self.final)                          # (a stale table of an earlier run next to this run's other files)
 
     def __call__(self, df):
+        self._drain()                                      # (parts are appended in the order they were handed over)
         _write_removed(df, self.path, header=(self.parts == 0), append=(self.parts > 0))
         self.parts += 1
 
     def write_arrays(self, arrays):
         """a chunk's removed sites as its extraction worker flattened them (lgmi.region._removed_arrays: names + codes):
         formatted by liblgmi_io (lgio_write_removed_table) — no DataFrame, no categoricals; 15 M rows of an 8,000-gene run
-        were 1.3 s of the parent's time through pandas + pyarrow"""
+        were 1.3 s of the parent's time through pandas + pyarrow.  The call is queued to ONE writer thread (the native
+        writer holds no interpreter lock: 450 MB of text leave the parent's critical path, 0.6 s of that run); what it
+        raises comes out of the next call or of close()"""
+        if self._thread is None:
+            import queue
+            import threading
+            self._q = queue.Queue(maxsize=8)               # (bounded: a slow disk holds the pipeline back instead of the rows piling up)
+            self._thread = threading.Thread(target=self._writer, name='lgmi-removed-writer', daemon=True)
+            self._thread.start()
+        if self._err is not None:
+            self._drain()
+        self._q.put(arrays)
+
+    def _writer(self):
+        while True:
+            arrays = self._q.get()
+            if arrays is None:
+                return
+            if self._err is None:
+                try:
+                    self._write_arrays_now(arrays)
+                except BaseException as e:                  # noqa: BLE001 — handed to the thread that owns the run
+                    self._err = e
+
+    def _write_arrays_now(self, arrays):
         from .io import write_removed_table
         chroms, reasons, g_chrom, g_strand, g_pos, g_reason = arrays
         try:
@@ -108,16 +134,30 @@ class _RemovedWriter:
                                 append=(self.parts > 0))
         except ValueError:                                  # a name pandas would quote: pandas writes it
             from .region import _removed_frame_from_arrays
-            return self(_removed_frame_from_arrays(arrays, {}, {}))
+            _write_removed(_removed_frame_from_arrays(arrays, {}, {}), self.path, header=(self.parts == 0), append=(self.parts > 0))
         self.parts += 1
 
+    def _drain(self):
+        if self._thread is not None:
+            self._q.put(None)
+            self._thread.join()
+            self._thread = None
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+
     def close(self):
+        self._drain()
         if not self.parts:
             import pandas as pd
             _write_removed(pd.DataFrame({c: [] for c in ('chromosome', 'strand', 'pos', 'removed')}), self.path)
         os.replace(self.path, self.final)
 
     def abort(self):
+        try:
+            self._drain()
+        except BaseException:                               # noqa: BLE001 — the run already failed; its own error is the one to show
+            pass
         if os.path.exists(self.path):
             os.remove(self.path)
 

@@ -400,3 +400,49 @@ def test_native_removed_table_writer_equals_pandas(tmp_path):
         write_removed_table(b, ['chr\t1'], reasons, cc[:5] * 0, st[:5], ps[:5], rc[:5])
     with pytest.raises(ValueError):
         write_removed_table(b, chroms, reasons, cc[:5] + 7, st[:5], ps[:5], rc[:5])
+
+
+def test_removed_writer_queues_parts_in_order(tmp_path):
+    """cli._RemovedWriter.write_arrays hands the parts to one writer thread: the file is the whole table in the order the
+    parts were handed over — also when one part falls back to pandas (a name pandas would quote) and when a DataFrame part
+    comes in between; a part the native writer refuses for good surfaces from close(), and abort() leaves nothing"""
+    import filecmp
+    import pandas as pd
+    from lgmi.cli import _RemovedWriter, _write_removed
+    rng = np.random.default_rng(11)
+    chroms, reasons = ['chr1', 'chr2'], ['in homopoly regions', 'too few usable reads after filters']
+
+    def part(n, names=chroms):
+        return (list(names), list(reasons), rng.integers(0, 2, n).astype(np.int32), rng.integers(0, 2, n).astype(np.int8),
+                rng.integers(1, 10 ** 8, n).astype(np.int64), rng.integers(0, 2, n).astype(np.int8))
+
+    def frame(parts):
+        cols = {'chromosome': [], 'strand': [], 'pos': [], 'removed': []}
+        for names, rs, cc, st, ps, rc in parts:
+            cols['chromosome'] += [names[k] for k in cc]
+            cols['strand'] += ['+-'[k] for k in st]
+            cols['pos'] += ps.tolist()
+            cols['removed'] += [rs[k] for k in rc]
+        return pd.DataFrame(cols)
+
+    parts = [part(4000), part(1), part(0), part(30, ['chr\t1', 'chr2']), part(2500)]
+    w = _RemovedWriter(str(tmp_path / 'r.txt'))
+    for k, p in enumerate(parts):
+        w.write_arrays(p)
+        if k == 1:
+            w(frame([part0 := part(7)]))                                  # a DataFrame part between two queued ones
+            parts_with_frame = parts[:2] + [part0]
+    assert not os.path.exists(w.final)
+    w.close()
+    want = str(tmp_path / 'want.txt')
+    _write_removed(frame(parts_with_frame + parts[2:]), want)
+    assert filecmp.cmp(want, w.final, shallow=False) and not os.path.exists(w.path)
+    bad = _RemovedWriter(str(tmp_path / 'bad.txt'))
+    bad.write_arrays(part(10))
+    wrong = list(part(10))
+    wrong[2] = wrong[2] + 9                                               # chromosome codes outside the name list
+    bad.write_arrays(tuple(wrong))
+    with pytest.raises(Exception):
+        bad.close()
+    bad.abort()
+    assert not os.path.exists(bad.path) and not os.path.exists(bad.final)
