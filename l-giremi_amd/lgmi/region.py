@@ -466,6 +466,30 @@ def _removed_frame(staged, chrom_code, reason_code):
                         columns=['chromosome', 'strand', 'pos', 'removed'])
 
 
+def _ordered_parts(pool, fn, jobs, poll_s=0.5):
+    """``pool.imap(fn, jobs)`` that notices a worker's death.  multiprocessing.Pool replaces a dead worker by forking the
+    parent again — here a parent that holds a HIP context and its runtime threads by then (advice r4) — and the dead
+    worker's job never comes back, so a plain imap would wait for ever.  The set of worker pids is taken when the pool is
+    new and looked at between results: any change ends the run with an error instead."""
+    import multiprocessing as mp
+    pids = sorted(p.pid for p in list(pool._pool))
+    it = pool.imap(fn, jobs)
+    while True:
+        try:
+            part = it.next(timeout=poll_s)
+        except StopIteration:
+            return
+        except mp.TimeoutError:
+            part = None
+        now = sorted(p.pid for p in list(pool._pool) if p.exitcode is None)
+        if now != pids:
+            pool.terminate()
+            raise RuntimeError('an extraction worker died (worker pids %s, now %s: out of memory?); the run was stopped — '
+                               'a replacement would have been forked from a process that holds a GPU context' % (pids, now))
+        if part is not None:
+            yield part
+
+
 def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
                               concat=False, threads=1, reopen=None, timing=None, group=None, removed_sink=None,
                               pairs_sink=None, **filter_kwargs):
@@ -502,7 +526,7 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
                 for k in range(0, len(footprints), chunk)]
         with mp.get_context('fork').Pool(threads) as pool:
             if concat and not multi_rank:
-                parts = pool.imap(_extract_chunk, jobs)               # in job order, as they finish
+                parts = _ordered_parts(pool, _extract_chunk, jobs)    # in job order, as they finish
                 if callable(engine) and not hasattr(engine, 'run'):
                     engine = engine()
                 t_gpu = t_tab = 0.0

@@ -3,6 +3,8 @@ specification, the Python routine get_region_mismatches_with_filters: same survi
 allele order, same read lists, same window counts), same removed table (same order, same reasons) — on simulated
 genes at several error rates and filter settings, on hand-made records for the quirks, and refused (None, so the
 caller runs the Python routine) for the inputs the native walk does not cover."""
+import os
+
 import numpy as np
 import pytest
 
@@ -312,3 +314,26 @@ def test_repeat_intervals_outside_a_footprint_never_remove_a_site(tmp_path):
     # ... while an interval INSIDE the footprint does remove sites (the filter itself works)
     inside, _g = get_region_mismatches_with_filters(simple_repeat_intervals=[[start, end]], **kw)
     assert all(len(inside[strand]) == 0 for strand in '+-')
+
+
+def _part_or_die(job):
+    if job == 'die':
+        os._exit(3)                                    # a worker killed from outside (the kernel's out-of-memory killer)
+    return job
+
+
+def test_pipeline_stops_when_a_worker_dies():
+    """region._ordered_parts: results in job order; a worker's death ends the run with an error — a plain Pool.imap waits
+    for the lost job for ever, while the pool forks a replacement from the parent (which holds the GPU context by then)"""
+    import multiprocessing as mp
+    import time
+    from lgmi.region import _ordered_parts
+    with mp.get_context('fork').Pool(3) as pool:
+        assert list(_ordered_parts(pool, _part_or_die, list(range(40)), poll_s=0.05)) == list(range(40))
+    with mp.get_context('fork').Pool(3) as pool:
+        t0 = time.time()
+        got = []
+        with pytest.raises(RuntimeError, match='extraction worker died'):
+            for x in _ordered_parts(pool, _part_or_die, [0, 1, 'die', 3, 4], poll_s=0.05):
+                got.append(x)
+        assert got == [0, 1][:len(got)] and time.time() - t0 < 20          # (stopped at once: what had come back is not handed on)
