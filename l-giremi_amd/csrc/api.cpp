@@ -214,6 +214,8 @@ struct lgmi_ctx {
     hipStream_t comm_stream = nullptr;   // the gather runs here, beside the kernels of `stream`
     hipStream_t copy_stream = nullptr;   // lgmi_run's copies (planes up in pieces, rows down under the permutation stage): a stream
                                          // of its own, never the one RCCL's collectives were queued on
+    hipStream_t prep_stream = nullptr;   // layout prep of a pipelined upload's pieces (made on first use, kept: making and
+                                         // destroying a stream per call was milliseconds of every lgmi_run)
     hipEvent_t comm_event = nullptr;     // main stream -> communication stream ordering (comm.cpp: comm_after_main)
     int rank = 0, world = 1;
     size_t mem_total = 0;       // device memory, for the "allocate rows by their upper bound" decision
@@ -396,6 +398,7 @@ extern "C" void lgmi_ctx_destroy(lgmi_ctx* ctx) {
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
     if (ctx->comm_event) (void)hipEventDestroy(ctx->comm_event);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -407,6 +410,10 @@ hipStream_t ctx_stream(lgmi_ctx* c) { return c->stream; }
 hipStream_t ctx_comm_stream(lgmi_ctx* c) {               // created on first use
     if (!c->comm_stream && hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess) c->comm_stream = nullptr;
     return c->comm_stream ? c->comm_stream : c->stream;
+}
+static hipStream_t ctx_prep_stream(lgmi_ctx* c) {        // NULL when the runtime refuses one (the caller then uses the copy stream)
+    if (!c->prep_stream && hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->prep_stream = nullptr; }
+    return c->prep_stream;
 }
 hipStream_t ctx_copy_stream(lgmi_ctx* c) {               // created on first use; the main stream when the runtime refuses one
     if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->copy_stream = nullptr; }
@@ -572,7 +579,7 @@ struct UploadPipe {
     lgmi_ctx* ctx = nullptr;
     const lgmi_batch* b = nullptr;
     hipStream_t us = nullptr;                      // the upload stream (the context's copy stream)
-    hipStream_t ps = nullptr;                      // the prep kernels' stream (made on first use)
+    hipStream_t ps = nullptr;                      // the prep kernels' stream (the context's)
     uint32_t K = 0;
     std::vector<uint64_t> site_begin, word_begin, pseudo_begin;   // [K + 1] chunk k = sites [site_begin[k], site_begin[k + 1]), their plane words, their pseudo columns
     uint64_t* d_planes = nullptr; uint64_t* d_poff = nullptr; uint32_t* d_nw = nullptr; uint32_t* d_pseudo = nullptr;
@@ -583,7 +590,7 @@ struct UploadPipe {
     ~UploadPipe() {
         if (!ctx) return;
         if (us) (void)hipStreamSynchronize(us);
-        if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+        if (ps) (void)hipStreamSynchronize(ps);
         (void)hipStreamSynchronize(ctx->stream);
         Pool& p = ctx->pool;
         p.release(d_planes); p.release(d_poff); p.release(d_nw); p.release(d_pseudo); p.release(d_tri_chk); p.release(d_bad);
@@ -747,7 +754,7 @@ extern "C" int lgmi_batch_upload(lgmi_ctx* ctx, const lgmi_batch* b, lgmi_dbatch
 static int pipe_chunk(UploadPipe& p, lgmi_dbatch* db, uint32_t k, hipEvent_t done) {
     const uint64_t w0 = p.word_begin[k], w1 = p.word_begin[k + 1], s0 = p.site_begin[k], s1 = p.site_begin[k + 1];
     const uint32_t ns = (uint32_t)db->d.n_sites;
-    if (!p.ps && hipStreamCreateWithFlags(&p.ps, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); p.ps = nullptr; }
+    if (!p.ps) p.ps = ctx_prep_stream(p.ctx);
     hipStream_t ps = p.ps ? p.ps : p.us;
     if (w1 > w0) HIPCHK(hipMemcpyAsync(p.d_planes + w0, p.b->planes + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, p.us));
     if (ps != p.us) {
@@ -1659,19 +1666,27 @@ static int permute_impl(lgmi_ctx* ctx, lgmi_dresult* res, uint32_t n_chunks, F a
     float ms_fast = 0.f, ms_exact = 0.f;
     enum { HS_ROWS = 512, HS_GEN = 576 };                    // pinned words: the chunks' row counts (up), their queue counters (down)
     if (chunked) for (uint32_t k = 0; k < 3 * n_chunks; ++k) if (!ctx->event(k)) return fail(LGMI_E_HIP, "hipEventCreate failed");
+    // the ranges' first rows: equal ranges, except that the LAST one is half as long (what is left to copy when the stage's
+    // last kernel ends is the last range's counts) — every start even, so that the 16-bit narrowing stays aligned
+    uint64_t range_begin[33];
+    {
+        const uint64_t unit = chunked ? (n_rows + 2 * n_chunks - 2) / (2 * n_chunks - 1) : 0;      // the last range: one unit, the others two
+        for (uint32_t c = 0; c <= n_chunks; ++c) range_begin[c] = c == n_chunks ? n_rows : std::min<uint64_t>(n_rows, (2 * c * unit + 1) & ~1ull);
+    }
     if (res->cap_rows) {
-        const uint64_t chunk_cap = chunked ? ((n_rows + n_chunks - 1) / n_chunks + 1) & ~1ull : res->cap_rows;   // even: the 16-bit narrowing stays aligned
+        uint64_t chunk_cap = res->cap_rows;
+        if (chunked) { chunk_cap = 0; for (uint32_t c = 0; c < n_chunks; ++c) chunk_cap = std::max(chunk_cap, range_begin[c + 1] - range_begin[c]); }
         if ((rc = pool.alloc((void**)&d_genlist, (size_t)chunk_cap * 4))) return rc;
         if ((rc = pool.alloc((void**)&d_gencount, 64 * (size_t)n_chunks))) return rc;      // per chunk: [0] queued rows, [1] k_perm_general's next row, [2] rows k_perm_enum leaves to it, [3] some row is enumerable, ...
         HIPCHK(hipMemsetAsync(d_gencount, 0, 64 * (size_t)n_chunks, st));
         unsigned long long* const hs = ctx->h_scal;
         if (chunked) {
             if ((rc = pool.alloc((void**)&d_chunk_rows, 8 * (size_t)n_chunks))) return rc;
-            for (uint32_t c = 0; c < n_chunks; ++c) hs[HS_ROWS + c] = std::min<uint64_t>(chunk_cap, n_rows - std::min<uint64_t>(n_rows, c * chunk_cap));
+            for (uint32_t c = 0; c < n_chunks; ++c) hs[HS_ROWS + c] = range_begin[c + 1] - range_begin[c];
             HIPCHK(hipMemcpyAsync(d_chunk_rows, &hs[HS_ROWS], 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
         }
         for (uint32_t c = 0; c < n_chunks; ++c) {
-            const uint64_t r0 = chunked ? std::min<uint64_t>(n_rows, c * chunk_cap) : 0, nr = chunked ? (uint64_t)hs[HS_ROWS + c] : res->cap_rows;
+            const uint64_t r0 = chunked ? range_begin[c] : 0, nr = chunked ? range_begin[c + 1] - range_begin[c] : res->cap_rows;
             PermArgs pa{};
             pa.n_rows_dev = chunked ? d_chunk_rows + c : res->d_nrows; pa.max_rows = nr;
             pa.row_i = res->d_i + r0; pa.row_j = res->d_j + r0; pa.counts = res->d_counts ? res->d_counts + 9 * r0 : nullptr; pa.rec = res->d_rec + r0;
@@ -1981,6 +1996,7 @@ extern "C" int lgmi_run(lgmi_ctx* ctx, const lgmi_batch* batch, const lgmi_param
     tr.mark("planned");
     if (!split && !rc) {
         rc = run_device_impl(ctx, db, prm, &dr, true, 0, pipe.get());
+        tr.mark("impl_done");
         pipe.reset();                                        // (waits for the upload stream; releases the planes' staging copies)
     }
     tr.mark("rows");
