@@ -269,14 +269,25 @@ def get_footprints(sam, chromosomes, min_read_count=2):
     return out
 
 
-class _Reopen:
-    """picklable: a pool worker opens its own handles on the alignment and genome files"""
+_WORKER_HANDLES = {}          # (bam, fasta) -> (sam, genome) of THIS process
 
-    def __init__(self, bam, fasta):
-        self.bam, self.fasta = bam, fasta
+
+class _Reopen:
+    """picklable: a pool worker opens its own handles on the alignment and genome files — once per worker process, not
+    once per job (a job is a few dozen footprints; every open read the .bai again, and a FASTA without a .fai was indexed
+    by a pass over the whole file in every job: a fifth of a second per job on a 12-MB genome).  ``fai``: the index the
+    parent's FastaReader already holds."""
+
+    def __init__(self, bam, fasta, fai=None):
+        self.bam, self.fasta, self.fai = bam, fasta, fai
 
     def __call__(self):
-        return open_alignment(self.bam), open_fasta(self.fasta)
+        key = (os.getpid(), self.bam, self.fasta)
+        got = _WORKER_HANDLES.get(key)
+        if got is None:
+            _WORKER_HANDLES.clear()                            # (a forked child inherits the parent's entry under the parent's pid)
+            got = _WORKER_HANDLES[key] = (open_alignment(self.bam), open_fasta(self.fasta, fai=self.fai))
+        return got
 
 
 def read_repeats(path):
@@ -373,7 +384,7 @@ def main(argv=None):
     try:
         df_sites, df_mi, df_removed = regions_mismatch_analysis(
             jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
-            engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta), timing=timing,
+            engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta, fai=getattr(genome, 'index', None)), timing=timing,
             group=group, removed_sink=removed_writer, pairs_sink=pairs_writer,
             keep_non_spliced_read=args.keep_non_spliced_read,
             min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,

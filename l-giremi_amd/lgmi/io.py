@@ -468,10 +468,16 @@ class FastaReader:
     line); the index is built in memory by one pass over the file when there is no .fai next to it.  gzip input
     is read whole (no random access into plain gzip)."""
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, fai=None):
+        """``fai``: the index another FastaReader of the same file built (FastaReader.index): no .fai is read, no pass made"""
         self.path = path
         self._fai: Dict[str, Tuple[int, int, int, int]] = {}
         self._seq: Optional[Dict[str, str]] = None
+        if fai is not None and not path.endswith('.gz'):
+            self._fai = dict(fai)
+            self.references = list(self._fai)
+            self._f = open(path, 'rb')
+            return
         if path.endswith('.gz'):
             self._seq = {}
             name, parts = None, []
@@ -495,9 +501,56 @@ class FastaReader:
                     if len(c) >= 5:
                         self._fai[c[0]] = (int(c[1]), int(c[2]), int(c[3]), int(c[4]))
         else:
-            self._fai = self._scan(path)
+            self._fai = self._scan_fast(path)
         self.references = list(self._fai)
         self._f = open(path, 'rb')
+
+    @property
+    def index(self):
+        """name -> (length, offset, bases per line, bytes per line), or None for a gzip file held in memory"""
+        return None if self._seq is not None else dict(self._fai)
+
+    @classmethod
+    def _scan_fast(cls, path):
+        """_scan without a Python step per line: the header lines are found with mmap.find, a sequence's length is its bytes
+        minus its line ends (bytes.count over pieces of the map).  (_scan reads the 800,000 lines of a 49-MB genome one by
+        one: 0.3 s at the start of every run on a FASTA without a .fai.)  Falls back to _scan for what it does not cover: a
+        sequence whose first line is empty."""
+        import mmap
+        size = os.path.getsize(path)
+        if size == 0:
+            return {}
+        piece = 1 << 26
+
+        def count(mm, a, b, ch):
+            return sum(mm[o:min(b, o + piece)].count(ch) for o in range(a, b, piece))
+
+        with open(path, 'rb') as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+            heads = [0] if mm[0:1] == b'>' else []                               # '>' at the start of a line
+            at = mm.find(b'\n>')
+            while at >= 0:
+                heads.append(at + 1)
+                at = mm.find(b'\n>', at + 1)
+            fai = {}
+            for k, h in enumerate(heads):
+                end = heads[k + 1] if k + 1 < len(heads) else size
+                nl = mm.find(b'\n', h, end)
+                head_end = end if nl < 0 else nl + 1                             # (a header that is the file's last line, unterminated)
+                name = mm[h + 1:head_end].split()[0].decode()
+                n_body = end - head_end
+                n_base = n_body - count(mm, head_end, end, b'\n') - count(mm, head_end, end, b'\r')
+                lb = lw = 0
+                if n_body:
+                    first = mm.find(b'\n', head_end, end)
+                    line = mm[head_end:end if first < 0 else first + 1]
+                    lb, lw = len(line.rstrip(b'\r\n')), len(line)
+                    if lb == 0 and n_base > 0:
+                        return cls._scan(path)                                    # bases after an empty first line: the line-by-line pass
+                    if lb == 0:
+                        lw = 0
+                # (_scan strips CR / LF at line ends only; a CR inside a line is not FASTA)
+                fai[name] = (n_base, head_end, lb, lw)
+            return fai
 
     @staticmethod
     def _scan(path):
@@ -589,8 +642,8 @@ def open_alignment(path):
     return BamReader(path)
 
 
-def open_fasta(path):
-    return FastaReader(path)
+def open_fasta(path, fai=None):
+    return FastaReader(path, fai=fai)
 
 
 def open_variants(path):

@@ -446,3 +446,44 @@ def test_removed_writer_queues_parts_in_order(tmp_path):
         bad.close()
     bad.abort()
     assert not os.path.exists(bad.path) and not os.path.exists(bad.final)
+
+
+def test_fasta_index_without_fai_matches_the_line_by_line_pass(tmp_path):
+    """FastaReader._scan_fast (mmap.find + bytes.count) builds the index _scan builds line by line: LF and CRLF files, an
+    unterminated last line, short lines, lines before the first header, an empty sequence, an empty first line (fallback),
+    '>' inside a line — and fetch() through it returns the bases"""
+    import random
+    rnd = random.Random(5)
+    seqs = [(b'chr1', 1000), (b'chr2', 0), (b'chrX', 61), (b'c4', 60), (b'c5', 1)]
+
+    def make(path, eol=b'\n', last_eol=True, width=60, blank_first=False, junk=False):
+        truth = {}
+        with open(path, 'wb') as f:
+            if junk:
+                f.write(b'junk line' + eol)
+            for k, (name, n) in enumerate(seqs):
+                f.write(b'>' + name + b' some description' + eol)
+                if blank_first:
+                    f.write(eol)
+                s = bytes(rnd.choice(b'ACGTN') for _ in range(n))
+                truth[name.decode()] = s.decode()
+                f.write(eol.join(s[i:i + width] for i in range(0, n, width)))
+                if n and (k + 1 < len(seqs) or last_eol):
+                    f.write(eol)
+        return truth
+
+    for kw in (dict(), dict(eol=b'\r\n'), dict(last_eol=False), dict(width=7), dict(junk=True), dict(blank_first=True)):
+        path = str(tmp_path / 'x.fa')
+        truth = make(path, **kw)
+        assert FastaReader._scan_fast(path) == FastaReader._scan(path), kw
+        if not kw.get('blank_first'):
+            fa = FastaReader(path)
+            assert fa.references == [n.decode() for n, _ in seqs]
+            assert fa.fetch('chr1', 100, 333) == truth['chr1'][100:333] and fa.fetch('chrX') == truth['chrX'] and fa.fetch('chr2') == ''
+            again = FastaReader(path, fai=fa.index)                    # a worker's reader on the parent's index
+            assert again.fetch('c4', 3, 60) == truth['c4'][3:60]
+    for raw in (b'>only', b'', b'>a\nAC>GT\n>b\n\n', b'no header at all\n'):
+        path = str(tmp_path / 'y.fa')
+        with open(path, 'wb') as f:
+            f.write(raw)
+        assert FastaReader._scan_fast(path) == FastaReader._scan(path), raw
