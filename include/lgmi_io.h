@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGIO_ABI_VERSION 3
+#define LGIO_ABI_VERSION 4
 #define LGIO_OK        0
 #define LGIO_E_ARG    -1
 #define LGIO_E_IO     -2   /* open / read / seek failed                     */
@@ -193,6 +193,26 @@ int  lgio_write_removed_table(const char* path, int append, int header, uint64_t
                               const int8_t* strand, const int64_t* pos, const int8_t* reason_code,
                               const char* const* chrom_names, uint32_t n_chrom, const char* const* reason_names,
                               uint32_t n_reasons, int threads);
+
+/* ---- round 5 (ABI 4): any table of integers, floats and dictionary strings, written the way
+ * pandas.DataFrame.to_csv(sep='\t', index=False) writes it — PREFIX.mi.txt (src/giremi/script/giremi.py:396-401:
+ * chromosome, strand, site1_pos, site1_type, site2_pos, site2_type, mi [, p_perm]).  A float64 is written as numpy's
+ * astype(str) writes it (what to_csv does): the shortest digits that read back as the same double, positional for
+ * 1e-4 <= |x| < 1e16 with at least one digit behind the point, d[.ddd]e+XX otherwise, NaN as an empty field.
+ * lgio_format_doubles writes the same text into out + k * stride (NUL-terminated, stride >= 33): the tests compare it with
+ * numpy on millions of values.  Names (columns and dictionary entries) that pandas would quote are refused (LGIO_E_ARG). */
+#define LGIO_COL_I64  0u       /* data: const int64_t[n_rows] */
+#define LGIO_COL_F64  1u       /* data: const double[n_rows] */
+#define LGIO_COL_DICT 2u       /* data: const int32_t[n_rows], codes into names[n_names] */
+typedef struct lgio_table_col {
+    const char* name;
+    uint32_t kind, n_names;
+    const void* data;
+    const char* const* names;
+} lgio_table_col;
+int  lgio_write_table(const char* path, int append, int header, uint64_t n_rows, uint32_t n_cols, const lgio_table_col* cols,
+                      int threads);
+int  lgio_format_doubles(uint64_t n, const double* x, char* out, uint32_t stride);
 
 /* bytes of compressed file read so far through this handle (tests use it to show that a region query does not
  * read the whole file) */

@@ -6,6 +6,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <charconv>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -634,6 +636,125 @@ extern "C" int lgio_write_removed_table(const char* path, int append, int header
                                         uint32_t n_reasons, int threads) {
     return guarded([&] { return write_removed_impl(path, append, header, n, chrom_code, strand, pos, reason_code, chrom_names, n_chrom,
                                                    reason_names, n_reasons, threads); });
+}
+
+// ---------------------------------------------------------------- any table of integers, floats and dictionary strings (lgmi_io.h)
+// A float64 the way numpy's astype(str) — pandas' to_csv — writes it: the shortest digits that read back as the same
+// double (std::to_chars gives them), positional for 1e-4 <= |x| < 1e16 with at least one digit behind the point, otherwise
+// d[.ddd]e+XX with at least two exponent digits; "nan" is the caller's empty field.  Returns the length written (<= 32).
+static int format_double_repr(double x, char* out) {
+    if (std::isnan(x)) return 0;
+    char* p = out;
+    if (std::signbit(x)) { *p++ = '-'; x = -x; }
+    if (std::isinf(x)) { memcpy(p, "inf", 3); return (int)(p + 3 - out); }
+    if (x == 0.0) { memcpy(p, "0.0", 3); return (int)(p + 3 - out); }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof sci, x, std::chars_format::scientific);      // d[.ddd]e[+-]XX
+    char digits[24];
+    int nd = 0;
+    const char* q = sci;
+    for (; q < r.ptr && *q != 'e'; ++q) if (*q != '.') digits[nd++] = *q;
+    int e10 = 0;
+    { const char* e = q + 1; const bool neg = *e == '-'; if (*e == '+' || *e == '-') ++e; for (; e < r.ptr; ++e) e10 = e10 * 10 + (*e - '0'); if (neg) e10 = -e10; }
+    if (x >= 1e-4 && x < 1e16) {
+        if (e10 >= 0) {
+            for (int k = 0; k <= e10; ++k) *p++ = k < nd ? digits[k] : '0';
+            *p++ = '.';
+            if (nd > e10 + 1) { memcpy(p, digits + e10 + 1, (size_t)(nd - e10 - 1)); p += nd - e10 - 1; } else *p++ = '0';
+        } else {
+            *p++ = '0'; *p++ = '.';
+            for (int k = 0; k < -e10 - 1; ++k) *p++ = '0';
+            memcpy(p, digits, (size_t)nd); p += nd;
+        }
+    } else {
+        *p++ = digits[0];
+        if (nd > 1) { *p++ = '.'; memcpy(p, digits + 1, (size_t)(nd - 1)); p += nd - 1; }
+        *p++ = 'e';
+        *p++ = e10 < 0 ? '-' : '+';
+        const int a = e10 < 0 ? -e10 : e10;
+        if (a >= 100) *p++ = (char)('0' + a / 100);
+        *p++ = (char)('0' + a / 10 % 10);
+        *p++ = (char)('0' + a % 10);
+    }
+    return (int)(p - out);
+}
+
+extern "C" int lgio_format_doubles(uint64_t n, const double* x, char* out, uint32_t stride) {
+    return guarded([&] {
+        if ((n && (!x || !out)) || stride < 33) return fail(LGIO_E_ARG, "lgio_format_doubles: NULL argument or stride < 33");
+        for (uint64_t k = 0; k < n; ++k) { char* o = out + k * stride; const int len = format_double_repr(x[k], o); o[len] = 0; }
+        return (int)LGIO_OK;
+    });
+}
+
+static int write_table_impl(const char* path, int append, int header, uint64_t n, uint32_t n_cols, const lgio_table_col* cols, int threads) {
+    if (!path || !n_cols || !cols) return fail(LGIO_E_ARG, "NULL argument");
+    auto plain = [](const char* s) { return s && *s && !strpbrk(s, "\t\"\r\n"); };
+    std::vector<std::vector<std::string>> names(n_cols);
+    for (uint32_t c = 0; c < n_cols; ++c) {
+        const lgio_table_col& col = cols[c];
+        if (!plain(col.name)) return fail(LGIO_E_ARG, "column %u: a name that needs quoting", c);
+        if (col.kind > LGIO_COL_DICT || (n && !col.data)) return fail(LGIO_E_ARG, "column %u: kind %u / no data", c, col.kind);
+        if (col.kind == LGIO_COL_DICT) {
+            names[c].resize(col.n_names);
+            for (uint32_t k = 0; k < col.n_names; ++k) {
+                if (!col.names || !plain(col.names[k])) return fail(LGIO_E_ARG, "column %u: name %u needs quoting", c, k);
+                names[c][k] = col.names[k];
+            }
+            const int32_t* code = static_cast<const int32_t*>(col.data);
+            for (uint64_t k = 0; k < n; ++k)
+                if (code[k] < 0 || (uint32_t)code[k] >= col.n_names) return fail(LGIO_E_ARG, "column %u, row %llu: code out of range", c, (unsigned long long)k);
+        }
+    }
+    if (threads < 1) threads = 1;
+    if (threads > 32) threads = 32;
+    if (n < 100000) threads = 1;
+    std::vector<std::string> buf((size_t)threads);
+    auto format = [&](int t) {
+        const uint64_t k0 = n * (uint64_t)t / (uint64_t)threads, k1 = n * (uint64_t)(t + 1) / (uint64_t)threads;
+        std::string& out = buf[(size_t)t];
+        out.reserve((size_t)(k1 - k0) * 24 * n_cols);
+        char num[40];
+        for (uint64_t k = k0; k < k1; ++k)
+            for (uint32_t c = 0; c < n_cols; ++c) {
+                const lgio_table_col& col = cols[c];
+                if (col.kind == LGIO_COL_DICT) out += names[c][(size_t)static_cast<const int32_t*>(col.data)[k]];
+                else if (col.kind == LGIO_COL_F64) out.append(num, (size_t)format_double_repr(static_cast<const double*>(col.data)[k], num));
+                else {
+                    const int64_t v = static_cast<const int64_t*>(col.data)[k];
+                    const bool neg = v < 0;
+                    uint64_t u = neg ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+                    int at = 24;
+                    do { num[--at] = (char)('0' + u % 10); u /= 10; } while (u);
+                    if (neg) num[--at] = '-';
+                    out.append(num + at, (size_t)(24 - at));
+                }
+                out += c + 1 < n_cols ? '\t' : '\n';
+            }
+    };
+    {
+        std::vector<std::thread> th;
+        int started = 1;
+        for (; started < threads; ++started) { try { th.emplace_back(format, started); } catch (...) { break; } }
+        format(0);
+        for (int t = started; t < threads; ++t) format(t);           // (threads the system refused: their ranges here)
+        for (auto& x : th) x.join();
+    }
+    FILE* f = fopen(path, append ? "ab" : "wb");
+    if (!f) return fail(LGIO_E_IO, "cannot open %s for writing", path);
+    bool ok = true;
+    if (header) {
+        std::string h;
+        for (uint32_t c = 0; c < n_cols; ++c) { h += cols[c].name; h += c + 1 < n_cols ? '\t' : '\n'; }
+        ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+    }
+    for (const std::string& b : buf) if (ok && !b.empty()) ok = fwrite(b.data(), 1, b.size(), f) == b.size();
+    if (fclose(f) != 0) ok = false;
+    return ok ? LGIO_OK : fail(LGIO_E_IO, "writing %s failed", path);
+}
+extern "C" int lgio_write_table(const char* path, int append, int header, uint64_t n_rows, uint32_t n_cols, const lgio_table_col* cols,
+                                int threads) {
+    return guarded([&] { return write_table_impl(path, append, header, n_rows, n_cols, cols, threads); });
 }
 
 extern "C" uint64_t lgio_bam_bytes_read(const lgio_bam* b) { return b ? b->z.bytes_read : 0; }

@@ -172,11 +172,36 @@ class _PairsWriter:
     def __init__(self, path):
         self.final, self.path, self.parts, self.held, self.n_held = path, path + '.partial', 0, [], 0
 
-    def __call__(self, df):
+    def __call__(self, df, codes=None):
+        if self._write_native(df, codes):
+            return
         self.held.append(df)
         self.n_held += len(df)
         if self.n_held >= self.FLUSH_ROWS:
             self._flush()
+
+    def _write_native(self, df, codes):
+        """a chunk whose string columns came with dictionary codes (lgmi.mutual_information.regions_pair_mi_table) is
+        formatted by liblgmi_io (lgio_write_table: the bytes to_csv writes, floats included — tested against numpy on
+        millions of values); anything else, and a name pandas would quote, goes through pandas"""
+        if not codes or os.environ.get('LGMI_PANDAS_TABLES'):
+            return False
+        columns = []
+        for c in df.columns:
+            if c in codes:
+                columns.append((c,) + tuple(codes[c]))
+            elif df[c].dtype.kind in 'iuf':
+                columns.append((c, df[c].to_numpy()))
+            else:
+                return False
+        self._flush()                                       # (parts are appended in the order they came)
+        from .io import write_table
+        try:
+            write_table(self.path, columns, header=(self.parts == 0), append=(self.parts > 0))
+        except ValueError:
+            return False
+        self.parts += 1
+        return True
 
     def _flush(self):
         if self.held:

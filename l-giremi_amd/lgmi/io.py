@@ -99,7 +99,55 @@ IO_SYMBOLS = {
     'lgio_intervals_free': (None, [C.POINTER(_Intervals)]),
     'lgio_write_removed_table': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int8), _i64p,
                                            C.POINTER(C.c_int8), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_int]),
+    'lgio_write_table': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int]),
+    'lgio_format_doubles': (C.c_int, [C.c_uint64, C.POINTER(C.c_double), C.c_char_p, C.c_uint32]),
 }
+
+
+class _TableCol(C.Structure):           # include/lgmi_io.h: lgio_table_col
+    _fields_ = [('name', C.c_char_p), ('kind', C.c_uint32), ('n_names', C.c_uint32), ('data', C.c_void_p), ('names', C.POINTER(C.c_char_p))]
+
+
+def write_table(path, columns, header=True, append=False, threads=4):
+    """lgio_write_table: a tab-separated table as pandas' to_csv(sep='\\t', index=False) writes it.  ``columns``: a list of
+    (name, values) — an integer array, a float array — or (name, codes, names) for a string column held as dictionary codes.
+    Raises ValueError when a name would need quoting (the caller takes pandas)."""
+    lib = load_io()
+    cols = (_TableCol * max(len(columns), 1))()
+    keep, n = [], None
+    for k, col in enumerate(columns):
+        if len(col) == 3:
+            name, codes, names = col
+            a = np.ascontiguousarray(codes, np.int32)
+            arr = (C.c_char_p * max(len(names), 1))(*[str(x).encode() for x in names])
+            cols[k].kind, cols[k].n_names, cols[k].names = 2, len(names), arr
+            keep.append(arr)
+        else:
+            name, values = col
+            values = np.asarray(values)
+            if values.dtype.kind == 'f':
+                a, cols[k].kind = np.ascontiguousarray(values, np.float64), 1
+            elif values.dtype.kind in 'iu':
+                a, cols[k].kind = np.ascontiguousarray(values, np.int64), 0
+            else:
+                raise ValueError('column %r: dtype %s is not one the native writer takes' % (name, values.dtype))
+        if n is None:
+            n = len(a)
+        elif len(a) != n:
+            raise ValueError('column %r has %d rows, the first one %d' % (name, len(a), n))
+        cols[k].name, cols[k].data = str(name).encode(), a.ctypes.data if a.size else None
+        keep.append(a)
+    _check(lib.lgio_write_table(str(path).encode(), 1 if append else 0, 1 if header else 0, n or 0, len(columns), C.addressof(cols), int(threads)))
+
+
+def format_doubles(values):
+    """lgio_format_doubles: every value as the native table writer writes it (tests: against numpy's astype(str))"""
+    lib = load_io()
+    a = np.ascontiguousarray(values, np.float64)
+    buf = C.create_string_buffer(max(len(a), 1) * 40)
+    _check(lib.lgio_format_doubles(len(a), a.ctypes.data_as(C.POINTER(C.c_double)), buf, 40))
+    raw = np.frombuffer(buf, dtype='S40', count=len(a))
+    return [x.decode() for x in raw.tolist()]
 
 
 def write_removed_table(path, chrom_names, reason_names, chrom_code, strand, pos, reason_code, header=True, append=False, threads=4):
@@ -127,8 +175,8 @@ def load_io():
         for name, (res, args) in IO_SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.lgio_abi_version() != 3:
-            raise RuntimeError('liblgmi_io.so ABI %d != binding ABI 3 (rebuild with `make -C l-giremi_amd`)' % lib.lgio_abi_version())
+        if lib.lgio_abi_version() != 4:
+            raise RuntimeError('liblgmi_io.so ABI %d != binding ABI 4 (rebuild with `make -C l-giremi_amd`)' % lib.lgio_abi_version())
         _iolib = lib
     return _iolib
 

@@ -507,7 +507,7 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     chunk's own batch on the GPU (``stream_site_base`` = the sites before it: pair for pair the permutation draws of the one
     batch holding every footprint), builds its rows of the two site tables and hands its part of the removed-site table to
     ``removed_sink`` (a callable taking a DataFrame; the returned df_removed is then empty); ``pairs_sink`` (a callable taking a
-    chunk's pair rows as a DataFrame, in order) lets the caller write the pair table while the run goes on — the returned
+    chunk's pair rows as a DataFrame, in order, and its string columns as dictionary codes — regions_pair_mi_table: codes_out) lets the caller write the pair table while the run goes on — the returned
     df_pairs is still the whole table."""
     import time
     t0 = time.perf_counter()
@@ -536,12 +536,13 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
                 for part, b, extras in parts:
                     t1 = time.perf_counter()
                     kw = {'site_base': site_base} if site_base else {}
+                    codes = {} if pairs_sink is not None else None
                     df_c, means_c = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in part], min_common_reads,
-                                                          n_shuffles=n_shuffles, seed=seed, engine=engine, batch=b, **kw)
+                                                          n_shuffles=n_shuffles, seed=seed, engine=engine, batch=b, codes_out=codes, **kw)
                     site_base += len(b.site_pos) if b is not None else 0
                     pair_frames.append(df_c)
                     if pairs_sink is not None and len(df_c):
-                        pairs_sink(df_c)
+                        pairs_sink(df_c, codes)
                     t2 = time.perf_counter()
                     # the worker made the footprints' rows of the mismatch table; their last column is the GPU's per-site mean
                     for rows, mean_mi in zip(extras['site_rows'], means_c):

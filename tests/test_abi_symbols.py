@@ -37,7 +37,7 @@ def test_io_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), 'liblgmi_io.so does not export %s' % name
     assert sorted(io.IO_SYMBOLS) == names
-    assert io.load_io().lgio_abi_version() == 3
+    assert io.load_io().lgio_abi_version() == 4
     assert C.sizeof(io._Reads) == 152 and C.sizeof(io._Pileup) == 48 + 152
 
 

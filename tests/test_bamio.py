@@ -487,3 +487,23 @@ def test_fasta_index_without_fai_matches_the_line_by_line_pass(tmp_path):
         with open(path, 'wb') as f:
             f.write(raw)
         assert FastaReader._scan_fast(path) == FastaReader._scan(path), raw
+
+
+def test_native_float_text_equals_numpy():
+    """lgio_format_doubles (what lgio_write_table writes for a float64) against numpy's astype(str) — what pandas' to_csv
+    writes: random bit patterns, magnitudes from 1e-12 to 1e20, uniform values, whole numbers, p-values k / 1001, and the
+    edges of the positional / scientific switch"""
+    from lgmi.io import format_doubles
+    rng = np.random.default_rng(1)
+    specials = np.array([0.0, -0.0, 1.0, -1.0, 0.1, 1e-4, 9.999999999999999e-5, 1e-5, 1e16, 9999999999999998.0, 1e15,
+                         123456789012345.0, 1e22, 1e100, 1e-100, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                         np.inf, -np.inf, np.nan, 0.000999000999000999, 1 / 3, 2 / 3, 1e-7, 1.5e-7, 123456.789, 100.0, 1e23, 8.41e21])
+    bits = rng.integers(0, 2 ** 63, 60000, dtype=np.int64).view(np.float64)
+    x = np.concatenate([specials, bits[np.isfinite(bits)], 10.0 ** rng.uniform(-12, 20, 60000) * rng.choice([-1, 1], 60000),
+                        rng.random(60000), rng.integers(-10 ** 6, 10 ** 6, 20000).astype(np.float64), np.round(rng.random(20000), 3),
+                        rng.integers(1, 1002, 20000) / 1001.0])
+    want = x.astype(str)
+    want[np.isnan(x)] = ''
+    got = format_doubles(x)
+    bad = [(a, b, c) for a, b, c in zip(x.tolist(), got, want.tolist()) if b != c]
+    assert not bad, bad[:5]

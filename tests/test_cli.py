@@ -149,7 +149,7 @@ def test_cli_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
-    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None, site_base=0):
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None, site_base=0, codes_out=None):
         blocks = oracle_blocks(regions, mc)
         cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
         return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),
@@ -224,7 +224,7 @@ def test_cli_cfg1_host_side_matches_the_reference(tmp_path, monkeypatch):
 
         def close(self):
             pass
-    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None, site_base=0):
+    def oracle_table(regions, mc=5, n_shuffles=0, seed=0, engine=None, batch=None, site_base=0, codes_out=None):
         blocks = oracle_blocks(regions, mc)
         cols = ['chromosome', 'strand', 'site1_pos', 'site1_type', 'site2_pos', 'site2_type', 'mi']
         return (pd.DataFrame.from_records([r for recs, _m, _p in blocks for r in recs], columns=cols),
@@ -368,3 +368,35 @@ def test_pair_table_written_in_parts_matches_one_to_csv(tmp_path):
     w(df.iloc[:5])
     w.abort()
     assert not os.path.exists(w.path) and not os.path.exists(w.final)
+    # chunks that bring dictionary codes for their string columns are written natively (lgio_write_table): the same bytes,
+    # also mixed with chunks that do not, and with a name pandas would quote (that chunk falls back)
+    types = np.array(['het_snp', 'mismatch', 'edit'], dtype=object)
+    chroms = np.array(['chr1', 'chr\t2'], dtype=object)
+    cc, t1, t2 = rng.integers(0, 2, n), rng.integers(0, 3, n), rng.integers(0, 3, n)
+    mi = df['mi'].to_numpy().copy()
+    mi[::97] = np.nan
+    mi[5] = 1e-7
+    mi[6] = 123456789012345680.0
+    full = pd.DataFrame({'chromosome': np.array(['chr1', 'chr2'], dtype=object)[cc], 'strand': np.array(['+', '-'], dtype=object)[cc ^ 1],
+                         'site1_pos': df['site1_pos'], 'site1_type': types[t1], 'site2_pos': df['site2_pos'], 'site2_type': types[t2],
+                         'mi': mi, 'p_perm': df['p_perm']})
+
+    def codes_of(sl, names=('chr1', 'chr2')):
+        return {'chromosome': (cc[sl].astype(np.int32), list(names)), 'strand': ((cc[sl] ^ 1).astype(np.int32), ['+', '-']),
+                'site1_type': (t1[sl].astype(np.int32), list(types)), 'site2_type': (t2[sl].astype(np.int32), list(types))}
+
+    full.to_csv(want, sep='\t', index=False)
+    w = _PairsWriter(str(tmp_path / 'native.txt'))
+    w.FLUSH_ROWS = 900
+    for k, (a, b) in enumerate(((0, 700), (700, 800), (800, 2000), (2000, 2001), (2001, n))):
+        sl = slice(a, b)
+        w(full.iloc[sl], codes_of(sl) if k != 1 else None)                      # (the second chunk without codes: pandas, in order)
+    w.close(full)
+    assert filecmp.cmp(want, w.final, shallow=False)
+    odd = full.iloc[:50].copy()
+    odd['chromosome'] = chroms[cc[:50]]
+    odd.to_csv(want, sep='\t', index=False)
+    w = _PairsWriter(str(tmp_path / 'quoted.txt'))
+    w(odd, codes_of(slice(0, 50), names=tuple(chroms)))
+    w.close(odd)
+    assert filecmp.cmp(want, w.final, shallow=False)
