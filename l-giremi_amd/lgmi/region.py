@@ -369,6 +369,8 @@ def _extract_chunk(job, sam=None, genome=None):
     reopen, footprints, filter_kwargs = job[:3]
     compact = len(job) > 3 and job[3]
     pack = len(job) > 4 and job[4]
+    import time
+    t_job = time.time()
     if reopen is not None:
         sam, genome = reopen()
     out = []
@@ -410,6 +412,8 @@ def _extract_chunk(job, sam=None, genome=None):
         nothing = {'+': {}, '-': {}}
         extras = {'site_rows': [_site_rows(chrom, sites, nothing) for chrom, sites, _gone in out],
                   'removed': _removed_arrays(out) if compact else None}
+        if os.environ.get('LGMI_TRACE_JOBS'):                   # when this job ran, and where (the pipeline's parent prints them)
+            extras['job'] = (os.getpid(), t_job, time.time())
         return out, batch, extras
     return out
 
@@ -533,8 +537,11 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
                 site_base, site_rows, pair_frames, removed_frames = 0, [], [], []
                 chrom_code, reason_code = {}, {}
                 nan = float('nan')
+                trace_jobs = [] if os.environ.get('LGMI_TRACE_JOBS') else None
                 for part, b, extras in parts:
                     t1 = time.perf_counter()
+                    if trace_jobs is not None:
+                        trace_jobs.append(extras.get('job', (0, 0.0, 0.0)) + (time.time(),))
                     kw = {'site_base': site_base} if site_base else {}
                     codes = {} if pairs_sink is not None else None
                     df_c, means_c = regions_pair_mi_table([(sites, chrom) for chrom, sites, _gone in part], min_common_reads,
@@ -570,6 +577,11 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
                                                    else np.concatenate([f[c].to_numpy() for f in removed_frames]))
                                                for c in ('chromosome', 'strand', 'pos', 'removed')}) if removed_frames \
                         else _removed_frame([], {}, {})
+                if trace_jobs:
+                    import sys
+                    base = min(j[1] for j in trace_jobs)
+                    for k, (pid, a, b_, got) in enumerate(trace_jobs):
+                        print('[lgmi jobs] %3d pid %d ran %.3f - %.3f s, received %.3f s' % (k, pid, a - base, b_ - base, got - base), file=sys.stderr)
                 if timing is not None:
                     timing['extract_s'] = time.perf_counter() - t0          # the pipeline's wall time: extraction with the
                     timing['pack_gpu_table_s'] = t_gpu                       # parent's GPU and table work (listed beside it)
