@@ -414,6 +414,10 @@ def _extract_chunk(job, sam=None, genome=None):
                   'removed': _removed_arrays(out) if compact else None}
         if os.environ.get('LGMI_TRACE_JOBS'):                   # when this job ran, and where (the pipeline's parent prints them)
             extras['job'] = (os.getpid(), t_job, time.time())
+        if len(job) > 5 and job[5] and compact:
+            # the pipeline's parent reads the removed sites from extras['removed'] only: the per-footprint arrays — the same
+            # 15 million rows once more — need not cross the process boundary (they were half of what a job sent back)
+            out = [(chrom, sites, None) for chrom, sites, _gone in out]
         return out, batch, extras
     return out
 
@@ -526,7 +530,8 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
         # parent creates its HIP context only after the workers exist (fork).
         import multiprocessing as mp
         chunk = max(1, -(-len(footprints) // (4 * threads)))
-        jobs = [(reopen, footprints[k:k + chunk], filter_kwargs, bool(concat), bool(concat))
+        lean = bool(concat and not multi_rank)                  # (the pipelined run below)
+        jobs = [(reopen, footprints[k:k + chunk], filter_kwargs, bool(concat), bool(concat), lean)
                 for k in range(0, len(footprints), chunk)]
         with mp.get_context('fork').Pool(threads) as pool:
             if concat and not multi_rank:
