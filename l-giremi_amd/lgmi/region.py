@@ -480,6 +480,9 @@ def _ordered_parts(pool, fn, jobs, poll_s=0.5):
     worker's job never comes back, so a plain imap would wait for ever.  The set of worker pids is taken when the pool is
     new and looked at between results: any change ends the run with an error instead."""
     import multiprocessing as mp
+    if not hasattr(pool, '_pool'):                              # (not the multiprocessing.Pool this was written against)
+        yield from pool.imap(fn, jobs)
+        return
     pids = sorted(p.pid for p in list(pool._pool))
     it = pool.imap(fn, jobs)
     while True:
