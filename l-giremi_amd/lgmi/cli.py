@@ -345,8 +345,7 @@ def main(argv=None):
     timing = {}
     t_all = t0 = time.perf_counter()
     import os
-    from .engine import Engine
-    from .region import regions_mismatch_analysis
+    from . import region as _region                      # (loaded before the workers are forked: they run its _extract_chunk)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if args.gpus is not None and args.gpus != world:
@@ -356,6 +355,26 @@ def main(argv=None):
     if world > 1:
         from .dist import group_from_env
         group = group_from_env()                         # plain sockets: the RCCL id, barriers, small gathers
+    # the extraction workers of a one-rank run are forked HERE, while this process is still small (a fork copies the page
+    # tables of everything loaded so far: sixteen of them after the index, the variants and 8,000 footprints were a quarter
+    # of a second) and long before the HIP context exists; they wait for their jobs (regions_mismatch_analysis: pool)
+    pool = None
+    if world == 1 and args.thread and args.thread > 1:
+        import multiprocessing as mp
+        pool = mp.get_context('fork').Pool(args.thread)
+    try:
+        return _run(args, timing, t_all, t0, world, rank, group, pool)
+    finally:
+        if pool is not None:
+            pool.terminate()
+            pool.join()
+
+
+def _run(args, timing, t_all, t0, world, rank, group, pool):
+    import os
+    import time
+    from .engine import Engine
+    from .region import regions_mismatch_analysis
     sam = open_alignment(args.bam_file)
     genome = open_fasta(args.genome_fasta)
     vcf = open_variants(args.snp_bcf) if args.snp_bcf else None
@@ -404,13 +423,16 @@ def main(argv=None):
         return made[0]
     # one rank: the removed-site table (one row per covered position: most of what a run writes) goes out part by part
     # while later footprints are still being extracted
+    fai = getattr(genome, 'index', None)
+    if fai is not None and len(fai) > 4096:
+        fai = None                                         # (it travels with every job: a transcriptome's 200,000 entries would not pay; the workers index once each)
     removed_writer = _RemovedWriter(args.output_prefix + '.removed.txt') if world == 1 else None
     pairs_writer = _PairsWriter(args.output_prefix + '.mi.txt') if world == 1 else None
     try:
         df_sites, df_mi, df_removed = regions_mismatch_analysis(
             jobs, sam, genome, min_common_reads=args.mi_min_common_read, n_shuffles=args.n_shuffles, seed=args.seed,
-            engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta, fai=getattr(genome, 'index', None)), timing=timing,
-            group=group, removed_sink=removed_writer, pairs_sink=pairs_writer,
+            engine=make_engine, concat=True, threads=args.thread, reopen=_Reopen(args.bam_file, args.genome_fasta, fai=fai), timing=timing,
+            group=group, removed_sink=removed_writer, pairs_sink=pairs_writer, pool=pool,
             keep_non_spliced_read=args.keep_non_spliced_read,
             min_dist_from_splice=args.min_dist_from_splice, min_allele_depth=args.min_allele_depth,
             min_allele_ratio=args.min_allele_ratio, min_total_depth=args.min_total_depth,

@@ -503,7 +503,7 @@ def _ordered_parts(pool, fn, jobs, poll_s=0.5):
 
 def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shuffles=0, seed=0, engine=None,
                               concat=False, threads=1, reopen=None, timing=None, group=None, removed_sink=None,
-                              pairs_sink=None, **filter_kwargs):
+                              pairs_sink=None, pool=None, **filter_kwargs):
     """``region_mismatch_analysis`` over many footprints with the MI blocks of many footprints per GPU batch — the shape the
     reference's per-chunk loop (src/giremi/script/giremi.py:32-88) takes when the MI step is a device call.
 
@@ -518,7 +518,8 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
     chunk's own batch on the GPU (``stream_site_base`` = the sites before it: pair for pair the permutation draws of the one
     batch holding every footprint), builds its rows of the two site tables and hands its part of the removed-site table to
     ``removed_sink`` (a callable taking a DataFrame; the returned df_removed is then empty); ``pairs_sink`` (a callable taking a
-    chunk's pair rows as a DataFrame, in order, and its string columns as dictionary codes — regions_pair_mi_table: codes_out) lets the caller write the pair table while the run goes on — the returned
+    chunk's pair rows as a DataFrame, in order, and its string columns as dictionary codes — regions_pair_mi_table: codes_out);
+    ``pool``: a multiprocessing pool of forked workers to use instead of making one (the caller forked it while still small) lets the caller write the pair table while the run goes on — the returned
     df_pairs is still the whole table."""
     import time
     t0 = time.perf_counter()
@@ -536,7 +537,9 @@ def regions_mismatch_analysis(footprints, sam, genome, min_common_reads=5, n_shu
         lean = bool(concat and not multi_rank)                  # (the pipelined run below)
         jobs = [(reopen, footprints[k:k + chunk], filter_kwargs, bool(concat), bool(concat), lean)
                 for k in range(0, len(footprints), chunk)]
-        with mp.get_context('fork').Pool(threads) as pool:
+        import contextlib
+        # `pool`: the caller's pool of forked workers (made before it loaded its inputs: lgmi.cli) — used, not closed
+        with (contextlib.nullcontext(pool) if pool is not None else mp.get_context('fork').Pool(threads)) as pool:
             if concat and not multi_rank:
                 parts = _ordered_parts(pool, _extract_chunk, jobs)    # in job order, as they finish
                 if callable(engine) and not hasattr(engine, 'run'):
