@@ -376,12 +376,28 @@ def _run(args, timing, t_all, t0, world, rank, group, pool):
     from .engine import Engine
     from .region import regions_mismatch_analysis
     sam = open_alignment(args.bam_file)
-    genome = open_fasta(args.genome_fasta)
-    vcf = open_variants(args.snp_bcf) if args.snp_bcf else None
-    repeats = read_repeats(args.repeat_txt)
-
+    # the footprint scan (native, on its own threads, no interpreter lock) runs while this thread indexes the genome and
+    # reads the variants
+    import threading
     logging.info('Get regions that are covered by enough reads.')
-    footprints = get_footprints(sam, args.chromosomes, args.min_total_depth)
+    scan = {}
+
+    def scan_footprints():
+        try:
+            scan['footprints'] = get_footprints(sam, args.chromosomes, args.min_total_depth)
+        except BaseException as e:                          # noqa: BLE001 — raised again below, in the thread that owns the run
+            scan['error'] = e
+    scanner = threading.Thread(target=scan_footprints, name='lgmi-footprints')
+    scanner.start()
+    try:
+        genome = open_fasta(args.genome_fasta)
+        vcf = open_variants(args.snp_bcf) if args.snp_bcf else None
+        repeats = read_repeats(args.repeat_txt)
+    finally:
+        scanner.join()
+    if 'error' in scan:
+        raise scan['error']
+    footprints = scan['footprints']
     if world > 1:
         # contiguous runs of footprints balanced by read count (the reference cuts the footprint list into contiguous
         # chunks too, script/giremi.py:367-370): rank order stays footprint order, which is the output order
